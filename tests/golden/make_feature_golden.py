@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/*.npz|*.tsv from the reference's own data fixtures.
+
+Run in the dev container only (needs /root/reference, which never travels):
+
+    python tests/golden/make_feature_golden.py
+
+Outputs (data only - inputs and expected outputs, no reference source text):
+
+  features_golden.npz
+      on[6960], off[6960]        23-mers  (workflow/data-objects/datasetsSampling.RData,
+                                  built by workflow/processDataForModel.R:378-394)
+      feat[6960, 442] uint8      the 442 sequence features of every pair, in the column order
+                                  of variant_processing/feature_matrix.h:155-202
+                                  (workflow/data-objects/featureMatrix.RData, built by
+                                  workflow/evalFunctions.R:7-126 via classificationModel.R:21-23)
+      names[442]                 column names as stored in the RData
+      activity[6960] float64     the ontargetActivity column (col 442)
+  siteseq_pairs.tsv
+      4443 (on, off, NM, strand) pairs incl. non-GG PAMs, NM up to 14
+      (workflow/data-objects/offtargetBiochemicalData.RData) - inputs only.
+  crispor_mit.tsv
+      (guide, offtarget, mitOfftargetScore) rows of
+      workflow/pipeline-comparison/crispor-siteseq-offtargets.txt for which CRISPOR's
+      formula coincides with variant_processing/mit_score.h:12-68 (fewer than two
+      mismatches in the 20-mer, or sum of consecutive distances divisible by their count;
+      CRISPOR floors the mean, VARSCOT does not - SURVEY.md section 4).
+  guides_ontargets.tsv
+      the 9 GUIDE-seq + 7 SITE-seq on-target 23-mers with their activity values
+      (workflow/guideseq-data/guideseqOntargets.fasta, guideseqOntargetActivity.txt,
+       workflow/siteseq-data/siteseqOntargets.fasta, siteseqOntargetActivity.txt).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from rdata_reader import data_frame, load_rdata  # noqa: E402
+
+REF = "/root/reference/workflow"
+
+
+def main():
+    ds = load_rdata(f"{REF}/data-objects/datasetsSampling.RData")["datasetsSampling"]
+    fm = load_rdata(f"{REF}/data-objects/featureMatrix.RData")["featureMatrix"]
+    on, off, feat, act = [], [], [], []
+    names = None
+    for d, f in zip(ds["val"], fm["val"]):
+        d = data_frame(d)
+        f = data_frame(f)
+        cols = list(f.keys())
+        assert cols[0] == "offtargetActivity" and cols[-1] == "ontargetActivity" and len(cols) == 444
+        if names is None:
+            names = cols[1:-1]
+        assert names == cols[1:-1]
+        n = len(d["Target_Sequence"])
+        on += d["Target_Sequence"]
+        off += d["Offtarget_Sequence"]
+        m = np.zeros((n, 442), dtype=np.uint8)
+        for j, c in enumerate(names):
+            m[:, j] = np.asarray([int(float(v)) for v in f[c]], dtype=np.uint8)
+        feat.append(m)
+        act += [float(v) for v in f["ontargetActivity"]]
+    feat = np.concatenate(feat)
+    assert feat.shape == (6960, 442), feat.shape
+    np.savez_compressed(f"{HERE}/features_golden.npz", on=np.array(on), off=np.array(off), feat=feat,
+                        names=np.array(names), activity=np.array(act))
+    print("features_golden.npz", feat.shape)
+
+    bd = data_frame(load_rdata(f"{REF}/data-objects/offtargetBiochemicalData.RData")["offtargetBiochemicalData"])
+    with open(f"{HERE}/siteseq_pairs.tsv", "w") as out:
+        out.write("#on\toff\tNM\tstrand\n")
+        for a, b, nm, s in zip(bd["Target_Sequence"], bd["Offtarget_Sequence"], bd["NM"], bd["Strand"]):
+            out.write(f"{a}\t{b}\t{int(nm)}\t{s}\n")
+    print("siteseq_pairs.tsv", len(bd["Chr"]))
+
+    kept = 0
+    with open(f"{REF}/pipeline-comparison/crispor-siteseq-offtargets.txt") as f, \
+            open(f"{HERE}/crispor_mit.tsv", "w") as out:
+        out.write("#guide\tofftarget\tmitOfftargetScore\n")
+        next(f)
+        seen = set()
+        for line in f:
+            p = line.rstrip("\n").split("\t")
+            g, o, score = p[1], p[2], p[4]
+            if len(g) != 23 or len(o) != 23 or (g, o) in seen:
+                continue
+            pos = [i for i in range(20) if g[i] != o[i]]
+            if len(pos) >= 2 and (pos[-1] - pos[0]) % (len(pos) - 1) != 0:
+                continue
+            seen.add((g, o))
+            out.write(f"{g}\t{o}\t{score}\n")
+            kept += 1
+    print("crispor_mit.tsv", kept)
+
+    rows = []
+    for fa, actf in (("guideseq-data/guideseqOntargets.fasta", "guideseq-data/guideseqOntargetActivity.txt"),
+                     ("siteseq-data/siteseqOntargets.fasta", "siteseq-data/siteseqOntargetActivity.txt")):
+        acts = {}
+        with open(f"{REF}/{actf}") as f:
+            for line in f:
+                p = line.split()
+                if len(p) >= 3:
+                    try:
+                        acts[p[0]] = float(p[2])
+                    except ValueError:
+                        pass
+        with open(f"{REF}/{fa}") as f:
+            name = None
+            for line in f:
+                line = line.strip()
+                if line.startswith(">"):
+                    name = line[1:]
+                elif line:
+                    rows.append((name, line, acts.get(name)))
+    with open(f"{HERE}/guides_ontargets.tsv", "w") as out:
+        out.write("#name\tsequence\tactivity\n")
+        for r in rows:
+            out.write("%s\t%s\t%r\n" % r)
+    print("guides_ontargets.tsv", len(rows))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,218 @@
+"""CPU-only: pins the oracle (oracle/) against the reference's golden vectors and checks its two
+search formulations (SURVEY.md 8.1 predicate vs bidir_mapping.cpp control flow) and the
+bit-parallel port against each other."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import hits_as_tuples, make_genome, mutate, random_guides, random_seq, revcomp
+
+
+# ---------------------------------------------------------------- feature matrix (row R6)
+def test_features_match_reference_golden(oracle, golden_dir):
+    """All 6960 x 442 values of workflow/data-objects/featureMatrix.RData."""
+    g = np.load(os.path.join(golden_dir, "features_golden.npz"))
+    on, off, feat = g["on"], g["off"], g["feat"]
+    assert feat.shape == (6960, 442)
+    bad = 0
+    for i in range(len(on)):
+        row = oracle.feature_row(str(on[i]), str(off[i]))
+        if not np.array_equal(row, feat[i].astype(np.uint32)):
+            bad += 1
+    assert bad == 0
+
+
+def test_feature_names_layout(golden_dir):
+    """Column order of variant_processing/feature_matrix.h:155-202 as stored in the RData."""
+    names = list(np.load(os.path.join(golden_dir, "features_golden.npz"))["names"])
+    assert names[0] == "totalMismatches" and names[1] == "mismatchPos1" and names[21] == "mismatchPos21"
+    assert names[22:34] == ["AtoC", "AtoG", "AtoT", "CtoA", "CtoG", "CtoT", "GtoA", "GtoC", "GtoT", "TtoA", "TtoC", "TtoG"]
+    assert names[34:36] == ["transitionNumber", "transversionNumber"]
+    assert names[36] == "A1" and names[115] == "T20" and names[116:120] == ["PAMA", "PAMC", "PAMG", "PAMT"]
+    assert names[120] == "AA1" and names[423] == "TT19" and names[424] == "AA" and names[439] == "TT"
+    assert names[440:442] == ["adjacentMismatches", "seedMismatches"]
+
+
+# ---------------------------------------------------------------- MIT score (row R5)
+# Known answers listed in SURVEY.md section 8 row R5 (produced from variant_processing/mit_score.h).
+MIT_KATS = [
+    ([-1], "100"), ([0], "100"), ([19], "41.7"), ([20], "100"), ([5, 7], "3.30316"), ([1, 3, 8], "1.59246"),
+    ([3, 12, 19], "0.540776"), ([3, 12, 20], "3.11568"), ([0, 22], "100"),
+    ([2, 5, 9, 13, 17, 19], "0.00433807"), ([1, 2, 10, 11, 12, 13, 14, 19], "0.000608023"),
+    ([0, 1, 2, 3, 4, 5, 6, 7], "0.132918"),
+]
+
+
+@pytest.mark.parametrize("pos,expected", MIT_KATS)
+def test_mit_known_answers(oracle, pos, expected):
+    s, ub = oracle.mit_score(pos)
+    assert "%g" % s == expected  # default ostream formatting = 6 significant digits
+    assert not ub
+
+
+def test_mit_exact_bits(oracle):
+    s, _ = oracle.mit_score([5, 7])
+    assert s.hex() == "0x1.a6cdfa1d6cdf9p+1"
+
+
+def test_mit_reference_ub_is_flagged(oracle):
+    # two positions >= 20: the reference indexes its 20-entry weight vector out of bounds (8.2 Q2)
+    s, ub = oracle.mit_score([3, 20, 22])
+    assert ub and s > 0
+
+
+def test_mit_against_crispor_rows(oracle, golden_dir):
+    """Rows of the reference's CRISPOR table where CRISPOR's formula coincides with mit_score.h."""
+    n = 0
+    with open(os.path.join(golden_dir, "crispor_mit.tsv")) as f:
+        next(f)
+        for line in f:
+            g, o, score = line.split()
+            pos = [i for i in range(20) if g[i] != o[i]] or [-1]
+            s, ub = oracle.mit_score(pos)
+            assert not ub
+            assert s == pytest.approx(float(score), rel=1e-9), (g, o)
+            n += 1
+    assert n == 2425
+
+
+# ---------------------------------------------------------------- MD strings
+def test_md_styles_and_reference_parser(oracle):
+    w = "ACGTACGTACGTACGTACGTAGG"
+    r = "ACGTACGTACGTACGTACGTAGG"
+    assert oracle.md_string(w, r, 0) == "23" and oracle.md_positions("23") == [-1]
+    r2 = "TCGTAGCTACGTACGTACGTAGC"  # mismatches at 0, 5, 6, 22
+    assert oracle.md_string(w, r2, 0) == "0A4C0G15G0"
+    assert oracle.md_positions("0A4C0G15G0") == [0, 5, 6, 22]
+    assert oracle.md_string(w, r2, 1) == "A4CG15G"
+    # filter_output_bam.h:338-342 stops at the first token that is not <number><char>
+    assert oracle.md_positions("A4CG15G") == [-1]
+    assert oracle.md_positions("5AC16") == [5]
+
+
+# ---------------------------------------------------------------- search: predicate == reference flow
+def _r4_order(block):
+    """bidir_mapping.cpp:167-187 applied to one (guide, strand) block sorted by (contig, pos)."""
+    out, best = [], 0
+    for i in range(1, len(block)):
+        if block[i][4] >= block[best][4]:
+            out.append(block[i] + (1,))
+        else:
+            out.append(block[best] + (1,))
+            best = i
+    out.append(block[best] + (0,))
+    return out
+
+
+@pytest.mark.parametrize("seed,max_mm,extra_pam", [(1, 0, None), (2, 1, None), (3, 2, None), (4, 3, "AG"),
+                                                    (5, 4, None), (6, 5, "TT"), (7, 6, None), (8, 7, None),
+                                                    (9, 8, None), (10, 8, "CC")])
+def test_predicate_equals_reference_flow(oracle, seed, max_mm, extra_pam):
+    rng = np.random.default_rng(seed)
+    guides = random_guides(rng, 6) + [random_seq(rng, 23)]
+    contigs = make_genome(seed, [3000, 22, 23, 24, 700, 5, 1500], guides, max_mm)
+    a = oracle.search(contigs, guides, max_mm, extra_pam, mode=oracle.MODE_PREDICATE)
+    b = oracle.search(contigs, guides, max_mm, extra_pam, mode=oracle.MODE_REFERENCE_FLOW)
+    ta, tb = hits_as_tuples(a), hits_as_tuples(b)
+    assert len(ta) > 10
+    assert sorted(ta) == sorted(tb)
+    assert ta == sorted(ta)
+    # emission order and secondary flags of the reference flow
+    expect = []
+    blocks = {}
+    for t in ta:
+        blocks.setdefault((t[0], t[1]), []).append(t)
+    for key in sorted(blocks):
+        expect += _r4_order(blocks[key])
+    got = [t + (int(i >> 30) & 1,) for t, i in zip(tb, b["info"])]
+    assert got == expect
+
+
+def test_hits_are_sound(oracle):
+    """Every reported hit satisfies the definition when re-derived in plain Python."""
+    rng = np.random.default_rng(77)
+    guides = random_guides(rng, 5)
+    contigs = make_genome(77, [4000, 900], guides, 6)
+    for g, s, c, p, nm, mask in hits_as_tuples(oracle.search(contigs, guides, 6)):
+        w = contigs[c][p:p + 23]
+        r = revcomp(guides[g]) if s else guides[g]
+        assert "N" not in w and len(w) == 23
+        assert (w[21:] in ("GG", "GA")) if not s else (w[:2] in ("CC", "TC"))
+        mm = [i for i in range(23) if w[i] != r[i]]
+        assert len(mm) == nm <= 6 and mask == sum(1 << i for i in mm)
+
+
+def test_right_edge_rule(oracle):
+    """A window that ends exactly at the contig end is only reported through the second-half route
+    (bidir_mapping.cpp:51-52): it needs <= floor(m/2) mismatches in read[11..23)."""
+    g = "ACGTTGCATGCAAGTCCTAGTGG"
+    pad = "T" * 50
+    ok = mutate(np.random.default_rng(1), g, 2, 0, 11)      # errors in the first half only
+    bad = g[:11] + "".join("A" if c != "A" else "C" for c in g[11:14]) + g[14:]  # 3 errors in second half
+    for site, expected in ((ok, 1), (bad, 0)):
+        h = oracle.search([pad + site], [g], 4)            # k = 2
+        assert len(h) == expected
+        h2 = oracle.search([pad + site + "T"], [g], 4)     # one base further in: both routes apply
+        assert len(h2) == 1
+    # reverse strand: the read is revcomp(g); its second half is the first half of g reversed
+    h = oracle.search([pad + revcomp(bad)], [g], 4)
+    assert len(h) == 1
+    h = oracle.search([pad + revcomp(g[:3] + "".join("A" if c != "A" else "C" for c in g[3:6]) + g[6:])], [g], 4)
+    assert len(h) == 0
+
+
+def test_non_acgt_guide_letters_become_A(oracle):
+    contig = "T" * 30 + "AAGTTGCATGCAAGTCCTAGTGG" + "T" * 30
+    h = oracle.search([contig], ["NXGTTGCATGCAAGTCCTAGTGG"], 0)
+    assert len(h) == 1 and h["pos"][0] == 30
+
+
+def test_lowercase_and_iupac_genome(oracle):
+    contig = "t" * 30 + "acgttgcatgcaagtcctagtgg" + "R" + "T" * 30
+    h = oracle.search([contig], ["ACGTTGCATGCAAGTCCTAGTGG"], 0)
+    assert len(h) == 1
+    contig = "t" * 30 + "acgttgcatgcRagtcctagtgg" + "T" * 30
+    assert len(oracle.search([contig], ["ACGTTGCATGCAAGTCCTAGTGG"], 8)) == 0
+
+
+def test_mismatch_budget_is_validated(oracle):
+    with pytest.raises(ValueError):
+        oracle.search(["ACGT" * 20], ["ACGTTGCATGCAAGTCCTAGTGG"], 9)
+
+
+def test_u16_contig_key_compat(oracle):
+    """bidir_mapping.cpp:13: with the uint16_t key a hit in contig 65536 + c at the offset of a hit in
+    contig c is dropped."""
+    g = "ACGTTGCATGCAAGTCCTAGTGG"
+    contigs = ["T" * 5 + g + "T" * 5] + ["TTTT"] * 65535 + ["A" * 5 + g + "A" * 5]
+    full = oracle.search(contigs, [g], 0, mode=oracle.MODE_REFERENCE_FLOW)
+    compat = oracle.search(contigs, [g], 0, mode=oracle.MODE_REFERENCE_FLOW, compat_u16=True)
+    assert len(full) == 2 and len(compat) == 1
+
+
+# ---------------------------------------------------------------- bit-parallel port == restatement
+@pytest.mark.parametrize("seed,max_mm,extra_pam", [(21, 0, None), (22, 3, None), (23, 4, "AG"), (24, 6, None),
+                                                    (25, 8, None), (26, 8, "TA")])
+def test_fast_port_equals_restatement(oracle, seed, max_mm, extra_pam):
+    rng = np.random.default_rng(seed)
+    guides = random_guides(rng, 8) + [random_seq(rng, 23)]
+    contigs = make_genome(seed, [5000, 23, 22, 1200, 64, 2500], guides, max_mm)
+    a = oracle.search(contigs, guides, max_mm, extra_pam)
+    for threads in (1, 3):
+        b = oracle.search_fast(contigs, guides, max_mm, extra_pam, threads=threads)
+        assert hits_as_tuples(a) == hits_as_tuples(b)
+    n, sites = oracle.count_fast(contigs, guides, max_mm, extra_pam)
+    assert n == len(a) and sites > 0
+
+
+def test_sam_text(oracle):
+    g = "ACGTTGCATGCAAGTCCTAGTGG"
+    site = "ACGTTGCATGCAAGTCCTAGTGA"  # GA PAM, 1 mismatch at 22
+    contigs = ["T" * 10 + site + "T" * 10, "C" * 8 + revcomp(g) + "C" * 8]
+    sam = oracle.search_sam(contigs, ["chrA", "chrB"], [g], ["guide1"], 2)
+    lines = sam.splitlines()
+    assert lines == [
+        "guide1\t0\tchrA\t11\t255\t23M\t*\t0\t0\t%s\t%s\tNM:i:1\tMD:Z:22A0" % (g, "I" * 23),
+        "guide1\t16\tchrB\t9\t255\t23M\t*\t0\t0\t%s\t%s\tNM:i:0\tMD:Z:23" % (g, "I" * 23),
+    ]
