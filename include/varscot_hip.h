@@ -1,0 +1,192 @@
+/*
+ * varscot_hip.h - C ABI of libvarscot_hip.so, the MI355X (gfx950) implementation of VARSCOT's
+ * genome-wide off-target search hot path.
+ *
+ * The reference (BauerLab/VARSCOT) has no plugin / FFI interface: its only seams are the argv +
+ * file boundaries between stage binaries.  This ABI is therefore the boundary a maintainer would
+ * bind *inside* those binaries; every entry point cites the reference code it replaces
+ * (paths relative to VARSCOT_pipeline/).  INTEGRATION.md shows the binding.
+ *
+ * Conventions: every call returns an int status (0 = VSC_OK, negative errno-style otherwise); no
+ * C++ exception crosses the boundary; no global state; a vsc_ctx is single-threaded (a process
+ * may own several, one per device / stream); all sizes are explicit; all buffers little-endian;
+ * pointers are HOST pointers unless the parameter name ends in _dev.
+ *
+ * Genome layout ("packed planes"): the genome is one global coordinate space.  Contig c occupies
+ * global positions [offset_c, offset_c + length_c); consecutive contigs are separated by at least
+ * one N position, and every position outside a contig is N.  Three bit planes describe it, one bit
+ * per base, bit b of 32-bit word w <-> global position 32*w + b:
+ *     hi, lo : the 2-bit base code (A = 00, C = 01, G = 10, T = 11 as hi:lo; complement = NOT both)
+ *     nmask  : 1 where the position is N / a separator / padding (hi and lo are then ignored)
+ * = 0.375 byte per base.  The total padded length must be < 2^32 - 4096 (the reference's own limit
+ * is 4 Gbases: read_mapping/bidir_index.cpp:17, read_mapping/common.h:12-18).
+ */
+#ifndef VARSCOT_HIP_H
+#define VARSCOT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSC_ABI_VERSION 1
+
+#define VSC_OK 0
+#define VSC_ERR_INVALID (-22)  /* EINVAL: bad argument (e.g. mismatches outside 0..8)          */
+#define VSC_ERR_NOMEM (-12)    /* ENOMEM: host or device allocation failed                      */
+#define VSC_ERR_DEVICE (-5)    /* EIO:    a HIP call failed, see vsc_last_error()               */
+#define VSC_ERR_RANGE (-34)    /* ERANGE: genome / result does not fit the 32-bit position space */
+#define VSC_ERR_NODEVICE (-19) /* ENODEV: no usable gfx950 device                               */
+
+#define VSC_READ_LEN 23 /* VARSCOT fixes SEQLENGTH=23 (VARSCOT:253; CIGAR "23M" bidir_mapping.cpp:102) */
+#define VSC_MAX_MISMATCHES 8 /* read_mapping/bidir_mapping.cpp:234-238 */
+
+typedef struct vsc_ctx vsc_ctx;
+typedef struct vsc_genome vsc_genome;
+typedef struct vsc_hits vsc_hits;
+
+/* One contig of the global coordinate space. */
+typedef struct {
+    uint64_t offset; /* global position of the contig's first base */
+    uint32_t length; /* number of bases */
+    uint32_t reserved;
+} vsc_contig;
+
+/*
+ * One candidate off-target site = one record the reference inserts into its `records` map
+ * (read_mapping/bidir_mapping.cpp:88-125).
+ *   info: bit 31       strand, 1 = '-' (BAM_FLAG_RC, :97-98)
+ *         bits 23..27  NM = mismatches over all 23 positions (:79-86,121)
+ *         bits 0..22   mismatch mask in forward-genome window coordinates, bit i = window position
+ *                      i differs from fullRead[i] - the information the reference routes through
+ *                      the MD tag (:114-122) and re-parses in
+ *                      variant_processing/filter_output_bam.h:330-349.
+ */
+typedef struct {
+    uint32_t guide;  /* index of the read in input order (:287) */
+    uint32_t contig; /* record.r.rID (:99) */
+    uint32_t pos;    /* record.r.beginPos, 0-based (:100) */
+    uint32_t info;
+} vsc_hit;
+
+#define VSC_HIT_STRAND(info) (((info) >> 31) & 1u)
+#define VSC_HIT_NM(info) (((info) >> 23) & 31u)
+#define VSC_HIT_MASK(info) ((info)&0x7FFFFFu)
+
+/* Search options = the -M and -P options of bidir_mapping (read_mapping/bidir_mapping.cpp:207-216). */
+typedef struct {
+    uint32_t max_mismatches; /* -M, 0..8 (:234-238) */
+    uint8_t has_extra_pam;   /* -P given */
+    char extra_pam[2];       /* -P: additional non-canonical PAM besides (N)GG and (N)GA (:240-247) */
+    uint8_t reserved;
+} vsc_search_params;
+
+/* Per-search device timings measured with HIP events on the context's stream (milliseconds). */
+typedef struct {
+    double scan_ms;          /* off-target scan kernel(s) */
+    double sort_ms;          /* radix sort of the hit keys */
+    double finalize_ms;      /* contig resolution + record assembly */
+    double score_ms;         /* last vsc_score_hits call */
+    double total_ms;         /* first launch to last completion of the last vsc_search */
+    uint64_t sites;          /* PAM-valid, N-free windows compared (both strands), per pass */
+    uint64_t hits;           /* hits reported */
+    uint64_t genome_bytes;   /* plane bytes streamed per pass (0.375 B/base) */
+    uint32_t passes;         /* scan launches needed (1 unless the hit buffer overflowed) */
+    uint32_t reserved;
+} vsc_timing;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int vsc_abi_version(void);
+/* Number of visible HIP devices (0 when there is none); never initialises a device. */
+int vsc_device_count(void);
+/* Binds device_id and creates the context's stream.  Replaces: process start-up of bidir_mapping
+ * (read_mapping/bidir_mapping.cpp:190-258). */
+int vsc_ctx_create(int device_id, vsc_ctx **out);
+int vsc_ctx_destroy(vsc_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. the framework's current stream) instead of the context's own. */
+int vsc_ctx_set_stream(vsc_ctx *ctx, void *hip_stream);
+/* Text of the last error on this context ("" if none).  Valid until the next call on ctx. */
+const char *vsc_last_error(const vsc_ctx *ctx);
+int vsc_ctx_timing(const vsc_ctx *ctx, vsc_timing *out);
+
+/* ---- host-side packing helpers (no device needed) -------------------------------------------- */
+/* Lays out n contigs in the global coordinate space (one N separator between contigs) and returns
+ * the number of 32-bit words each plane needs.  Replaces the StringSet<Dna5String> concatenation of
+ * read_mapping/bidir_index.cpp:36-40. */
+uint64_t vsc_layout_contigs(const uint32_t *contig_len, uint32_t n_contigs, vsc_contig *out_table);
+/* Initialises planes of n_words words to "all N". */
+void vsc_planes_init(uint32_t *hi, uint32_t *lo, uint32_t *nmask, uint64_t n_words);
+/* Writes n characters (ACGT any case; everything else = N, SeqAn Dna5 conversion) at global
+ * position dst_pos. */
+void vsc_pack_bases(const char *seq, uint64_t n, uint64_t dst_pos, uint32_t *hi, uint32_t *lo, uint32_t *nmask);
+/* Inverse of vsc_pack_bases: n characters from global position src_pos. */
+void vsc_unpack_bases(const uint32_t *hi, const uint32_t *lo, const uint32_t *nmask, uint64_t src_pos, uint64_t n,
+                      char *out);
+/* Packs one 23-nt read: 2 bits per base, base i in bits 2i..2i+1, A=0 C=1 G=2 T=3; every other
+ * character becomes A (SeqAn Dna conversion of the reads, read_mapping/bidir_mapping.cpp:194,256,264). */
+uint64_t vsc_pack_guide(const char *seq23);
+
+/* ---- genome ---------------------------------------------------------------------------------- */
+/*
+ * Uploads (a shard of) the packed genome.  The arrays hold words [first_word, first_word+n_words)
+ * of the global planes; windows STARTING in the first own_words words are searched, the remaining
+ * words are halo (a 22-base halo = 1 word is enough); positions past the arrays are N.
+ * contigs / n_contigs always describe the WHOLE genome (positions are reported per contig).
+ * The caller keeps ownership of the host arrays; the library owns the device copies.
+ * Replaces: open(index, path) + contig-name pass of read_mapping/bidir_mapping.cpp:268-280 (the
+ * FM index is replaced by the resident planes).
+ */
+int vsc_genome_load(vsc_ctx *ctx, const uint32_t *hi, const uint32_t *lo, const uint32_t *nmask, uint64_t first_word,
+                    uint64_t n_words, uint64_t own_words, const vsc_contig *contigs, uint32_t n_contigs,
+                    vsc_genome **out);
+int vsc_genome_free(vsc_genome *genome);
+/* Bytes of HBM the resident genome occupies. */
+uint64_t vsc_genome_device_bytes(const vsc_genome *genome);
+
+/* ---- search ---------------------------------------------------------------------------------- */
+/*
+ * Searches every guide on both strands and returns all candidate sites, i.e. for every read the
+ * union of the two searchAndVerifyEntireRead calls of read_mapping/bidir_mapping.cpp:285-295
+ * (pigeonhole halves :157-162, find<0,k> :129-146, verify delegate :39-126), as the predicate
+ * DESIGN.md states.  guides = n_guides values of vsc_pack_guide.  The result is sorted ascending
+ * by (guide, strand '+' before '-', contig, pos) - the order of the reference's std::map (:154)
+ * per read and strand; primary/secondary selection (:167-187) is host-side formatting
+ * (vsc_sam_order).  The result is library-owned; release it with vsc_hits_free.
+ */
+int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
+               const vsc_search_params *params, vsc_hits **out);
+uint64_t vsc_hits_count(const vsc_hits *hits);
+/* Device pointer to vsc_hits_count() records of type vsc_hit (valid until vsc_hits_free). */
+const void *vsc_hits_data_dev(const vsc_hits *hits);
+/* Host copy of the records (made on first use; valid until vsc_hits_free). */
+int vsc_hits_data(vsc_hits *hits, const vsc_hit **out);
+int vsc_hits_free(vsc_hits *hits);
+
+/*
+ * Per-hit scores for rows [first, first+count) of a result (rows R5/R6):
+ *   mit       : count doubles  = calcMitScore (variant_processing/mit_score.h:12-68) on the hit's
+ *               mismatch positions (forward-genome orientation, as merge_output_bam.h:549 passes them)
+ *   mit_flags : count bytes, 1 where the reference would index its weight table out of bounds
+ *   features  : count * 442 bytes = featureMatrixRecord (variant_processing/feature_matrix.h:25-126)
+ *               of (guide, off-target in guide orientation), as merge_output_bam.h:696 calls it
+ * Any of the three output pointers may be NULL.  guides must be the array passed to vsc_search.
+ */
+int vsc_score_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, const uint64_t *guides,
+                   uint32_t n_guides, uint64_t first, uint64_t count, double *mit, uint8_t *mit_flags,
+                   uint8_t *features);
+#define VSC_N_FEATURES 442
+
+/* ---- host-side formatting helpers (no device needed) ------------------------------------------ */
+/*
+ * Order in which read_mapping/bidir_mapping.cpp:167-187 writes the records of one search result
+ * and which of them it flags BAM_FLAG_SECONDARY.  hits must be sorted as vsc_search returns them.
+ * order[i] = index into hits of the i-th record written; secondary[i] = 1 if that record carries
+ * flag 256.
+ */
+void vsc_sam_order(const vsc_hit *hits, uint64_t n, uint64_t *order, uint8_t *secondary);
+#ifdef __cplusplus
+}
+#endif
+#endif

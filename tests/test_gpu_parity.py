@@ -1,0 +1,213 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs - bit-exact hit sets, NM, mismatch masks, MIT scores and feature rows."""
+import os
+
+import numpy as np
+import pytest
+
+import varscot_amd as va
+from helpers import hits_as_tuples, make_genome, mutate, random_guides, random_seq, revcomp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = va.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_search(ctx, contigs, guides, max_mm, extra_pam=None, world=1):
+    packed = va.PackedGenome.from_sequences(contigs)
+    out = []
+    for rank in range(world):
+        b, e = packed.shard_words(rank, world)
+        if e <= b:
+            continue
+        g = ctx.load_genome(packed, rank, world)
+        h = g.search(guides, max_mm, extra_pam)
+        out.append(h.to_numpy())
+        h.close()
+        g.close()
+    return np.concatenate(out) if out else np.zeros(0, dtype=va.HIT_DTYPE)
+
+
+CASES = [(101, 0, None), (102, 1, None), (103, 2, "AG"), (104, 3, None), (105, 4, None), (106, 5, "TT"),
+         (107, 6, None), (108, 7, None), (109, 8, None), (110, 8, "CC")]
+
+
+@pytest.mark.parametrize("seed,max_mm,extra_pam", CASES)
+def test_search_matches_oracle(ctx, oracle, seed, max_mm, extra_pam):
+    rng = np.random.default_rng(seed)
+    guides = random_guides(rng, 9) + [random_seq(rng, 23), "NNGT" + random_seq(rng, 17) + "GG"]
+    contigs = make_genome(seed, [9000, 22, 23, 24, 700, 5, 4100, 2049, 64], guides, max_mm, n_plant=120, n_runs=6)
+    want = oracle.search(contigs, guides, max_mm, extra_pam, mode=oracle.MODE_PREDICATE)
+    got = gpu_search(ctx, contigs, guides, max_mm, extra_pam)
+    assert len(want) > 20
+    assert hits_as_tuples(got) == hits_as_tuples(want)  # same records in the same (sorted) order
+
+
+def test_search_matches_reference_flow_order(ctx, oracle):
+    """SAM emission order + secondary flags (bidir_mapping.cpp:167-187) from the sorted GPU result."""
+    rng = np.random.default_rng(7)
+    guides = random_guides(rng, 6)
+    contigs = make_genome(7, [6000, 3000], guides, 6, n_plant=150)
+    flow = oracle.search(contigs, guides, 6, mode=oracle.MODE_REFERENCE_FLOW)
+    got = gpu_search(ctx, contigs, guides, 6)
+    order, sec = va.sam_order(got)
+    got = got[order.astype(np.int64)]
+    for f in ("guide", "contig", "pos"):
+        assert np.array_equal(got[f], flow[f])
+    assert np.array_equal(got["info"] | (sec.astype(np.uint32) << 30), flow["info"])
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_genome_shards_reproduce_the_whole(ctx, oracle, world):
+    """Sharding by tile-aligned plane ranges with a one-word halo loses and duplicates nothing."""
+    rng = np.random.default_rng(50 + world)
+    guides = random_guides(rng, 8)
+    contigs = make_genome(50 + world, [30000, 12000, 7000, 100, 23], guides, 6, n_plant=200, n_runs=5)
+    # plant sites across every shard boundary
+    packed = va.PackedGenome.from_sequences(contigs)
+    seq = list(contigs[0])
+    for r in range(1, world):
+        b, _ = packed.shard_words(r, world)
+        p = b * 32
+        if p + 30 < len(seq):
+            for k, shift in enumerate((-22, -11, -1, 0)):
+                site = mutate(rng, guides[k % len(guides)], 2, 0, 20)
+                site = site if k % 2 else revcomp(site)
+                q = p + shift
+                seq[q:q + 23] = list(site)
+    contigs[0] = "".join(seq)
+    want = oracle.search_fast(contigs, guides, 6)
+    got = gpu_search(ctx, contigs, guides, 6, world=world)
+    got = got[np.lexsort((got["pos"], got["contig"], got["info"] >> 31, got["guide"]))]
+    assert hits_as_tuples(got) == hits_as_tuples(want)
+
+
+def test_empty_and_degenerate_inputs(ctx, oracle):
+    contigs = ["ACGT", "N" * 100, "ACGTTGCATGCAAGTCCTAGTGG"]
+    g = "ACGTTGCATGCAAGTCCTAGTGG"
+    assert len(gpu_search(ctx, contigs, [], 4)) == 0
+    got = gpu_search(ctx, contigs, [g], 0)
+    want = oracle.search(contigs, [g], 0)
+    assert hits_as_tuples(got) == hits_as_tuples(want) and len(want) == 1
+    assert len(gpu_search(ctx, ["ACGT" * 3], [g], 8)) == 0
+    packed = va.PackedGenome.from_sequences(contigs)
+    gen = ctx.load_genome(packed)
+    with pytest.raises(va.VarscotError) as e:
+        gen.search([g], 9)
+    assert e.value.code == -22 and "between 0 and 8" in str(e.value)
+    gen.close()
+
+
+def test_right_edge_rule_on_gpu(ctx, oracle):
+    g = "ACGTTGCATGCAAGTCCTAGTGG"
+    bad = g[:11] + "".join("A" if c != "A" else "C" for c in g[11:14]) + g[14:]
+    for contigs in (["T" * 50 + bad], ["T" * 50 + bad + "T"], ["T" * 50 + revcomp(bad), "T" * 9 + bad],
+                    ["T" * 50 + bad + "N" + "T" * 40]):
+        want = oracle.search(contigs, [g], 4)
+        got = gpu_search(ctx, contigs, [g], 4)
+        assert hits_as_tuples(got) == hits_as_tuples(want)
+
+
+def test_dense_pam_region_and_many_guides(ctx, oracle):
+    """Low-complexity sequence where almost every window is a candidate on both strands, and a read
+    count that is not a multiple of the kernel's unroll factor."""
+    rng = np.random.default_rng(9)
+    guides = random_guides(rng, 37)
+    contigs = ["CCGG" * 3000 + random_seq(rng, 5000) + "G" * 4000 + "C" * 4000 + "GGCC" * 1000]
+    contigs[0] = contigs[0][:20000] + guides[3] + contigs[0][20023:]
+    want = oracle.search_fast(contigs, guides, 7)
+    got = gpu_search(ctx, contigs, guides, 7)
+    assert hits_as_tuples(got) == hits_as_tuples(want)
+
+
+def test_larger_genome_against_fast_port(ctx, oracle):
+    """8 Mbp x 64 reads x 8 mismatches: tens of thousands of hits; exercises queue carry-over,
+    staged-hit flushes and the dynamic chunk schedule."""
+    rng = np.random.default_rng(11)
+    guides = random_guides(rng, 64)
+    lens = [3_000_000, 2_500_000, 1_500_000, 999_983, 17]
+    contigs = make_genome(11, lens, guides, 8, n_plant=500, n_runs=40)
+    want = oracle.search_fast(contigs, guides, 8)
+    got = gpu_search(ctx, contigs, guides, 8)
+    assert len(want) > 20000
+    assert hits_as_tuples(got) == hits_as_tuples(want)
+
+
+def test_hit_buffer_overflow_is_retried(ctx, oracle):
+    """Far more hits than the random-genome estimate sizes the buffer for."""
+    g = "ACGTTGCATGCAAGTCCTAGTGG"
+    unit = g + "T"
+    contigs = [unit * 60000]  # 60 000 perfect sites: the estimate allows ~1M + few
+    guides = [g] * 40        # 2.4 M hits
+    got = gpu_search(ctx, contigs, guides, 0)
+    assert len(got) == 60000 * 40
+    assert ctx.timing()["passes"] == 2
+    assert np.array_equal(np.unique(got["guide"]), np.arange(40))
+    assert np.all(got["pos"] % 24 == 0) and np.all((got["info"] >> 23) == 0)
+
+
+# ------------------------------------------------------------------------------------ scores
+def test_mit_and_features_match_oracle(ctx, oracle):
+    rng = np.random.default_rng(21)
+    guides = random_guides(rng, 10) + [random_seq(rng, 21) + "GA"]
+    contigs = make_genome(21, [20000, 8000], guides, 8, n_plant=300)
+    packed = va.PackedGenome.from_sequences(contigs)
+    gen = ctx.load_genome(packed)
+    hits = gen.search(guides, 8)
+    rec = hits.to_numpy()
+    mit, flags, feat = hits.scores(mit=True, features=True)
+    assert len(rec) > 200
+    n_ub = 0
+    for i, (gi, s, c, p, nm, mask) in enumerate(hits_as_tuples(rec)):
+        pos = [b for b in range(23) if (mask >> b) & 1] or [-1]
+        want, ub = oracle.mit_score(pos)
+        assert mit[i] == want  # bit-exact fp64
+        assert bool(flags[i]) == ub
+        n_ub += ub
+        off = contigs[c][p:p + 23]
+        off = revcomp(off) if s else off
+        assert np.array_equal(feat[i].astype(np.uint32), oracle.feature_row(guides[gi], off))
+    assert n_ub > 0  # '-' hits with PAM-side mismatches exercise the reference's out-of-bounds case
+    # sub-range scoring
+    m2, _, f2 = hits.scores(first=5, count=7, mit=True, features=True)
+    assert np.array_equal(m2, mit[5:12]) and np.array_equal(f2, feat[5:12])
+    hits.close()
+    gen.close()
+
+
+def test_features_match_reference_golden_on_gpu(ctx, golden_dir):
+    """The reference's own 6960 golden rows (featureMatrix.RData): each (on, off) pair is planted as
+    a site, found by the search, and its GPU feature row compared with the stored row."""
+    g = np.load(os.path.join(golden_dir, "features_golden.npz"))
+    on, off, feat = [str(s) for s in g["on"]], [str(s) for s in g["off"]], g["feat"]
+    uniq_on = sorted(set(on))
+    gidx = {s: i for i, s in enumerate(uniq_on)}
+    # one contig per pair keeps sites apart: "T"*4 + off + "T"*4 (T-flanks add no GG/GA/CC/TC PAMs)
+    step = 4 + 23 + 4
+    contigs = ["TTTT" + o + "TTTT" for o in off]
+    packed = va.PackedGenome.from_sequences(contigs)
+    gen = ctx.load_genome(packed)
+    hits = gen.search(uniq_on, 8)
+    rec = hits.to_numpy()
+    _, _, f = hits.scores(mit=False, features=True)
+    found = {}
+    for i, (gi, s, c, p, nm, mask) in enumerate(hits_as_tuples(rec)):
+        if s == 0 and p == 4:
+            found[(gi, c)] = i
+    checked = 0
+    for row, (a, o) in enumerate(zip(on, off)):
+        nm23 = sum(x != y for x, y in zip(a, o))
+        if nm23 > 8 or o[21:] not in ("GG", "GA"):
+            continue
+        i = found[(gidx[a], row)]
+        assert np.array_equal(f[i], feat[row]), (a, o)
+        checked += 1
+    assert checked > 6000
+    hits.close()
+    gen.close()
+    assert step == len(contigs[0])

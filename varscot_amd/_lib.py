@@ -1,0 +1,106 @@
+"""ctypes binding of libvarscot_hip.so (include/varscot_hip.h).
+
+The library is the product: there is no Python or CPU implementation of the search behind this
+module.  Importing it fails loudly when the shared library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C varscot_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvarscot_hip.so")
+
+VSC_OK = 0
+ERRORS = {-22: "VSC_ERR_INVALID", -12: "VSC_ERR_NOMEM", -5: "VSC_ERR_DEVICE", -34: "VSC_ERR_RANGE",
+          -19: "VSC_ERR_NODEVICE"}
+
+HIT_DTYPE = np.dtype([("guide", "<u4"), ("contig", "<u4"), ("pos", "<u4"), ("info", "<u4")])
+CONTIG_DTYPE = np.dtype([("offset", "<u8"), ("length", "<u4"), ("reserved", "<u4")])
+N_FEATURES = 442
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("max_mismatches", C.c_uint32), ("has_extra_pam", C.c_uint8), ("extra_pam", C.c_char * 2),
+                ("reserved", C.c_uint8)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("scan_ms", C.c_double), ("sort_ms", C.c_double), ("finalize_ms", C.c_double),
+                ("score_ms", C.c_double), ("total_ms", C.c_double), ("sites", C.c_uint64), ("hits", C.c_uint64),
+                ("genome_bytes", C.c_uint64), ("passes", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+# every symbol include/varscot_hip.h declares: (name, restype, argtypes)
+_u32p = C.POINTER(C.c_uint32)
+_vp = C.c_void_p
+SYMBOLS = [
+    ("vsc_abi_version", C.c_int, []),
+    ("vsc_device_count", C.c_int, []),
+    ("vsc_ctx_create", C.c_int, [C.c_int, C.POINTER(_vp)]),
+    ("vsc_ctx_destroy", C.c_int, [_vp]),
+    ("vsc_ctx_set_stream", C.c_int, [_vp, _vp]),
+    ("vsc_last_error", C.c_char_p, [_vp]),
+    ("vsc_ctx_timing", C.c_int, [_vp, C.POINTER(Timing)]),
+    ("vsc_layout_contigs", C.c_uint64, [_vp, C.c_uint32, _vp]),
+    ("vsc_planes_init", None, [_vp, _vp, _vp, C.c_uint64]),
+    ("vsc_pack_bases", None, [C.c_char_p, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
+    ("vsc_unpack_bases", None, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, _vp]),
+    ("vsc_pack_guide", C.c_uint64, [C.c_char_p]),
+    ("vsc_genome_load", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp, C.c_uint32,
+                                  C.POINTER(_vp)]),
+    ("vsc_genome_free", C.c_int, [_vp]),
+    ("vsc_genome_device_bytes", C.c_uint64, [_vp]),
+    ("vsc_search", C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(SearchParams), C.POINTER(_vp)]),
+    ("vsc_hits_count", C.c_uint64, [_vp]),
+    ("vsc_hits_data_dev", _vp, [_vp]),
+    ("vsc_hits_data", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("vsc_hits_free", C.c_int, [_vp]),
+    ("vsc_score_hits", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
+    ("vsc_sam_order", None, [_vp, C.c_uint64, _vp, _vp]),
+]
+
+_lib = None
+
+
+class VarscotError(RuntimeError):
+    def __init__(self, code, message=""):
+        self.code = code
+        super().__init__("%s (%d)%s" % (ERRORS.get(code, "VSC_ERR"), code, ": " + message if message else ""))
+
+
+def lib():
+    """The loaded shared library.  Raises ImportError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libvarscot_hip.so is not built (%s). Build it with `make -C varscot_amd/csrc` or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError = header and library out of sync
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+def check(code, ctx=None):
+    if code != VSC_OK:
+        msg = ""
+        if ctx:
+            msg = lib().vsc_last_error(ctx).decode(errors="replace")
+        raise VarscotError(code, msg)
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,215 @@
+"""Host-side Python mirror of the C ABI (include/varscot_hip.h): packed genome, device context,
+search and per-hit scoring.  Thin plumbing only - every computation happens in libvarscot_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import HIT_DTYPE, CONTIG_DTYPE, N_FEATURES, SearchParams, Timing, check, lib, ptr
+
+READ_LEN = 23
+TILE_WORDS = 64  # shard boundaries are multiples of this many 32-base words (one scan tile)
+
+
+def pack_guides(guides):
+    """23-nt reads -> uint64 codes (vsc_pack_guide; non-ACGT letters become A like SeqAn's Dna)."""
+    L = lib()
+    out = np.empty(len(guides), dtype=np.uint64)
+    for i, g in enumerate(guides):
+        b = g if isinstance(g, bytes) else g.encode()
+        if len(b) != READ_LEN:
+            raise ValueError("read %d has length %d; VARSCOT searches 23-nt reads (20 nt + PAM)" % (i, len(b)))
+        out[i] = L.vsc_pack_guide(b)
+    return out
+
+
+class PackedGenome:
+    """The host-side packed planes of a genome (0.375 byte per base) plus its contig table.
+
+    Counterpart of the reference's on-disk index (read_mapping/bidir_index.cpp) - here three bit
+    planes (hi, lo, nmask) over one global coordinate space, see include/varscot_hip.h.
+    """
+
+    def __init__(self, hi, lo, nmask, contigs, names=None):
+        self.hi, self.lo, self.nmask = hi, lo, nmask
+        self.contigs = np.ascontiguousarray(contigs, dtype=CONTIG_DTYPE)
+        self.names = list(names) if names is not None else ["contig%d" % i for i in range(len(self.contigs))]
+
+    @property
+    def n_words(self):
+        return len(self.hi)
+
+    @property
+    def n_bases(self):
+        return int(self.contigs["length"].sum())
+
+    @classmethod
+    def from_sequences(cls, seqs, names=None):
+        L = lib()
+        bufs = [s if isinstance(s, bytes) else s.encode() for s in seqs]
+        lens = np.array([len(b) for b in bufs], dtype=np.uint32)
+        table = np.zeros(len(bufs), dtype=CONTIG_DTYPE)
+        n_words = int(L.vsc_layout_contigs(ptr(lens), len(bufs), ptr(table)))
+        n_words = max(n_words, 1)
+        hi = np.empty(n_words, dtype=np.uint32)
+        lo = np.empty(n_words, dtype=np.uint32)
+        nm = np.empty(n_words, dtype=np.uint32)
+        L.vsc_planes_init(ptr(hi), ptr(lo), ptr(nm), n_words)
+        for b, row in zip(bufs, table):
+            L.vsc_pack_bases(b, len(b), int(row["offset"]), ptr(hi), ptr(lo), ptr(nm))
+        return cls(hi, lo, nm, table, names)
+
+    def decode(self, pos, n):
+        """n characters starting at global position pos (N outside contigs)."""
+        out = C.create_string_buffer(n)
+        lib().vsc_unpack_bases(ptr(self.hi), ptr(self.lo), ptr(self.nmask), pos, n, out)
+        return out.raw.decode()
+
+    def contig_sequence(self, c):
+        row = self.contigs[c]
+        return self.decode(int(row["offset"]), int(row["length"]))
+
+    def shard_words(self, rank, world):
+        """Tile-aligned word range [begin, end) of the planes that rank `rank` of `world` owns."""
+        tiles = (self.n_words + TILE_WORDS - 1) // TILE_WORDS
+        b = (tiles * rank // world) * TILE_WORDS
+        e = (tiles * (rank + 1) // world) * TILE_WORDS
+        return min(b, self.n_words), min(e, self.n_words)
+
+
+class Context:
+    """One device + one stream (vsc_ctx).  Single-threaded."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib().vsc_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().vsc_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream_handle):
+        check(lib().vsc_ctx_set_stream(self._h, C.c_void_p(hip_stream_handle)), self._h)
+
+    def timing(self):
+        t = Timing()
+        check(lib().vsc_ctx_timing(self._h, C.byref(t)), self._h)
+        return t.as_dict()
+
+    def load_genome(self, packed, rank=0, world=1):
+        return Genome(self, packed, rank, world)
+
+
+class Genome:
+    """(A shard of) a packed genome resident in HBM (vsc_genome)."""
+
+    def __init__(self, ctx, packed, rank=0, world=1):
+        self.ctx, self.packed = ctx, packed
+        b, e = packed.shard_words(rank, world)
+        if e <= b:
+            raise ValueError("rank %d of %d owns no words of this genome" % (rank, world))
+        halo_end = min(e + 1, packed.n_words)  # 22-base halo = 1 word
+        self.first_word, self.own_words = b, e - b
+        hi = np.ascontiguousarray(packed.hi[b:halo_end])
+        lo = np.ascontiguousarray(packed.lo[b:halo_end])
+        nm = np.ascontiguousarray(packed.nmask[b:halo_end])
+        self._h = C.c_void_p()
+        check(lib().vsc_genome_load(ctx._h, ptr(hi), ptr(lo), ptr(nm), b, len(hi), e - b, ptr(packed.contigs),
+                                    len(packed.contigs), C.byref(self._h)), ctx._h)
+
+    @property
+    def device_bytes(self):
+        return int(lib().vsc_genome_device_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            lib().vsc_genome_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search(self, guides, max_mismatches, extra_pam=None):
+        """guides: list of 23-nt strings or a uint64 array from pack_guides()."""
+        codes = guides if isinstance(guides, np.ndarray) else pack_guides(guides)
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        p = SearchParams()
+        p.max_mismatches = max_mismatches
+        if extra_pam:
+            e = extra_pam if isinstance(extra_pam, bytes) else extra_pam.encode()
+            if len(e) != 2:
+                raise ValueError("the additional PAM (-P) must be 2 letters")
+            p.has_extra_pam = 1
+            p.extra_pam = e
+        h = C.c_void_p()
+        check(lib().vsc_search(self.ctx._h, self._h, ptr(codes), len(codes), C.byref(p), C.byref(h)), self.ctx._h)
+        return Hits(self, h, codes)
+
+
+class Hits:
+    """Result of one search (vsc_hits): records sorted by (guide, strand, contig, pos)."""
+
+    def __init__(self, genome, handle, codes):
+        self.genome, self._h, self.codes = genome, handle, codes
+
+    def __len__(self):
+        return int(lib().vsc_hits_count(self._h))
+
+    @property
+    def device_ptr(self):
+        return lib().vsc_hits_data_dev(self._h)
+
+    def to_numpy(self):
+        n = len(self)
+        p = C.c_void_p()
+        check(lib().vsc_hits_data(self._h, C.byref(p)), self.genome.ctx._h)
+        if n == 0:
+            return np.zeros(0, dtype=HIT_DTYPE)
+        buf = (C.c_char * (n * HIT_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=HIT_DTYPE).copy()
+
+    def scores(self, first=0, count=None, mit=True, features=False):
+        """(mit float64[count] | None, mit_flags uint8[count] | None, features uint8[count,442] | None)."""
+        count = len(self) - first if count is None else count
+        m = np.empty(count, dtype=np.float64) if mit else None
+        fl = np.empty(count, dtype=np.uint8) if mit else None
+        ft = np.empty((count, N_FEATURES), dtype=np.uint8) if features else None
+        check(lib().vsc_score_hits(self.genome.ctx._h, self.genome._h, self._h, ptr(self.codes), len(self.codes),
+                                   first, count, ptr(m), ptr(fl), ptr(ft)), self.genome.ctx._h)
+        return m, fl, ft
+
+    def close(self):
+        if self._h:
+            lib().vsc_hits_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sam_order(hits):
+    """(order, secondary) in which read_mapping/bidir_mapping.cpp:167-187 writes a sorted result."""
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    order = np.empty(len(hits), dtype=np.uint64)
+    sec = np.empty(len(hits), dtype=np.uint8)
+    lib().vsc_sam_order(ptr(hits), len(hits), ptr(order), ptr(sec))
+    return order, sec
+
+
+def device_count():
+    return int(lib().vsc_device_count())

@@ -1,0 +1,523 @@
+// vsc_api.cpp - the C ABI of include/varscot_hip.h: context, resident genome, search orchestration
+// (scan -> radix sort -> record assembly) and per-hit scoring.  Host C++ only; all device work is in
+// vsc_kernels.hip.  No CPU implementation of the search exists in this library: without a HIP
+// device every compute entry point fails with VSC_ERR_NODEVICE / VSC_ERR_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "vsc_internal.h"
+
+using namespace vsc;
+
+namespace {
+
+struct DeviceBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct vsc_ctx {
+    int device = 0;
+    int n_cus = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::string err;
+    vsc_timing timing{};
+    DeviceBuf counters, guides, keys_a, keys_b, vals_a, vals_b, sort_temp, score_mit, score_flags, score_feat;
+};
+
+struct vsc_genome {
+    vsc_ctx *ctx = nullptr;
+    uint32_t *d_hi = nullptr, *d_lo = nullptr, *d_nm = nullptr;
+    uint32_t *d_contig_off = nullptr, *d_contig_end = nullptr;
+    uint64_t first_word = 0, own_words = 0, dev_words = 0;
+    uint32_t n_tiles = 0, n_contigs = 0;
+    uint64_t device_bytes = 0;
+    uint64_t sites = 0;  // PAM-valid windows seen by the last scan (sizes the next hit buffer)
+};
+
+struct vsc_hits {
+    vsc_ctx *ctx = nullptr;
+    vsc_hit *d_records = nullptr;
+    uint64_t n = 0;
+    std::vector<vsc_hit> host;
+    bool host_valid = false;
+};
+
+namespace {
+
+int fail(vsc_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        char buf[512];
+        if (e != hipSuccess)
+            std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        else
+            std::snprintf(buf, sizeof buf, "%s", what);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define VSC_HIP(ctx, call)                                                 \
+    do {                                                                   \
+        hipError_t e_ = (call);                                            \
+        if (e_ != hipSuccess) return fail((ctx), VSC_ERR_DEVICE, #call, e_); \
+    } while (0)
+
+// P[Binomial(21, 3/4) <= m]: chance that a PAM-valid random window is within m mismatches of a read
+double hit_probability(unsigned m)
+{
+    double p = 0, c = 1;
+    for (unsigned j = 0; j <= m && j <= 21; ++j) {
+        if (j > 0) c = c * (21 - (j - 1)) / j;
+        p += c * std::pow(0.75, (double)j) * std::pow(0.25, (double)(21 - j));
+    }
+    return p;
+}
+
+PamMasks pam_masks(int a, int b)
+{
+    PamMasks m;
+    m.ah = (a & 2) ? 0xFFFFFFFFu : 0u;
+    m.al = (a & 1) ? 0xFFFFFFFFu : 0u;
+    m.bh = (b & 2) ? 0xFFFFFFFFu : 0u;
+    m.bl = (b & 1) ? 0xFFFFFFFFu : 0u;
+    return m;
+}
+
+int base_code(char c)
+{
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+    }
+}
+
+void guide_planes(uint64_t g, uint32_t *h, uint32_t *l)
+{
+    uint32_t hh = 0, ll = 0;
+    for (int i = 0; i < VSC_READ_LEN; ++i) {
+        const unsigned c = (unsigned)(g >> (2 * i)) & 3u;
+        hh |= (c >> 1) << i;
+        ll |= (c & 1u) << i;
+    }
+    *h = hh;
+    *l = ll;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vsc_abi_version(void) { return VSC_ABI_VERSION; }
+
+int vsc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vsc_ctx_create(int device_id, vsc_ctx **out)
+{
+    if (!out) return VSC_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VSC_ERR_NODEVICE;
+    if (device_id < 0 || device_id >= n) return VSC_ERR_INVALID;
+    vsc_ctx *ctx = new (std::nothrow) vsc_ctx();
+    if (!ctx) return VSC_ERR_NOMEM;
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess ||
+        hipStreamCreate(&ctx->stream) != hipSuccess) {
+        delete ctx;
+        return VSC_ERR_DEVICE;
+    }
+    ctx->own_stream = true;
+    ctx->n_cus = prop.multiProcessorCount;
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            vsc_ctx_destroy(ctx);
+            return VSC_ERR_DEVICE;
+        }
+    *out = ctx;
+    return VSC_OK;
+}
+
+int vsc_ctx_destroy(vsc_ctx *ctx)
+{
+    if (!ctx) return VSC_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->vals_b,
+                         &ctx->sort_temp, &ctx->score_mit, &ctx->score_flags, &ctx->score_feat})
+        b->release();
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VSC_OK;
+}
+
+int vsc_ctx_set_stream(vsc_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return VSC_ERR_INVALID;
+    if (ctx->own_stream && ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return VSC_OK;
+}
+
+const char *vsc_last_error(const vsc_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int vsc_ctx_timing(const vsc_ctx *ctx, vsc_timing *out)
+{
+    if (!ctx || !out) return VSC_ERR_INVALID;
+    *out = ctx->timing;
+    return VSC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int vsc_genome_load(vsc_ctx *ctx, const uint32_t *hi, const uint32_t *lo, const uint32_t *nmask, uint64_t first_word,
+                    uint64_t n_words, uint64_t own_words, const vsc_contig *contigs, uint32_t n_contigs,
+                    vsc_genome **out)
+{
+    if (!ctx || !out) return VSC_ERR_INVALID;
+    *out = nullptr;
+    ctx->err.clear();
+    if (!hi || !lo || !nmask || !contigs || n_contigs == 0 || n_words == 0 || own_words == 0 || own_words > n_words)
+        return fail(ctx, VSC_ERR_INVALID, "vsc_genome_load: null or empty argument");
+    if (own_words < n_words && own_words % kTileWords != 0)
+        return fail(ctx, VSC_ERR_INVALID, "vsc_genome_load: a shard followed by halo words must own a multiple of 64 words");
+    const uint64_t n_tiles = (own_words + kTileWords - 1) / kTileWords;
+    const uint64_t dev_words = std::max<uint64_t>(n_tiles * kTileWords, n_words) + kPadWords;
+    if ((first_word + dev_words) * 32 >= (1ull << 32) - 4096)
+        return fail(ctx, VSC_ERR_RANGE, "vsc_genome_load: genome exceeds the 32-bit position space (4 Gbases)");
+    std::vector<uint32_t> off(n_contigs), end(n_contigs);
+    for (uint32_t c = 0; c < n_contigs; ++c) {
+        const uint64_t e = contigs[c].offset + contigs[c].length;
+        if (e >= (1ull << 32) - 4096) return fail(ctx, VSC_ERR_RANGE, "vsc_genome_load: contig table exceeds 4 Gbases");
+        if (c > 0 && contigs[c].offset < contigs[c - 1].offset + contigs[c - 1].length + 1)
+            return fail(ctx, VSC_ERR_INVALID, "vsc_genome_load: contigs must be ascending and separated by >= 1 N position");
+        off[c] = (uint32_t)contigs[c].offset;
+        end[c] = (uint32_t)e;
+    }
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    vsc_genome *g = new (std::nothrow) vsc_genome();
+    if (!g) return fail(ctx, VSC_ERR_NOMEM, "vsc_genome_load: out of host memory");
+    g->ctx = ctx;
+    g->first_word = first_word;
+    g->own_words = own_words;
+    g->dev_words = dev_words;
+    g->n_tiles = (uint32_t)n_tiles;
+    g->n_contigs = n_contigs;
+    const size_t pb = dev_words * sizeof(uint32_t), cb = (size_t)n_contigs * sizeof(uint32_t);
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+    };
+    step(hipMalloc((void **)&g->d_hi, pb));
+    step(hipMalloc((void **)&g->d_lo, pb));
+    step(hipMalloc((void **)&g->d_nm, pb));
+    step(hipMalloc((void **)&g->d_contig_off, cb));
+    step(hipMalloc((void **)&g->d_contig_end, cb));
+    if (e == hipSuccess) {
+        step(hipMemsetAsync(g->d_hi, 0, pb, ctx->stream));
+        step(hipMemsetAsync(g->d_lo, 0, pb, ctx->stream));
+        step(hipMemsetAsync(g->d_nm, 0xFF, pb, ctx->stream));  // everything past the shard is N
+        step(hipMemcpyAsync(g->d_hi, hi, n_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        step(hipMemcpyAsync(g->d_lo, lo, n_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        step(hipMemcpyAsync(g->d_nm, nmask, n_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        step(hipMemcpyAsync(g->d_contig_off, off.data(), cb, hipMemcpyHostToDevice, ctx->stream));
+        step(hipMemcpyAsync(g->d_contig_end, end.data(), cb, hipMemcpyHostToDevice, ctx->stream));
+        step(hipStreamSynchronize(ctx->stream));
+    }
+    if (e != hipSuccess) {
+        vsc_genome_free(g);
+        return fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, "vsc_genome_load", e);
+    }
+    g->device_bytes = 3 * pb + 2 * cb;
+    *out = g;
+    return VSC_OK;
+}
+
+int vsc_genome_free(vsc_genome *g)
+{
+    if (!g) return VSC_OK;
+    if (g->ctx) (void)hipSetDevice(g->ctx->device);
+    for (void *p : {(void *)g->d_hi, (void *)g->d_lo, (void *)g->d_nm, (void *)g->d_contig_off, (void *)g->d_contig_end})
+        if (p) (void)hipFree(p);
+    delete g;
+    return VSC_OK;
+}
+
+uint64_t vsc_genome_device_bytes(const vsc_genome *g) { return g ? g->device_bytes : 0; }
+
+// ------------------------------------------------------------------------------------------------
+int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
+               const vsc_search_params *params, vsc_hits **out)
+{
+    if (!ctx || !out) return VSC_ERR_INVALID;
+    *out = nullptr;
+    ctx->err.clear();
+    if (!genome || !params || (n_guides && !guides)) return fail(ctx, VSC_ERR_INVALID, "vsc_search: null argument");
+    if (genome->ctx != ctx) return fail(ctx, VSC_ERR_INVALID, "vsc_search: genome belongs to another context");
+    if (params->max_mismatches > VSC_MAX_MISMATCHES)  // read_mapping/bidir_mapping.cpp:234-238
+        return fail(ctx, VSC_ERR_INVALID, "Maximum number of mismatches must lie between 0 and 8.");
+    if (n_guides >= (1u << 31)) return fail(ctx, VSC_ERR_RANGE, "vsc_search: too many reads");
+
+    ScanArgs a{};
+    a.n_pam = 2;
+    a.pam[0] = pam_masks(2, 2);  // GG  (bidir_mapping.cpp:240)
+    a.pam[1] = pam_masks(2, 0);  // GA
+    if (params->has_extra_pam) {  // :242-247
+        const int p0 = base_code(params->extra_pam[0]), p1 = base_code(params->extra_pam[1]);
+        // a PAM containing a non-ACGT letter can only match windows that contain N, which never
+        // pass the verification (:81-82) - it adds nothing
+        if (p0 < 4 && p1 < 4) a.pam[a.n_pam++] = pam_masks(p0, p1);
+    }
+
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    vsc_hits *hits = new (std::nothrow) vsc_hits();
+    if (!hits) return fail(ctx, VSC_ERR_NOMEM, "vsc_search: out of host memory");
+    hits->ctx = ctx;
+    vsc_timing t{};
+    t.genome_bytes = (uint64_t)genome->n_tiles * kTileWords * 3 * sizeof(uint32_t);
+    if (n_guides == 0) {
+        hits->host_valid = true;
+        ctx->timing = t;
+        *out = hits;
+        return VSC_OK;
+    }
+
+    // reads as (hi, lo) plane pairs, padded to the unroll factor with reads that can never match
+    const uint32_t n_pad = (n_guides + kGuideUnroll - 1) / kGuideUnroll * kGuideUnroll;
+    std::vector<uint32_t> gp((size_t)(n_pad + kGuideUnroll) * 2, 0xFFFFFFFFu);  // + one prefetch group
+    for (uint32_t i = 0; i < n_guides; ++i) guide_planes(guides[i], &gp[2 * (size_t)i], &gp[2 * (size_t)i + 1]);
+
+    auto cleanup = [&](int code) {
+        vsc_hits_free(hits);
+        return code;
+    };
+#define VSC_HIP_H(call)                                                              \
+    do {                                                                             \
+        hipError_t e_ = (call);                                                      \
+        if (e_ != hipSuccess)                                                        \
+            return cleanup(fail(ctx, e_ == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, #call, e_)); \
+    } while (0)
+
+    VSC_HIP_H(ctx->guides.ensure(gp.size() * sizeof(uint32_t)));
+    VSC_HIP_H(ctx->counters.ensure(kCntSlots * sizeof(unsigned long long)));
+    VSC_HIP_H(hipMemcpyAsync(ctx->guides.p, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+
+    const double own_bases = (double)genome->n_tiles * kTileBases;
+    const double sites_est = genome->sites ? (double)genome->sites : own_bases / 4;
+    uint64_t cap = (uint64_t)(1.5 * sites_est * n_guides * hit_probability(params->max_mismatches)) + (1u << 20);
+
+    // enough chunks that the dynamic schedule balances, but at least one tile per chunk
+    const uint32_t n_waves_max = (uint32_t)ctx->n_cus * 4 * kWavesPerGroup;
+
+    a.hi = genome->d_hi;
+    a.lo = genome->d_lo;
+    a.nm = genome->d_nm;
+    a.first_pos = (uint32_t)(genome->first_word * 32);
+    a.n_tiles = genome->n_tiles;
+    a.guides = (const uint4 *)ctx->guides.p;
+    a.n_guides_padded = n_pad;
+    a.max_mm = params->max_mismatches;
+    a.k_half = params->max_mismatches / 2;  // bidir_mapping.cpp:129-146
+    a.contig_end = genome->d_contig_end;
+    a.n_contigs = genome->n_contigs;
+    a.counters = (unsigned long long *)ctx->counters.p;
+    const uint32_t n_chunks = (a.n_tiles + kChunkTiles - 1) / kChunkTiles;
+    const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, n_chunks));
+    const int n_groups = (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
+
+    unsigned long long cnt[kCntSlots] = {0, 0, 0, 0};
+    VSC_HIP_H(hipEventRecord(ctx->ev[0], ctx->stream));
+    for (;;) {
+        VSC_HIP_H(ctx->keys_a.ensure(cap * sizeof(uint64_t)));
+        VSC_HIP_H(ctx->vals_a.ensure(cap * sizeof(uint32_t)));
+        a.hit_keys = (uint64_t *)ctx->keys_a.p;
+        a.hit_vals = (uint32_t *)ctx->vals_a.p;
+        a.hit_cap = cap;
+        VSC_HIP_H(hipMemsetAsync(ctx->counters.p, 0, kCntSlots * sizeof(unsigned long long), ctx->stream));
+        VSC_HIP_H(hipEventRecord(ctx->ev[1], ctx->stream));
+        VSC_HIP_H(launch_scan(a, n_groups, ctx->stream));
+        VSC_HIP_H(hipEventRecord(ctx->ev[2], ctx->stream));
+        VSC_HIP_H(hipMemcpyAsync(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+        VSC_HIP_H(hipStreamSynchronize(ctx->stream));
+        t.passes++;
+        if (!cnt[kCntOverflow]) break;
+        if (t.passes >= 3) return cleanup(fail(ctx, VSC_ERR_DEVICE, "vsc_search: hit buffer overflowed repeatedly"));
+        cap = cnt[kCntHits] + (cnt[kCntHits] >> 6) + 4096;  // the counter holds the true total
+    }
+    const uint64_t n = cnt[kCntHits];
+    const_cast<vsc_genome *>(genome)->sites = cnt[kCntSites];
+    t.sites = cnt[kCntSites];
+    t.hits = n;
+
+    if (n > 0) {
+        unsigned guide_bits = 1;
+        while (guide_bits < 31 && (1ull << guide_bits) < n_guides) ++guide_bits;
+        const unsigned end_bit = 33 + guide_bits;
+        size_t temp_bytes = 0;
+        VSC_HIP_H(sort_temp_bytes(n, end_bit, &temp_bytes));
+        VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
+        VSC_HIP_H(ctx->keys_b.ensure(n * sizeof(uint64_t)));
+        VSC_HIP_H(ctx->vals_b.ensure(n * sizeof(uint32_t)));
+        VSC_HIP_H(hipMalloc((void **)&hits->d_records, n * sizeof(vsc_hit)));
+        VSC_HIP_H(launch_sort(ctx->sort_temp.p, temp_bytes, (const uint64_t *)ctx->keys_a.p, (uint64_t *)ctx->keys_b.p,
+                              (const uint32_t *)ctx->vals_a.p, (uint32_t *)ctx->vals_b.p, n, end_bit, ctx->stream));
+        VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
+        FinalizeArgs f{};
+        f.keys = (const uint64_t *)ctx->keys_b.p;
+        f.vals = (const uint32_t *)ctx->vals_b.p;
+        f.n = n;
+        f.contig_off = genome->d_contig_off;
+        f.n_contigs = genome->n_contigs;
+        f.out = hits->d_records;
+        VSC_HIP_H(launch_finalize(f, ctx->stream));
+    } else {
+        VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
+    }
+    VSC_HIP_H(hipEventRecord(ctx->ev[4], ctx->stream));
+    VSC_HIP_H(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+    t.scan_ms = ms;
+    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    t.sort_ms = ms;
+    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+    t.finalize_ms = ms;
+    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]));
+    t.total_ms = ms;
+    ctx->timing = t;
+    hits->n = n;
+    *out = hits;
+    return VSC_OK;
+#undef VSC_HIP_H
+}
+
+uint64_t vsc_hits_count(const vsc_hits *hits) { return hits ? hits->n : 0; }
+
+const void *vsc_hits_data_dev(const vsc_hits *hits) { return hits ? hits->d_records : nullptr; }
+
+int vsc_hits_data(vsc_hits *hits, const vsc_hit **out)
+{
+    if (!hits || !out) return VSC_ERR_INVALID;
+    *out = nullptr;
+    if (!hits->host_valid) {
+        vsc_ctx *ctx = hits->ctx;
+        try {
+            hits->host.resize(hits->n);
+        } catch (...) {
+            return fail(ctx, VSC_ERR_NOMEM, "vsc_hits_data: out of host memory");
+        }
+        if (hits->n) {
+            VSC_HIP(ctx, hipSetDevice(ctx->device));
+            VSC_HIP(ctx, hipMemcpyAsync(hits->host.data(), hits->d_records, hits->n * sizeof(vsc_hit),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+            VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        hits->host_valid = true;
+    }
+    *out = hits->host.data();
+    return VSC_OK;
+}
+
+int vsc_hits_free(vsc_hits *hits)
+{
+    if (!hits) return VSC_OK;
+    if (hits->d_records) {
+        (void)hipSetDevice(hits->ctx->device);
+        (void)hipFree(hits->d_records);
+    }
+    delete hits;
+    return VSC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int vsc_score_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, const uint64_t *guides,
+                   uint32_t n_guides, uint64_t first, uint64_t count, double *mit, uint8_t *mit_flags,
+                   uint8_t *features)
+{
+    if (!ctx) return VSC_ERR_INVALID;
+    ctx->err.clear();
+    if (!genome || !hits || (n_guides && !guides)) return fail(ctx, VSC_ERR_INVALID, "vsc_score_hits: null argument");
+    if (first > hits->n || count > hits->n - first) return fail(ctx, VSC_ERR_INVALID, "vsc_score_hits: row range outside the result");
+    ctx->timing.score_ms = 0;
+    if (count == 0 || (!mit && !mit_flags && !features)) return VSC_OK;
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> gp((size_t)std::max<uint32_t>(n_guides, 1) * 2, 0);
+    for (uint32_t i = 0; i < n_guides; ++i) guide_planes(guides[i], &gp[2 * (size_t)i], &gp[2 * (size_t)i + 1]);
+    VSC_HIP(ctx, ctx->guides.ensure(gp.size() * sizeof(uint32_t)));
+    VSC_HIP(ctx, hipMemcpyAsync(ctx->guides.p, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    ScoreArgs s{};
+    s.hits = hits->d_records + first;
+    s.n = count;
+    s.hi = genome->d_hi;
+    s.lo = genome->d_lo;
+    s.first_pos = (uint32_t)(genome->first_word * 32);
+    s.n_plane_words = genome->dev_words;
+    s.contig_off = genome->d_contig_off;
+    s.guides = (const uint2 *)ctx->guides.p;
+    if (mit) {
+        VSC_HIP(ctx, ctx->score_mit.ensure(count * sizeof(double)));
+        s.mit = (double *)ctx->score_mit.p;
+    }
+    if (mit_flags) {
+        VSC_HIP(ctx, ctx->score_flags.ensure(count));
+        s.mit_flags = (uint8_t *)ctx->score_flags.p;
+    }
+    if (features) {
+        VSC_HIP(ctx, ctx->score_feat.ensure(count * VSC_N_FEATURES));
+        s.features = (uint8_t *)ctx->score_feat.p;
+    }
+    VSC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    VSC_HIP(ctx, launch_score(s, ctx->stream));
+    VSC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (mit) VSC_HIP(ctx, hipMemcpyAsync(mit, s.mit, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (mit_flags) VSC_HIP(ctx, hipMemcpyAsync(mit_flags, s.mit_flags, count, hipMemcpyDeviceToHost, ctx->stream));
+    if (features)
+        VSC_HIP(ctx, hipMemcpyAsync(features, s.features, count * VSC_N_FEATURES, hipMemcpyDeviceToHost, ctx->stream));
+    VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    VSC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timing.score_ms = ms;
+    return VSC_OK;
+}
+
+}  // extern "C"

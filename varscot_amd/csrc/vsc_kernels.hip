@@ -1,0 +1,464 @@
+// vsc_kernels.hip - CDNA4 (gfx950) kernels of the off-target search hot path.
+//
+// scan_kernel     rows R1-R3 of DESIGN.md: for every read and both strands, every genome window that
+//                 the reference's pigeonhole search + verify delegate would accept
+//                 (VARSCOT_pipeline/read_mapping/bidir_mapping.cpp:31-148,150-162,285-295).
+// finalize_kernel global position -> (contig, offset) records (bidir_mapping.cpp:99-100).
+// score_kernel    rows R5/R6: calcMitScore (variant_processing/mit_score.h:12-68) and
+//                 featureMatrixRecord (variant_processing/feature_matrix.h:25-126) per hit.
+//
+// Integer / bitwise work on the VALU (v_alignbit, v_xor, v_or, v_bcnt, v_min3, ballot / mbcnt);
+// no MFMA: the comparison is not a dense contraction.
+#include "vsc_internal.h"
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace vsc {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, sh);  // ({hi,lo} >> sh)[31:0], sh in 0..31
+}
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// The four waves of a workgroup never exchange data; lanes of one wave exchange data through their
+// wave's LDS slice.  DS operations of one wave execute in order, so all that is needed is to stop
+// the compiler from moving LDS accesses across the hand-off.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// reverse complement of a 23-base plane: reverse the bit order, complement (A<->T, C<->G = NOT both planes)
+__device__ __forceinline__ uint32_t revcomp_plane(uint32_t p) { return (~__brev(p)) >> 9; }
+__device__ __forceinline__ uint32_t reverse23(uint32_t p) { return __brev(p) >> 9; }
+
+// reads are fetched through the constant address space so that the (wave-uniform) loads are scalar
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) v4u *const_v4u_ptr;
+
+// ------------------------------------------------------------------------------------------------
+// scan kernel
+// ------------------------------------------------------------------------------------------------
+struct WaveState {
+    uint32_t *qsh, *qsl, *qpos;  // this wave's LDS site queue: hi plane (| strand << 23), lo plane, global position
+    uint64_t *hkey;              // this wave's LDS hit staging buffer
+    uint32_t *hval;
+    uint32_t q;       // queue fill (wave-uniform)
+    uint32_t hn;      // staged hits (wave-uniform)
+    uint32_t lane;
+};
+
+// Copies the staged hits of this wave to the global hit arrays (one atomic per flush).
+__device__ __forceinline__ void flush_hits(const ScanArgs &a, WaveState &w)
+{
+    if (w.hn == 0) return;
+    unsigned long long base = 0;
+    if (w.lane == 0) base = atomicAdd(&a.counters[kCntHits], (unsigned long long)w.hn);
+    base = ((unsigned long long)uniform((uint32_t)(base >> 32)) << 32) | uniform((uint32_t)base);
+    if (base + w.hn <= a.hit_cap) {
+        for (uint32_t i = w.lane; i < w.hn; i += kWave) {
+            a.hit_keys[base + i] = w.hkey[i];
+            a.hit_vals[base + i] = w.hval[i];
+        }
+    } else if (w.lane == 0) {
+        atomicMax(&a.counters[kCntOverflow], 1ull);  // the host re-runs with a buffer of counters[kCntHits] records
+    }
+    wave_sync();
+    w.hn = 0;
+}
+
+// Is global position p the end (offset + length) of a contig?
+__device__ __forceinline__ bool is_contig_end(const ScanArgs &a, uint32_t p)
+{
+    uint32_t lo = 0, hi = a.n_contigs;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (a.contig_end[mid] < p) lo = mid + 1; else hi = mid;
+    }
+    return lo < a.n_contigs && a.contig_end[lo] == p;
+}
+
+// Slow path of the guide loop: stage the hits of one (read, site slot) pair.
+// t = mismatch mask in READ orientation, c = popcount(t); lanes with c > max_mm do not take part.
+__device__ __forceinline__ void emit_hits(const ScanArgs &a, WaveState &w, uint32_t guide, uint32_t slot, uint32_t t,
+                                          uint32_t c)
+{
+    bool hit = c <= a.max_mm;
+    uint32_t pos = 0, strand = 0, mask = 0;
+    if (hit) {
+        uint32_t idx = slot * kWave + w.lane;
+        pos = w.qpos[idx];
+        strand = (w.qsh[idx] >> 23) & 1u;
+        // mismatch positions in forward-genome window coordinates: on '-' the site was stored
+        // reverse-complemented, so read position j is window position 22 - j
+        mask = strand ? reverse23(t) : t;
+        // Right-edge rule (bidir_mapping.cpp:51-52): a window that ends exactly at its contig's end is
+        // never reported through the first-half route; the second-half route needs
+        // HD(fullRead[11..23), window[11..23)) <= k.  The separator after a contig is N, so only
+        // windows followed by an N position can be affected.
+        uint32_t e = pos + VSC_READ_LEN;
+        uint32_t rel = e - a.first_pos;
+        if ((a.nm[rel >> 5] >> (rel & 31u)) & 1u) {
+            if (__popc(mask >> (VSC_READ_LEN / 2)) > a.k_half && is_contig_end(a, e)) hit = false;
+        }
+    }
+    uint64_t b = __ballot(hit);
+    if (b == 0) return;
+    uint32_t n = (uint32_t)__popcll(b);
+    if (hit) {
+        uint32_t at = w.hn + lanes_below(b);
+        w.hkey[at] = ((uint64_t)guide << 33) | ((uint64_t)strand << 32) | pos;
+        w.hval[at] = (c << 23) | mask;
+    }
+    wave_sync();
+    w.hn += n;
+    if (w.hn > kHitCap - kWave) flush_hits(a, w);
+}
+
+// Compares the first min(q, kBatch) queued sites of this wave against every read.
+__device__ __forceinline__ void process_batch(const ScanArgs &a, WaveState &w)
+{
+    const uint32_t take = w.q < (uint32_t)kBatch ? w.q : (uint32_t)kBatch;
+    uint32_t sh[kSitesPerLane], sl[kSitesPerLane];
+#pragma unroll
+    for (int j = 0; j < kSitesPerLane; ++j) {
+        uint32_t idx = j * kWave + w.lane;
+        bool live = idx < take;
+        // an empty slot can never match: its upper bits differ from every read's (zero) upper bits,
+        // and from the padding reads (all ones) in the lo plane
+        sh[j] = live ? (w.qsh[idx] & kMask23) : 0xFFFFFFFFu;
+        sl[j] = live ? w.qsl[idx] : 0u;
+    }
+    const const_v4u_ptr gp = (const_v4u_ptr)(uintptr_t)a.guides;
+    const uint32_t m = a.max_mm;
+    // the read table ends with one extra (never matching) group so that the next group can always be
+    // fetched while the current one is compared
+    v4u na = gp[0], nb = gp[1];
+    for (uint32_t g = 0; g < a.n_guides_padded; g += kGuideUnroll) {
+        const v4u ga = na, gb = nb;
+        na = gp[(g >> 1) + 2];
+        nb = gp[(g >> 1) + 3];
+        const uint32_t gh[kGuideUnroll] = {ga.x, ga.z, gb.x, gb.z};
+        const uint32_t gl[kGuideUnroll] = {ga.y, ga.w, gb.y, gb.w};
+        uint32_t best[kGuideUnroll];
+#pragma unroll
+        for (int u = 0; u < kGuideUnroll; ++u) {
+            uint32_t cm = 32;
+#pragma unroll
+            for (int j = 0; j < kSitesPerLane; ++j) {
+                uint32_t t = (sh[j] ^ gh[u]) | (sl[j] ^ gl[u]);
+                cm = min(cm, (uint32_t)__popc(t));
+            }
+            best[u] = cm;
+        }
+        uint32_t any = min(min(best[0], best[1]), min(best[2], best[3]));
+        if (__ballot(any <= m) != 0) {
+            // rare: at least one lane has a hit for one of the four reads
+#pragma unroll
+            for (int u = 0; u < kGuideUnroll; ++u) {
+                if (__ballot(best[u] <= m) == 0) continue;
+#pragma unroll
+                for (int j = 0; j < kSitesPerLane; ++j) {
+                    uint32_t t = (sh[j] ^ gh[u]) | (sl[j] ^ gl[u]);
+                    uint32_t c = (uint32_t)__popc(t);
+                    if (__ballot(c <= m) != 0) emit_hits(a, w, g + u, j, t, c);
+                }
+            }
+        }
+    }
+    // keep what the batch did not take (at most 63 entries) at the front of the queue
+    wave_sync();
+    uint32_t left = w.q - take;
+    uint32_t vh = 0, vl = 0, vp = 0;
+    if (w.lane < left) {
+        vh = w.qsh[take + w.lane];
+        vl = w.qsl[take + w.lane];
+        vp = w.qpos[take + w.lane];
+    }
+    wave_sync();
+    if (w.lane < left) {
+        w.qsh[w.lane] = vh;
+        w.qsl[w.lane] = vl;
+        w.qpos[w.lane] = vp;
+    }
+    wave_sync();
+    w.q = left;
+}
+
+__global__ __launch_bounds__(kWave *kWavesPerGroup) void scan_kernel(const ScanArgs a)
+{
+    __shared__ uint32_t s_qsh[kWavesPerGroup][kQueueCap];
+    __shared__ uint32_t s_qsl[kWavesPerGroup][kQueueCap];
+    __shared__ uint32_t s_qpos[kWavesPerGroup][kQueueCap];
+    __shared__ uint64_t s_hkey[kWavesPerGroup][kHitCap];
+    __shared__ uint32_t s_hval[kWavesPerGroup][kHitCap];
+
+    const uint32_t wave = threadIdx.x / kWave;
+    WaveState w;
+    w.lane = threadIdx.x % kWave;
+    w.qsh = s_qsh[wave];
+    w.qsl = s_qsl[wave];
+    w.qpos = s_qpos[wave];
+    w.hkey = s_hkey[wave];
+    w.hval = s_hval[wave];
+    w.q = 0;
+    w.hn = 0;
+
+    const uint32_t n_chunks = (a.n_tiles + kChunkTiles - 1) / kChunkTiles;
+    unsigned long long sites = 0;
+
+    for (;;) {
+        uint32_t chunk = 0;
+        if (w.lane == 0) chunk = (uint32_t)atomicAdd(&a.counters[kCntChunk], 1ull);
+        chunk = uniform(chunk);
+        if (chunk >= n_chunks) break;
+        const uint32_t tile_end = min((chunk + 1) * (uint32_t)kChunkTiles, a.n_tiles);
+        for (uint32_t tile = chunk * kChunkTiles; tile < tile_end; ++tile) {
+            // ---- one word of each plane per lane (+ its right neighbour for windows that cross) ----
+            const size_t wi = (size_t)tile * kTileWords + w.lane;
+            const uint32_t H0 = a.hi[wi], H1 = a.hi[wi + 1];
+            const uint32_t L0 = a.lo[wi], L1 = a.lo[wi + 1];
+            const uint32_t N0 = a.nm[wi], N1 = a.nm[wi + 1];
+            // windows (32 starts per lane) that contain an N: OR of the N plane shifted by 0..22
+            uint64_t nn = ((uint64_t)N1 << 32) | N0;
+            nn |= nn >> 1;
+            nn |= nn >> 2;
+            nn |= nn >> 4;
+            nn |= nn >> 8;   // bit i covers positions i .. i+15
+            nn |= nn >> 7;   // bit i covers positions i .. i+22
+            const uint32_t clean = ~(uint32_t)nn;
+            // PAM test, 32 window starts at a time (bidir_mapping.cpp:71-76, 240-247)
+            const uint32_t H21 = funnel(H1, H0, 21), L21 = funnel(L1, L0, 21);
+            const uint32_t H22 = funnel(H1, H0, 22), L22 = funnel(L1, L0, 22);
+            const uint32_t Hs1 = funnel(H1, H0, 1), Ls1 = funnel(L1, L0, 1);
+            uint32_t vf = 0, vr = 0;
+            for (uint32_t i = 0; i < a.n_pam; ++i) {
+                const PamMasks p = a.pam[i];
+                // '+': window[21] == a and window[22] == b
+                vf |= ~(H21 ^ p.ah) & ~(L21 ^ p.al) & ~(H22 ^ p.bh) & ~(L22 ^ p.bl);
+                // '-': window[0] == comp(b) and window[1] == comp(a)
+                vr |= (H0 ^ p.bh) & (L0 ^ p.bl) & (Hs1 ^ p.ah) & (Ls1 ^ p.al);
+            }
+            uint32_t mf = vf & clean, mr = vr & clean;
+            const uint32_t base_pos = a.first_pos + tile * (uint32_t)kTileBases + w.lane * 32u;
+
+            // ---- move the valid sites into the wave's queue, at most one per lane per step ----
+            for (;;) {
+                const bool has = (mf | mr) != 0;
+                const uint64_t act = __ballot(has);
+                if (act == 0) break;
+                const bool is_rev = mf == 0;
+                const uint32_t msk = is_rev ? mr : mf;
+                const uint32_t b = has ? (uint32_t)__builtin_ctz(msk) : 0u;
+                const uint32_t rest = msk & (msk - 1u);
+                if (is_rev) mr = rest; else mf = rest;
+                uint32_t ph = funnel(H1, H0, b) & kMask23;
+                uint32_t pl = funnel(L1, L0, b) & kMask23;
+                if (is_rev) {
+                    ph = revcomp_plane(ph) | (1u << 23);
+                    pl = revcomp_plane(pl);
+                }
+                if (has) {
+                    const uint32_t at = w.q + lanes_below(act);
+                    w.qsh[at] = ph;
+                    w.qsl[at] = pl;
+                    w.qpos[at] = base_pos + b;
+                }
+                const uint32_t added = (uint32_t)__popcll(act);
+                w.q += added;
+                sites += added;
+                wave_sync();
+                if (w.q >= (uint32_t)kBatch) process_batch(a, w);
+            }
+        }
+    }
+    if (w.q > 0) process_batch(a, w);
+    flush_hits(a, w);
+    if (w.lane == 0 && sites) atomicAdd(&a.counters[kCntSites], sites);
+}
+
+hipError_t launch_scan(const ScanArgs &args, int n_groups, hipStream_t stream)
+{
+    hipLaunchKernelGGL(scan_kernel, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// sort (rocPRIM radix sort of the 64-bit hit keys with their 32-bit payload)
+// ------------------------------------------------------------------------------------------------
+hipError_t sort_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes)
+{
+    *bytes = 0;
+    return rocprim::radix_sort_pairs((void *)nullptr, *bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                     (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, end_bit);
+}
+
+hipError_t launch_sort(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
+                       const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream)
+{
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit,
+                                     stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: sorted (key, value) pairs -> vsc_hit records
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t contig_of(const uint32_t *contig_off, uint32_t n_contigs, uint32_t pos)
+{
+    uint32_t lo = 0, hi = n_contigs;  // last contig whose start is <= pos
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (contig_off[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const uint64_t key = a.keys[i];
+    const uint32_t pos = (uint32_t)key;
+    const uint32_t strand = (uint32_t)(key >> 32) & 1u;
+    const uint32_t c = contig_of(a.contig_off, a.n_contigs, pos);
+    vsc_hit h;
+    h.guide = (uint32_t)(key >> 33);
+    h.contig = c;
+    h.pos = pos - a.contig_off[c];
+    h.info = (strand << 31) | a.vals[i];
+    a.out[i] = h;
+}
+
+hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream)
+{
+    if (args.n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((args.n + 255) / 256);
+    hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-hit scores
+// ------------------------------------------------------------------------------------------------
+// variant_processing/mit_score.h:42 - position weights
+__constant__ double kMitWeights[20] = {0,     0,     0.014, 0,     0,     0.395, 0.317, 0,     0.389, 0.079,
+                                       0.445, 0.508, 0.613, 0.851, 0.732, 0.828, 0.615, 0.804, 0.685, 0.583};
+
+// calcMitScore (variant_processing/mit_score.h:12-68) on the set bits of `mask` (ascending positions,
+// forward-genome window coordinates - merge_output_bam.h:549 passes the MD-derived positions as is).
+// fp64 with the reference's operation order; contraction off so no multiply-add is fused.
+__device__ double mit_score(uint32_t mask, int *ub)
+{
+#pragma clang fp contract(off)
+    *ub = 0;
+    const int n = __popc(mask);
+    if (n == 0) return 100.0;  // perfectMatch {-1}, :19-22,38-41
+    const int last = 31 - __clz(mask);
+    const unsigned nm = last < 20 ? (unsigned)n : (unsigned)n - 1u;  // :26-33
+    if (nm == 0) return 100.0;                                       // :38-41
+    const double s3 = (double)1 / ((double)nm * (double)nm);        // :35, pow(nm, 2) is exact
+    double s1 = 1;
+    int dist_sum = 0, prev = 0;
+    uint32_t rest = mask;
+    for (unsigned i = 0; i < nm; ++i) {  // :48-55
+        const int p = __ffs(rest) - 1;
+        rest &= rest - 1u;
+        double wgt = 0;
+        if (p < 20) wgt = kMitWeights[p]; else *ub = 1;  // the reference reads past its 20-entry table here
+        s1 *= (1 - wgt);
+        if (i > 0) dist_sum += p - prev;
+        prev = p;
+    }
+    double s2;
+    if (nm < 2) {  // :57-60
+        s2 = 1;
+    } else {
+        const double avg = (double)dist_sum / (double)(nm - 1u);  // :63
+        s2 = 1 / (((19 - avg) / 19) * 4 + 1);                      // :64
+    }
+    return s1 * s2 * s3 * 100;  // :66
+}
+
+// featureMatrixRecord (variant_processing/feature_matrix.h:25-126): on / off are 23-base plane pairs
+// in read orientation.  f points at 442 zeroed bytes.
+__device__ void feature_row(uint32_t on_h, uint32_t on_l, uint32_t off_h, uint32_t off_l, uint8_t *f)
+{
+    bool prec = false;
+    for (int i = 0; i < VSC_READ_LEN - 2; ++i) {  // :53
+        const int b = (int)(((off_h >> i) & 1u) << 1 | ((off_l >> i) & 1u));
+        if (i < 19) {  // :56-61
+            const int b2 = (int)(((off_h >> (i + 1)) & 1u) << 1 | ((off_l >> (i + 1)) & 1u));
+            const int pair = b * 4 + b2;
+            f[120 + i * 16 + pair] = 1;
+            f[424 + pair]++;
+        }
+        f[36 + i * 4 + b] = 1;  // :64-83
+        const int o = (int)(((on_h >> i) & 1u) << 1 | ((on_l >> i) & 1u));
+        if (o != b) {  // :86
+            f[0]++;
+            f[i + 1] = 1;
+            if (i > 7 && i < 20) f[441]++;  // :94-98
+            if (prec) f[440]++;              // :100-103
+            prec = true;
+            // :47 transitions AG, CT, GA, TC <=> the two codes differ in the hi bit only
+            if ((o ^ b) == 2) f[34]++; else f[35]++;
+            // :45-46 AC,AG,AT,CA,CG,CT,GA,GC,GT,TA,TC,TG -> 0..11
+            f[22 + o * 3 + (b > o ? b - 1 : b)] = 1;  // :119
+        } else {
+            prec = false;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void score_kernel(const ScoreArgs a)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const vsc_hit h = a.hits[i];
+    const uint32_t mask = VSC_HIT_MASK(h.info);
+    if (a.mit || a.mit_flags) {
+        int ub;
+        const double s = mit_score(mask, &ub);
+        if (a.mit) a.mit[i] = s;
+        if (a.mit_flags) a.mit_flags[i] = (uint8_t)ub;
+    }
+    if (a.features) {
+        // off-target = genome[pos, pos+23), reverse-complemented for '-' (filter_output_bam.h:399)
+        const uint32_t rel = a.contig_off[h.contig] + h.pos - a.first_pos;
+        const uint64_t wi = rel >> 5;
+        const uint32_t sh = rel & 31u;
+        uint32_t oh = funnel(a.hi[wi + 1], a.hi[wi], sh) & kMask23;
+        uint32_t ol = funnel(a.lo[wi + 1], a.lo[wi], sh) & kMask23;
+        if (VSC_HIT_STRAND(h.info)) {
+            oh = revcomp_plane(oh);
+            ol = revcomp_plane(ol);
+        }
+        const uint2 g = a.guides[h.guide];
+        uint8_t *f = a.features + i * VSC_N_FEATURES;
+        for (int k = 0; k < VSC_N_FEATURES; ++k) f[k] = 0;
+        feature_row(g.x, g.y, oh, ol, f);
+    }
+}
+
+hipError_t launch_score(const ScoreArgs &args, hipStream_t stream)
+{
+    if (args.n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((args.n + 255) / 256);
+    hipLaunchKernelGGL(score_kernel, dim3(blocks), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace vsc
