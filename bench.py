@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the off-target search hot path (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input: all reads of the workload
+searched (both strands) against the resident synthetic 3 Gbp genome - scan kernel, radix sort of the
+hits, record assembly - and, for N > 1, the RCCL gather of the hit records to rank 0 plus the merge
+there.  Inputs (packed genome planes) are resident in HBM before the timed region starts; results
+stay in HBM.  The genome is sharded by position range across ranks (total work fixed => strong
+scaling).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (reads, genome bases, max mismatches, description)  - BASELINE.json configs
+    "c1": (10, 1_000_000, 4, "10 guides, 1 Mbp synthetic genome, <=4 mismatches"),
+    "c2": (1_000, 3_000_000_000, 6, "1 000 guides, hg38-sized 3 Gbp synthetic ref, <=6 mismatches"),
+    "c3": (10_000, 3_000_000_000, 8, "10 000 guides, 3 Gbp synthetic ref, <=8 mismatches, genome-sharded"),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz (32-bit integer lane-ops / s)
+LANE_OPS_PER_COMPARE = 3.5  # v_xor + v_bitop3 + v_bcnt + 1/2 v_min3 per (site, read) pair
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--guides", type=int, default=None, help="override the read count")
+    ap.add_argument("--bases", type=int, default=None, help="override the genome size")
+    ap.add_argument("--mismatches", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-bases", type=int, default=192_000_000)
+    ap.add_argument("--cpu-sample-guides", type=int, default=64)
+    return ap.parse_args()
+
+
+def cpu_baseline(total_bases, max_mm, sample_bases, sample_guides, seqs):
+    """The oracle's bit-parallel OpenMP port (oracle/vsc_fastport.c, kind "port": the reference itself
+    needs SeqAn and cannot be built) timed on a bounded slice of the same synthetic genome."""
+    from oracle import pyoracle
+    from varscot_amd import synth
+    pyoracle.build()
+    # a slice that starts past the leading N block of chr1
+    w0 = 20_000 // 32
+    hi, lo, nm, table, names, _ = synth.synthetic_planes(total_bases, w0, w0 + sample_bases // 32)
+    from varscot_amd.api import PackedGenome
+    import ctypes as C
+    from varscot_amd._lib import lib, ptr
+    buf = C.create_string_buffer(len(hi) * 32)
+    lib().vsc_unpack_bases(ptr(hi), ptr(lo), ptr(nm), 0, len(hi) * 32, buf)
+    text = buf.raw
+    guides = seqs[:sample_guides]
+    threads = pyoracle.max_threads()
+    t0 = time.perf_counter()
+    hits, sites = pyoracle.count_fast([text], guides, max_mm, threads=threads)
+    dt = time.perf_counter() - t0
+    scale = len(text) / float(total_bases)
+    return {
+        "value": len(guides) / dt * scale, "unit": "guides/s", "cores": threads, "kind": "port",
+        "sample": "%d reads x %.0f Mbp slice of the same synthetic genome, <=%d mismatches, %.1f s wall, "
+                  "scaled linearly to %.1f Gbp; bit-parallel scan port of the oracle (the reference's "
+                  "FM-index search needs SeqAn and cannot be built here)"
+                  % (len(guides), len(text) / 1e6, max_mm, dt, total_bases / 1e9),
+        "sites_per_s": hits / dt, "cpu_seconds": dt * threads,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    import varscot_amd as va
+    from varscot_amd import synth
+    from varscot_amd import dist as vdist
+
+    n_guides, total_bases, max_mm, desc = WORKLOADS[args.workload]
+    n_guides = args.guides or n_guides
+    total_bases = args.bases or total_bases
+    max_mm = args.mismatches if args.mismatches is not None else max_mm
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    # ---- inputs: this rank's shard of the synthetic genome, resident in HBM ------------------------
+    table, names = synth.contig_table(total_bases)
+    span = int(table[-1]["offset"]) + int(table[-1]["length"]) + 1
+    n_words_total = (span + 31) // 32
+    wb, we = vdist.shard_words(n_words_total, rank, world)
+    t_gen = time.perf_counter()
+    hi, lo, nm, _, _, _ = synth.synthetic_planes(total_bases, wb, min(we + 1, n_words_total))
+    t_gen = time.perf_counter() - t_gen
+    ctx = va.Context(local_rank)
+    genome = va.Genome.from_shard(ctx, hi, lo, nm, wb, we - wb, table)
+    del hi, lo, nm
+    ids, seqs = synth.synthetic_guides(n_guides)
+    codes = va.pack_guides(seqs)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        if world == 1:
+            return genome.search(codes, max_mm), None
+        merged, local = vdist.sharded_search(ctx, genome, codes, max_mm, device=device)
+        return local, merged
+
+    scan_ms, sort_ms, fin_ms, hits_local, sites_local, passes = [], [], [], 0, 0, 0
+    total_hits = 0
+    for i in range(args.warmup):
+        h, m = step()
+        h.close()
+        if m is not None:
+            m.close()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        h, m = step()
+        t = ctx.timing()
+        scan_ms.append(t["scan_ms"])
+        sort_ms.append(t["sort_ms"])
+        fin_ms.append(t["finalize_ms"])
+        hits_local, sites_local, passes = t["hits"], t["sites"], max(passes, t["passes"])
+        total_hits = len(m) if m is not None else len(h)
+        h.close()
+        if m is not None:
+            m.close()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        agg = torch.tensor([float(sites_local), float(np.mean(scan_ms))], dtype=torch.float64, device=device)
+        sites_all = agg.clone()
+        dist.all_reduce(sites_all, op=dist.ReduceOp.SUM)
+        total_sites = float(sites_all[0].item())
+    else:
+        total_sites = float(sites_local)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        guides_per_s = n_guides * args.steps / dt
+        # roofline of the dominant kernel (scan_kernel), per launch, this rank's shard
+        own_bases = (we - wb) * 32
+        alg_bytes = 0.375 * own_bases + 16.0 * hits_local + 16.0 * n_guides
+        scan_avg_ms = float(np.mean(scan_ms))
+        achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
+        compares = float(sites_local) * n_guides
+        lane_ops = compares * LANE_OPS_PER_COMPARE / (scan_avg_ms * 1e-3)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("%s/%d" % (args.workload, world))
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "guides/sec (candidate sites/sec alongside) at <=%d mismatches on a %.1f Gbp reference" % (max_mm, total_bases / 1e9),
+            "value": guides_per_s, "unit": "guides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, desc), "guides": n_guides, "genome_bases": total_bases,
+                       "max_mismatches": max_mm, "parallelism": "genome-shard x%d" % world,
+                       "hits_per_step": int(total_hits), "candidate_sites_per_s": total_hits * args.steps / dt,
+                       "pam_valid_sites": int(total_sites), "scan_passes": passes},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "scan_kernel", "launch_ms": scan_avg_ms, "algorithmic_bytes": alg_bytes,
+                         "note": "integer/bitwise scan: VALU-bound for every read batch >= 1 (DESIGN.md); "
+                                 "the VALU figures are the binding ones",
+                         "valu": {"pair_compares_per_s": compares / (scan_avg_ms * 1e-3),
+                                  "lane_ops_per_compare": LANE_OPS_PER_COMPARE, "achieved_lane_ops_per_s": lane_ops,
+                                  "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK, "frac": lane_ops / VALU_LANE_OPS_PEAK}},
+            "kernels_ms": {"scan": scan_avg_ms, "sort": float(np.mean(sort_ms)), "finalize": float(np.mean(fin_ms))},
+            "setup": {"genome_generate_s": t_gen, "genome_hbm_bytes": genome.device_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(total_bases, max_mm, args.cpu_sample_bases, args.cpu_sample_guides, seqs)
+        print(json.dumps(out), flush=True)
+
+    genome.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -162,6 +162,17 @@ uint64_t vsc_hits_count(const vsc_hits *hits);
 const void *vsc_hits_data_dev(const vsc_hits *hits);
 /* Host copy of the records (made on first use; valid until vsc_hits_free). */
 int vsc_hits_data(vsc_hits *hits, const vsc_hit **out);
+/* Copies the records into caller memory (host, or device when dst_is_device != 0 - e.g. a tensor the
+ * caller hands to RCCL). */
+int vsc_hits_copy(vsc_hits *hits, void *dst, int dst_is_device);
+/*
+ * Multi-GPU: merges the results of genome shards.  records_dev = the vsc_hit records of shard 0,
+ * shard 1, ... concatenated in shard order in device memory (each as vsc_search returned them; contig
+ * and pos are already global, so nothing is rewritten).  Because shards partition the positions in
+ * ascending order, a stable sort on (guide, strand) restores the global result order.  Replaces the
+ * concatenation of per-thread output buffers, read_mapping/bidir_mapping.cpp:307-308.
+ */
+int vsc_hits_merge(vsc_ctx *ctx, const void *records_dev, uint64_t n, uint32_t n_guides, vsc_hits **out);
 int vsc_hits_free(vsc_hits *hits);
 
 /*

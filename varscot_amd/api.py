@@ -113,18 +113,32 @@ class Genome:
     """(A shard of) a packed genome resident in HBM (vsc_genome)."""
 
     def __init__(self, ctx, packed, rank=0, world=1):
-        self.ctx, self.packed = ctx, packed
         b, e = packed.shard_words(rank, world)
         if e <= b:
             raise ValueError("rank %d of %d owns no words of this genome" % (rank, world))
         halo_end = min(e + 1, packed.n_words)  # 22-base halo = 1 word
-        self.first_word, self.own_words = b, e - b
-        hi = np.ascontiguousarray(packed.hi[b:halo_end])
-        lo = np.ascontiguousarray(packed.lo[b:halo_end])
-        nm = np.ascontiguousarray(packed.nmask[b:halo_end])
+        self._load(ctx, packed.hi[b:halo_end], packed.lo[b:halo_end], packed.nmask[b:halo_end], b, e - b,
+                   packed.contigs)
+        self.packed = packed
+
+    @classmethod
+    def from_shard(cls, ctx, hi, lo, nmask, first_word, own_words, contigs):
+        """Planes of words [first_word, first_word + len(hi)) of which the first own_words are owned."""
+        self = cls.__new__(cls)
+        self.packed = None
+        self._load(ctx, hi, lo, nmask, first_word, own_words, contigs)
+        return self
+
+    def _load(self, ctx, hi, lo, nm, first_word, own_words, contigs):
+        self.ctx = ctx
+        self.first_word, self.own_words = first_word, own_words
+        hi = np.ascontiguousarray(hi, dtype=np.uint32)
+        lo = np.ascontiguousarray(lo, dtype=np.uint32)
+        nm = np.ascontiguousarray(nm, dtype=np.uint32)
+        contigs = np.ascontiguousarray(contigs, dtype=CONTIG_DTYPE)
         self._h = C.c_void_p()
-        check(lib().vsc_genome_load(ctx._h, ptr(hi), ptr(lo), ptr(nm), b, len(hi), e - b, ptr(packed.contigs),
-                                    len(packed.contigs), C.byref(self._h)), ctx._h)
+        check(lib().vsc_genome_load(ctx._h, ptr(hi), ptr(lo), ptr(nm), first_word, len(hi), own_words, ptr(contigs),
+                                    len(contigs), C.byref(self._h)), ctx._h)
 
     @property
     def device_bytes(self):
@@ -180,6 +194,10 @@ class Hits:
         buf = (C.c_char * (n * HIT_DTYPE.itemsize)).from_address(p.value)
         return np.frombuffer(buf, dtype=HIT_DTYPE).copy()
 
+    def copy_to(self, dst_ptr, dst_is_device):
+        """Copy the records to caller memory (e.g. the data_ptr() of a uint8 tensor handed to RCCL)."""
+        check(lib().vsc_hits_copy(self._h, C.c_void_p(dst_ptr), int(bool(dst_is_device))), self.genome.ctx._h)
+
     def scores(self, first=0, count=None, mit=True, features=False):
         """(mit float64[count] | None, mit_flags uint8[count] | None, features uint8[count,442] | None)."""
         count = len(self) - first if count is None else count
@@ -200,6 +218,30 @@ class Hits:
             self.close()
         except Exception:
             pass
+
+
+class MergedHits(Hits):
+    """Result of vsc_hits_merge: the records of all genome shards in global order (rank 0 only)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self._h, self.codes, self.genome = ctx, handle, None, None
+
+    def to_numpy(self):
+        n = len(self)
+        out = np.zeros(n, dtype=HIT_DTYPE)
+        if n:
+            check(lib().vsc_hits_copy(self._h, ptr(out), 0), self.ctx._h)
+        return out
+
+    def scores(self, *a, **k):
+        raise NotImplementedError("score hits on the rank that owns the shard, before the gather")
+
+
+def merge_shard_records(ctx, records_dev_ptr, n, n_guides):
+    """records_dev_ptr: device pointer to n vsc_hit records = shard results concatenated in shard order."""
+    h = C.c_void_p()
+    check(lib().vsc_hits_merge(ctx._h, C.c_void_p(records_dev_ptr), n, n_guides, C.byref(h)), ctx._h)
+    return MergedHits(ctx, h)
 
 
 def sam_order(hits):

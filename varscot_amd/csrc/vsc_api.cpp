@@ -458,6 +458,64 @@ int vsc_hits_data(vsc_hits *hits, const vsc_hit **out)
     return VSC_OK;
 }
 
+int vsc_hits_copy(vsc_hits *hits, void *dst, int dst_is_device)
+{
+    if (!hits || (!dst && hits->n)) return VSC_ERR_INVALID;
+    if (hits->n == 0) return VSC_OK;
+    vsc_ctx *ctx = hits->ctx;
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    VSC_HIP(ctx, hipMemcpyAsync(dst, hits->d_records, hits->n * sizeof(vsc_hit),
+                                dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VSC_OK;
+}
+
+int vsc_hits_merge(vsc_ctx *ctx, const void *records_dev, uint64_t n, uint32_t n_guides, vsc_hits **out)
+{
+    if (!ctx || !out) return VSC_ERR_INVALID;
+    *out = nullptr;
+    ctx->err.clear();
+    if (n && !records_dev) return fail(ctx, VSC_ERR_INVALID, "vsc_hits_merge: null argument");
+    if (n >= (1ull << 32)) return fail(ctx, VSC_ERR_RANGE, "vsc_hits_merge: more than 2^32 records");
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    vsc_hits *hits = new (std::nothrow) vsc_hits();
+    if (!hits) return fail(ctx, VSC_ERR_NOMEM, "vsc_hits_merge: out of host memory");
+    hits->ctx = ctx;
+    hits->n = n;
+    if (n == 0) {
+        hits->host_valid = true;
+        *out = hits;
+        return VSC_OK;
+    }
+    unsigned guide_bits = 1;
+    while (guide_bits < 31 && (1ull << guide_bits) < n_guides) ++guide_bits;
+    const unsigned end_bit = guide_bits + 1;
+    size_t temp_bytes = 0;
+    hipError_t e = merge_temp_bytes(n, end_bit, &temp_bytes);
+    auto step = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+    };
+    // the four 32-bit work arrays reuse the search scratch buffers
+    step(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
+    step(ctx->keys_a.ensure(n * sizeof(uint32_t)));
+    step(ctx->keys_b.ensure(n * sizeof(uint32_t)));
+    step(ctx->vals_a.ensure(n * sizeof(uint32_t)));
+    step(ctx->vals_b.ensure(n * sizeof(uint32_t)));
+    step(hipMalloc((void **)&hits->d_records, n * sizeof(vsc_hit)));
+    step(hipEventRecord(ctx->ev[0], ctx->stream));
+    step(launch_merge(ctx->sort_temp.p, temp_bytes, (const vsc_hit *)records_dev, n, end_bit, (uint32_t *)ctx->keys_a.p,
+                      (uint32_t *)ctx->keys_b.p, (uint32_t *)ctx->vals_a.p, (uint32_t *)ctx->vals_b.p, hits->d_records,
+                      ctx->stream));
+    step(hipEventRecord(ctx->ev[1], ctx->stream));
+    step(hipStreamSynchronize(ctx->stream));
+    if (e != hipSuccess) {
+        vsc_hits_free(hits);
+        return fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, "vsc_hits_merge", e);
+    }
+    *out = hits;
+    return VSC_OK;
+}
+
 int vsc_hits_free(vsc_hits *hits)
 {
     if (!hits) return VSC_OK;

@@ -79,5 +79,8 @@ hipError_t launch_sort(void *temp, size_t temp_bytes, const uint64_t *keys_in, u
                        const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream);
 hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream);
 hipError_t launch_score(const ScoreArgs &args, hipStream_t stream);
+hipError_t merge_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
+hipError_t launch_merge(void *temp, size_t temp_bytes, const vsc_hit *in, uint64_t n, unsigned end_bit, uint32_t *keys_a,
+                        uint32_t *keys_b, uint32_t *idx_a, uint32_t *idx_b, vsc_hit *out, hipStream_t stream);
 
 }  // namespace vsc

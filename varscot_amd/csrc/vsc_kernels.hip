@@ -351,6 +351,47 @@ hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream)
 }
 
 // ------------------------------------------------------------------------------------------------
+// merge of per-shard results: a stable sort of the concatenated records by (guide, strand) restores
+// the global (guide, strand, contig, pos) order, because shards partition the positions in order
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_key_kernel(const vsc_hit *in, uint64_t n, uint32_t *keys, uint32_t *idx)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = (in[i].guide << 1) | VSC_HIT_STRAND(in[i].info);
+    idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const vsc_hit *in, const uint32_t *idx, uint64_t n, vsc_hit *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = in[idx[i]];
+}
+
+hipError_t merge_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes)
+{
+    *bytes = 0;
+    return rocprim::radix_sort_pairs((void *)nullptr, *bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                     (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, end_bit);
+}
+
+hipError_t launch_merge(void *temp, size_t temp_bytes, const vsc_hit *in, uint64_t n, unsigned end_bit, uint32_t *keys_a,
+                        uint32_t *keys_b, uint32_t *idx_a, uint32_t *idx_b, vsc_hit *out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(merge_key_kernel, dim3(blocks), dim3(256), 0, stream, in, n, keys_a, idx_a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_a, keys_b, (const uint32_t *)idx_a, idx_b,
+                                  (size_t)n, 0u, end_bit, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, stream, in, (const uint32_t *)idx_b, n, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // per-hit scores
 // ------------------------------------------------------------------------------------------------
 // variant_processing/mit_score.h:42 - position weights
