@@ -211,3 +211,55 @@ def test_features_match_reference_golden_on_gpu(ctx, golden_dir):
     hits.close()
     gen.close()
     assert step == len(contigs[0])
+
+
+# ------------------------------------------------------------------------------------ multi-rank
+def _rank_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from varscot_amd import dist as vdist
+        rng = np.random.default_rng(4242)
+        guides = random_guides(rng, 16)
+        contigs = make_genome(4242, [300000, 120000, 70000, 23], guides, 7, n_plant=400, n_runs=6)
+        packed = va.PackedGenome.from_sequences(contigs)
+        c = va.Context(0)  # both ranks share the one GPU of the test box; the data path is per rank
+        shard = c.load_genome(packed, rank, world)
+        merged, local = vdist.sharded_search(c, shard, va.pack_guides(guides), 7)
+        if rank == 0:
+            q.put(merged.to_numpy().tobytes())
+            merged.close()
+        local.close()
+        shard.close()
+        c.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_over_gloo(oracle):
+    """Two ranks, each scanning its genome shard on the GPU, one gather, merge on rank 0."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    blob = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    got = np.frombuffer(blob, dtype=va.HIT_DTYPE)
+    rng = np.random.default_rng(4242)
+    guides = random_guides(rng, 16)
+    contigs = make_genome(4242, [300000, 120000, 70000, 23], guides, 7, n_plant=400, n_runs=6)
+    want = oracle.search_fast(contigs, guides, 7)
+    assert len(want) > 300
+    assert got.tobytes() == want.tobytes()
