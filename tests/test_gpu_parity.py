@@ -215,6 +215,7 @@ def test_features_match_reference_golden_on_gpu(ctx, golden_dir):
 
 # ------------------------------------------------------------------------------------ multi-rank
 def _rank_worker(rank, world, port, q):
+    import traceback
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -235,6 +236,9 @@ def _rank_worker(rank, world, port, q):
         shard.close()
         c.close()
         dist.barrier()
+    except Exception:
+        q.put("rank %d failed: %s" % (rank, traceback.format_exc()))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -252,7 +256,8 @@ def test_sharded_search_over_gloo(oracle):
     procs = [mpctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    blob = q.get(timeout=300)
+    blob = q.get(timeout=120)
+    assert isinstance(blob, bytes), blob
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

@@ -470,12 +470,13 @@ int vsc_hits_copy(vsc_hits *hits, void *dst, int dst_is_device)
     return VSC_OK;
 }
 
-int vsc_hits_merge(vsc_ctx *ctx, const void *records_dev, uint64_t n, uint32_t n_guides, vsc_hits **out)
+int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, uint64_t n, uint32_t n_guides,
+                   vsc_hits **out)
 {
     if (!ctx || !out) return VSC_ERR_INVALID;
     *out = nullptr;
     ctx->err.clear();
-    if (n && !records_dev) return fail(ctx, VSC_ERR_INVALID, "vsc_hits_merge: null argument");
+    if (n && !records) return fail(ctx, VSC_ERR_INVALID, "vsc_hits_merge: null argument");
     if (n >= (1ull << 32)) return fail(ctx, VSC_ERR_RANGE, "vsc_hits_merge: more than 2^32 records");
     VSC_HIP(ctx, hipSetDevice(ctx->device));
     vsc_hits *hits = new (std::nothrow) vsc_hits();
@@ -502,8 +503,15 @@ int vsc_hits_merge(vsc_ctx *ctx, const void *records_dev, uint64_t n, uint32_t n
     step(ctx->vals_a.ensure(n * sizeof(uint32_t)));
     step(ctx->vals_b.ensure(n * sizeof(uint32_t)));
     step(hipMalloc((void **)&hits->d_records, n * sizeof(vsc_hit)));
+    const vsc_hit *records_dev = (const vsc_hit *)records;
+    if (!records_on_device) {
+        step(ctx->score_feat.ensure(n * sizeof(vsc_hit)));  // staging buffer for host input
+        if (e == hipSuccess)
+            step(hipMemcpyAsync(ctx->score_feat.p, records, n * sizeof(vsc_hit), hipMemcpyHostToDevice, ctx->stream));
+        records_dev = (const vsc_hit *)ctx->score_feat.p;
+    }
     step(hipEventRecord(ctx->ev[0], ctx->stream));
-    step(launch_merge(ctx->sort_temp.p, temp_bytes, (const vsc_hit *)records_dev, n, end_bit, (uint32_t *)ctx->keys_a.p,
+    step(launch_merge(ctx->sort_temp.p, temp_bytes, records_dev, n, end_bit, (uint32_t *)ctx->keys_a.p,
                       (uint32_t *)ctx->keys_b.p, (uint32_t *)ctx->vals_a.p, (uint32_t *)ctx->vals_b.p, hits->d_records,
                       ctx->stream));
     step(hipEventRecord(ctx->ev[1], ctx->stream));

@@ -62,8 +62,7 @@ def sharded_search(ctx, genome_shard, codes, max_mismatches, extra_pam=None, gro
     gathered, counts = gather_records(local, group)
     merged = None
     if gathered is not None:
-        if not gathered.is_cuda:  # gloo rehearsal: the merge itself only exists on the GPU
-            gathered = gathered.to(torch.device("cuda", ctx.device))
-        torch.cuda.current_stream(gathered.device).synchronize()
-        merged = merge_shard_records(ctx, gathered.data_ptr(), sum(counts), len(codes))
+        if gathered.is_cuda:
+            torch.cuda.current_stream(gathered.device).synchronize()
+        merged = merge_shard_records(ctx, gathered.data_ptr(), gathered.is_cuda, sum(counts), len(codes))
     return merged, hits
