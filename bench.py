@@ -42,7 +42,10 @@ def parse():
     ap.add_argument("--guides", type=int, default=None, help="override the read count")
     ap.add_argument("--bases", type=int, default=None, help="override the genome size")
     ap.add_argument("--mismatches", type=int, default=None)
+    ap.add_argument("--algorithm", default="auto", choices=["auto", "scan", "seed"],
+                    help="scan = stream the packed planes; seed = resident pigeonhole site tables; auto = seed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL gather/merge path even with one rank")
     ap.add_argument("--cpu-sample-bases", type=int, default=192_000_000)
     ap.add_argument("--cpu-sample-guides", type=int, default=64)
     return ap.parse_args()
@@ -102,9 +105,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     # ---- inputs: this rank's shard of the synthetic genome, resident in HBM ------------------------
     table, names = synth.contig_table(total_bases)
@@ -119,19 +124,25 @@ def main():
     del hi, lo, nm
     ids, seqs = synth.synthetic_guides(n_guides)
     codes = va.pack_guides(seqs)
+    algorithm = "seed" if args.algorithm == "auto" else args.algorithm
+    index_ms = None
+    if algorithm == "seed":  # the resident site tables are part of the inputs, like the reference's FM index
+        genome.build_index()
+        index_ms = ctx.timing()["index_ms"]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def step():
-        if world == 1:
-            return genome.search(codes, max_mm), None
-        merged, local = vdist.sharded_search(ctx, genome, codes, max_mm, device=device)
+        if not use_dist:
+            return genome.search(codes, max_mm, algorithm=algorithm), None
+        merged, local = vdist.sharded_search(ctx, genome, codes, max_mm, device=device, algorithm=algorithm)
         return local, merged
 
-    scan_ms, sort_ms, fin_ms, hits_local, sites_local, passes = [], [], [], 0, 0, 0
+    scan_ms, sort_ms, fin_ms, prep_ms, hits_local, sites_local, passes = [], [], [], [], 0, 0, 0
+    pairs_local, stream_bytes = 0, 0
     total_hits = 0
     for i in range(args.warmup):
         h, m = step()
@@ -146,14 +157,16 @@ def main():
         scan_ms.append(t["scan_ms"])
         sort_ms.append(t["sort_ms"])
         fin_ms.append(t["finalize_ms"])
+        prep_ms.append(t["prep_ms"])
         hits_local, sites_local, passes = t["hits"], t["sites"], max(passes, t["passes"])
+        pairs_local, stream_bytes = t["pairs"], t["genome_bytes"]
         total_hits = len(m) if m is not None else len(h)
         h.close()
         if m is not None:
             m.close()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -167,18 +180,28 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         guides_per_s = n_guides * args.steps / dt
-        # roofline of the dominant kernel (scan_kernel), per launch, this rank's shard
+        # roofline of the dominant kernel, per launch, this rank's shard
         own_bases = (we - wb) * 32
-        alg_bytes = 0.375 * own_bases + 16.0 * hits_local + 16.0 * n_guides
         scan_avg_ms = float(np.mean(scan_ms))
+        if algorithm == "scan":
+            kernel = "scan_kernel"
+            # 0.375 B/base of planes + 16 B per hit + 16 B per read
+            alg_bytes = 0.375 * own_bases + 16.0 * hits_local + 16.0 * n_guides
+        else:
+            kernel = "seed_compare_kernel"
+            # site records of the visited buckets (8 B each, read once) + the per-bucket read lists
+            # (12 B per entry) + 12 B per hit written
+            k_seg = max_mm // 3
+            list_entries = n_guides * 3 * (1, 22, 211)[k_seg]
+            alg_bytes = float(stream_bytes) + 12.0 * list_entries + 12.0 * hits_local
         achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
-        compares = float(sites_local) * n_guides
+        compares = float(pairs_local)
         lane_ops = compares * LANE_OPS_PER_COMPARE / (scan_avg_ms * 1e-3)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%s/%d" % (args.workload, world))
+                traffic = json.load(open(tpath)).get("%s/%s/%d" % (args.workload, algorithm, world))
             except Exception:
                 traffic = None
         out = {
@@ -187,19 +210,20 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, desc), "guides": n_guides, "genome_bases": total_bases,
-                       "max_mismatches": max_mm, "parallelism": "genome-shard x%d" % world,
+                       "max_mismatches": max_mm, "parallelism": "genome-shard x%d" % world, "algorithm": algorithm,
                        "hits_per_step": int(total_hits), "candidate_sites_per_s": total_hits * args.steps / dt,
                        "pam_valid_sites": int(total_sites), "scan_passes": passes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "scan_kernel", "launch_ms": scan_avg_ms, "algorithmic_bytes": alg_bytes,
-                         "note": "integer/bitwise scan: VALU-bound for every read batch >= 1 (DESIGN.md); "
-                                 "the VALU figures are the binding ones",
+                         "kernel": kernel, "launch_ms": scan_avg_ms, "algorithmic_bytes": alg_bytes,
+                         "note": "integer/bitwise compare kernel; VALU issue is the binding resource next to HBM "
+                                 "(DESIGN.md section 4) - both are reported",
                          "valu": {"pair_compares_per_s": compares / (scan_avg_ms * 1e-3),
                                   "lane_ops_per_compare": LANE_OPS_PER_COMPARE, "achieved_lane_ops_per_s": lane_ops,
                                   "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK, "frac": lane_ops / VALU_LANE_OPS_PEAK}},
-            "kernels_ms": {"scan": scan_avg_ms, "sort": float(np.mean(sort_ms)), "finalize": float(np.mean(fin_ms))},
-            "setup": {"genome_generate_s": t_gen, "genome_hbm_bytes": genome.device_bytes},
+            "kernels_ms": {"search": scan_avg_ms, "prep": float(np.mean(prep_ms)), "sort": float(np.mean(sort_ms)),
+                           "finalize": float(np.mean(fin_ms))},
+            "setup": {"genome_generate_s": t_gen, "genome_hbm_bytes": genome.device_bytes, "index_build_ms": index_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(total_bases, max_mm, args.cpu_sample_bases, args.cpu_sample_guides, seqs)
@@ -207,7 +231,7 @@ def main():
 
     genome.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -80,21 +80,34 @@ typedef struct {
     uint32_t max_mismatches; /* -M, 0..8 (:234-238) */
     uint8_t has_extra_pam;   /* -P given */
     char extra_pam[2];       /* -P: additional non-canonical PAM besides (N)GG and (N)GA (:240-247) */
-    uint8_t reserved;
+    uint8_t algorithm;       /* VSC_ALGO_*: how the (identical) hit set is computed */
 } vsc_search_params;
+
+/* Both algorithms return the same records.  SCAN streams the packed planes and compares every
+ * PAM-valid window with every read.  SEED keeps the PAM-valid windows filed by 7-base segments in HBM
+ * (built once per genome and PAM set, vsc_genome_build_index) and compares a read only with the
+ * windows that a pigeonhole argument cannot rule out - the role the FM-index halves play in
+ * read_mapping/bidir_mapping.cpp:129-162.  AUTO picks SEED when the index exists or the search is
+ * large enough to pay for building it. */
+#define VSC_ALGO_AUTO 0
+#define VSC_ALGO_SCAN 1
+#define VSC_ALGO_SEED 2
 
 /* Per-search device timings measured with HIP events on the context's stream (milliseconds). */
 typedef struct {
-    double scan_ms;          /* off-target scan kernel(s) */
+    double scan_ms;          /* the dominant search kernel: scan_kernel or seed_compare_kernel (last pass) */
+    double prep_ms;          /* read upload (+ per-bucket read lists for VSC_ALGO_SEED) */
     double sort_ms;          /* radix sort of the hit keys */
     double finalize_ms;      /* contig resolution + record assembly */
     double score_ms;         /* last vsc_score_hits call */
     double total_ms;         /* first launch to last completion of the last vsc_search */
-    uint64_t sites;          /* PAM-valid, N-free windows compared (both strands), per pass */
+    double index_ms;         /* last seed-index build on this context */
+    uint64_t sites;          /* PAM-valid, N-free windows of the shard (both strands) */
+    uint64_t pairs;          /* (window, read) comparisons made */
     uint64_t hits;           /* hits reported */
-    uint64_t genome_bytes;   /* plane bytes streamed per pass (0.375 B/base) */
-    uint32_t passes;         /* scan launches needed (1 unless the hit buffer overflowed) */
-    uint32_t reserved;
+    uint64_t genome_bytes;   /* genome bytes the search kernel streamed: planes (SCAN) or visited site records (SEED) */
+    uint32_t passes;         /* search launches needed (1 unless the hit buffer overflowed) */
+    uint32_t algorithm;      /* VSC_ALGO_SCAN or VSC_ALGO_SEED: what ran */
 } vsc_timing;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -104,6 +117,7 @@ int vsc_device_count(void);
 /* Binds device_id and creates the context's stream.  Replaces: process start-up of bidir_mapping
  * (read_mapping/bidir_mapping.cpp:190-258). */
 int vsc_ctx_create(int device_id, vsc_ctx **out);
+/* Genomes and results created on a context must be freed before it. */
 int vsc_ctx_destroy(vsc_ctx *ctx);
 /* Run on a caller-owned hipStream_t (e.g. the framework's current stream) instead of the context's own. */
 int vsc_ctx_set_stream(vsc_ctx *ctx, void *hip_stream);
@@ -142,7 +156,12 @@ int vsc_genome_load(vsc_ctx *ctx, const uint32_t *hi, const uint32_t *lo, const 
                     uint64_t n_words, uint64_t own_words, const vsc_contig *contigs, uint32_t n_contigs,
                     vsc_genome **out);
 int vsc_genome_free(vsc_genome *genome);
-/* Bytes of HBM the resident genome occupies. */
+/* Builds (or keeps, if it matches) the seed index of a resident genome for the PAM set of `params`
+ * (NULL = GG, GA only): the PAM-valid, N-free windows of both strands, filed once per 7-base
+ * segment in bucket order, 36 bytes per window.  Plays the part of `bidir_index`
+ * (read_mapping/bidir_index.cpp:45-47); vsc_search builds it on demand. */
+int vsc_genome_build_index(vsc_ctx *ctx, vsc_genome *genome, const vsc_search_params *params);
+/* Bytes of HBM the resident genome (planes + seed index) occupies. */
 uint64_t vsc_genome_device_bytes(const vsc_genome *genome);
 
 /* ---- search ---------------------------------------------------------------------------------- */

@@ -18,7 +18,10 @@ def ctx():
     c.close()
 
 
-def gpu_search(ctx, contigs, guides, max_mm, extra_pam=None, world=1):
+ALGOS = ["scan", "seed"]
+
+
+def gpu_search(ctx, contigs, guides, max_mm, extra_pam=None, world=1, algo="scan"):
     packed = va.PackedGenome.from_sequences(contigs)
     out = []
     for rank in range(world):
@@ -26,7 +29,8 @@ def gpu_search(ctx, contigs, guides, max_mm, extra_pam=None, world=1):
         if e <= b:
             continue
         g = ctx.load_genome(packed, rank, world)
-        h = g.search(guides, max_mm, extra_pam)
+        h = g.search(guides, max_mm, extra_pam, algorithm=algo)
+        assert ctx.timing()["algorithm"] == {"scan": 1, "seed": 2}[algo]
         out.append(h.to_numpy())
         h.close()
         g.close()
@@ -37,13 +41,14 @@ CASES = [(101, 0, None), (102, 1, None), (103, 2, "AG"), (104, 3, None), (105, 4
          (107, 6, None), (108, 7, None), (109, 8, None), (110, 8, "CC")]
 
 
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("seed,max_mm,extra_pam", CASES)
-def test_search_matches_oracle(ctx, oracle, seed, max_mm, extra_pam):
+def test_search_matches_oracle(ctx, oracle, seed, max_mm, extra_pam, algo):
     rng = np.random.default_rng(seed)
     guides = random_guides(rng, 9) + [random_seq(rng, 23), "NNGT" + random_seq(rng, 17) + "GG"]
     contigs = make_genome(seed, [9000, 22, 23, 24, 700, 5, 4100, 2049, 64], guides, max_mm, n_plant=120, n_runs=6)
     want = oracle.search(contigs, guides, max_mm, extra_pam, mode=oracle.MODE_PREDICATE)
-    got = gpu_search(ctx, contigs, guides, max_mm, extra_pam)
+    got = gpu_search(ctx, contigs, guides, max_mm, extra_pam, algo=algo)
     assert len(want) > 20
     assert hits_as_tuples(got) == hits_as_tuples(want)  # same records in the same (sorted) order
 
@@ -62,8 +67,9 @@ def test_search_matches_reference_flow_order(ctx, oracle):
     assert np.array_equal(got["info"] | (sec.astype(np.uint32) << 30), flow["info"])
 
 
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("world", [2, 3, 5])
-def test_genome_shards_reproduce_the_whole(ctx, oracle, world):
+def test_genome_shards_reproduce_the_whole(ctx, oracle, world, algo):
     """Sharding by tile-aligned plane ranges with a one-word halo loses and duplicates nothing."""
     rng = np.random.default_rng(50 + world)
     guides = random_guides(rng, 8)
@@ -82,19 +88,23 @@ def test_genome_shards_reproduce_the_whole(ctx, oracle, world):
                 seq[q:q + 23] = list(site)
     contigs[0] = "".join(seq)
     want = oracle.search_fast(contigs, guides, 6)
-    got = gpu_search(ctx, contigs, guides, 6, world=world)
+    got = gpu_search(ctx, contigs, guides, 6, world=world, algo=algo)
     got = got[np.lexsort((got["pos"], got["contig"], got["info"] >> 31, got["guide"]))]
     assert hits_as_tuples(got) == hits_as_tuples(want)
 
 
-def test_empty_and_degenerate_inputs(ctx, oracle):
+@pytest.mark.parametrize("algo", ALGOS)
+def test_empty_and_degenerate_inputs(ctx, oracle, algo):
     contigs = ["ACGT", "N" * 100, "ACGTTGCATGCAAGTCCTAGTGG"]
     g = "ACGTTGCATGCAAGTCCTAGTGG"
-    assert len(gpu_search(ctx, contigs, [], 4)) == 0
-    got = gpu_search(ctx, contigs, [g], 0)
+    packed = va.PackedGenome.from_sequences(contigs)
+    gen0 = ctx.load_genome(packed)
+    assert len(gen0.search([], 4, algorithm=algo)) == 0
+    gen0.close()
+    got = gpu_search(ctx, contigs, [g], 0, algo=algo)
     want = oracle.search(contigs, [g], 0)
     assert hits_as_tuples(got) == hits_as_tuples(want) and len(want) == 1
-    assert len(gpu_search(ctx, ["ACGT" * 3], [g], 8)) == 0
+    assert len(gpu_search(ctx, ["ACGT" * 3], [g], 8, algo=algo)) == 0
     packed = va.PackedGenome.from_sequences(contigs)
     gen = ctx.load_genome(packed)
     with pytest.raises(va.VarscotError) as e:
@@ -103,17 +113,19 @@ def test_empty_and_degenerate_inputs(ctx, oracle):
     gen.close()
 
 
-def test_right_edge_rule_on_gpu(ctx, oracle):
+@pytest.mark.parametrize("algo", ALGOS)
+def test_right_edge_rule_on_gpu(ctx, oracle, algo):
     g = "ACGTTGCATGCAAGTCCTAGTGG"
     bad = g[:11] + "".join("A" if c != "A" else "C" for c in g[11:14]) + g[14:]
     for contigs in (["T" * 50 + bad], ["T" * 50 + bad + "T"], ["T" * 50 + revcomp(bad), "T" * 9 + bad],
                     ["T" * 50 + bad + "N" + "T" * 40]):
         want = oracle.search(contigs, [g], 4)
-        got = gpu_search(ctx, contigs, [g], 4)
+        got = gpu_search(ctx, contigs, [g], 4, algo=algo)
         assert hits_as_tuples(got) == hits_as_tuples(want)
 
 
-def test_dense_pam_region_and_many_guides(ctx, oracle):
+@pytest.mark.parametrize("algo", ALGOS)
+def test_dense_pam_region_and_many_guides(ctx, oracle, algo):
     """Low-complexity sequence where almost every window is a candidate on both strands, and a read
     count that is not a multiple of the kernel's unroll factor."""
     rng = np.random.default_rng(9)
@@ -121,30 +133,32 @@ def test_dense_pam_region_and_many_guides(ctx, oracle):
     contigs = ["CCGG" * 3000 + random_seq(rng, 5000) + "G" * 4000 + "C" * 4000 + "GGCC" * 1000]
     contigs[0] = contigs[0][:20000] + guides[3] + contigs[0][20023:]
     want = oracle.search_fast(contigs, guides, 7)
-    got = gpu_search(ctx, contigs, guides, 7)
+    got = gpu_search(ctx, contigs, guides, 7, algo=algo)
     assert hits_as_tuples(got) == hits_as_tuples(want)
 
 
-def test_larger_genome_against_fast_port(ctx, oracle):
+@pytest.mark.parametrize("algo,max_mm", [("scan", 8), ("seed", 8), ("seed", 5), ("seed", 2)])
+def test_larger_genome_against_fast_port(ctx, oracle, algo, max_mm):
     """8 Mbp x 64 reads x 8 mismatches: tens of thousands of hits; exercises queue carry-over,
     staged-hit flushes and the dynamic chunk schedule."""
     rng = np.random.default_rng(11)
     guides = random_guides(rng, 64)
     lens = [3_000_000, 2_500_000, 1_500_000, 999_983, 17]
     contigs = make_genome(11, lens, guides, 8, n_plant=500, n_runs=40)
-    want = oracle.search_fast(contigs, guides, 8)
-    got = gpu_search(ctx, contigs, guides, 8)
-    assert len(want) > 20000
+    want = oracle.search_fast(contigs, guides, max_mm)
+    got = gpu_search(ctx, contigs, guides, max_mm, algo=algo)
+    assert len(want) > (20000 if max_mm == 8 else 50)
     assert hits_as_tuples(got) == hits_as_tuples(want)
 
 
-def test_hit_buffer_overflow_is_retried(ctx, oracle):
+@pytest.mark.parametrize("algo", ALGOS)
+def test_hit_buffer_overflow_is_retried(ctx, oracle, algo):
     """Far more hits than the random-genome estimate sizes the buffer for."""
     g = "ACGTTGCATGCAAGTCCTAGTGG"
     unit = g + "T"
     contigs = [unit * 60000]  # 60 000 perfect sites: the estimate allows ~1M + few
     guides = [g] * 40        # 2.4 M hits
-    got = gpu_search(ctx, contigs, guides, 0)
+    got = gpu_search(ctx, contigs, guides, 0, algo=algo)
     assert len(got) == 60000 * 40
     assert ctx.timing()["passes"] == 2
     assert np.array_equal(np.unique(got["guide"]), np.arange(40))
@@ -158,7 +172,7 @@ def test_mit_and_features_match_oracle(ctx, oracle):
     contigs = make_genome(21, [20000, 8000], guides, 8, n_plant=300)
     packed = va.PackedGenome.from_sequences(contigs)
     gen = ctx.load_genome(packed)
-    hits = gen.search(guides, 8)
+    hits = gen.search(guides, 8, algorithm="seed")
     rec = hits.to_numpy()
     mit, flags, feat = hits.scores(mit=True, features=True)
     assert len(rec) > 200
@@ -268,3 +282,28 @@ def test_sharded_search_over_gloo(oracle):
     want = oracle.search_fast(contigs, guides, 7)
     assert len(want) > 300
     assert got.tobytes() == want.tobytes()
+
+
+def test_auto_uses_an_existing_index_and_rebuilds_for_another_pam(ctx, oracle):
+    rng = np.random.default_rng(77)
+    guides = random_guides(rng, 5)
+    contigs = make_genome(77, [20000, 5000], guides, 5, n_plant=100)
+    packed = va.PackedGenome.from_sequences(contigs)
+    gen = ctx.load_genome(packed)
+    h = gen.search(guides, 5)                       # small search, no index: streaming scan
+    assert ctx.timing()["algorithm"] == 1
+    a = h.to_numpy()
+    h.close()
+    gen.build_index()
+    h = gen.search(guides, 5)                       # index present: used
+    assert ctx.timing()["algorithm"] == 2
+    assert h.to_numpy().tobytes() == a.tobytes()
+    h.close()
+    h = gen.search(guides, 5, extra_pam="AG", algorithm="seed")   # other PAM set: index rebuilt
+    want = oracle.search(contigs, guides, 5, "AG")
+    assert hits_as_tuples(h.to_numpy()) == hits_as_tuples(want)
+    h.close()
+    h = gen.search(guides, 5, algorithm="seed")     # and back
+    assert h.to_numpy().tobytes() == a.tobytes()
+    h.close()
+    gen.close()

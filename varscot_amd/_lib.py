@@ -23,13 +23,17 @@ N_FEATURES = 442
 
 class SearchParams(C.Structure):
     _fields_ = [("max_mismatches", C.c_uint32), ("has_extra_pam", C.c_uint8), ("extra_pam", C.c_char * 2),
-                ("reserved", C.c_uint8)]
+                ("algorithm", C.c_uint8)]
+
+
+ALGO_AUTO, ALGO_SCAN, ALGO_SEED = 0, 1, 2
 
 
 class Timing(C.Structure):
-    _fields_ = [("scan_ms", C.c_double), ("sort_ms", C.c_double), ("finalize_ms", C.c_double),
-                ("score_ms", C.c_double), ("total_ms", C.c_double), ("sites", C.c_uint64), ("hits", C.c_uint64),
-                ("genome_bytes", C.c_uint64), ("passes", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("scan_ms", C.c_double), ("prep_ms", C.c_double), ("sort_ms", C.c_double),
+                ("finalize_ms", C.c_double), ("score_ms", C.c_double), ("total_ms", C.c_double),
+                ("index_ms", C.c_double), ("sites", C.c_uint64), ("pairs", C.c_uint64), ("hits", C.c_uint64),
+                ("genome_bytes", C.c_uint64), ("passes", C.c_uint32), ("algorithm", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -54,6 +58,7 @@ SYMBOLS = [
     ("vsc_genome_load", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp, C.c_uint32,
                                   C.POINTER(_vp)]),
     ("vsc_genome_free", C.c_int, [_vp]),
+    ("vsc_genome_build_index", C.c_int, [_vp, _vp, C.POINTER(SearchParams)]),
     ("vsc_genome_device_bytes", C.c_uint64, [_vp]),
     ("vsc_search", C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(SearchParams), C.POINTER(_vp)]),
     ("vsc_hits_count", C.c_uint64, [_vp]),

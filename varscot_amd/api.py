@@ -2,11 +2,13 @@
 search and per-hit scoring.  Thin plumbing only - every computation happens in libvarscot_hip.so.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
 from . import _lib
-from ._lib import HIT_DTYPE, CONTIG_DTYPE, N_FEATURES, SearchParams, Timing, check, lib, ptr
+from ._lib import (ALGO_AUTO, ALGO_SCAN, ALGO_SEED, HIT_DTYPE, CONTIG_DTYPE, N_FEATURES, SearchParams, Timing, check,
+                   lib, ptr)
 
 READ_LEN = 23
 TILE_WORDS = 64  # shard boundaries are multiples of this many 32-base words (one scan tile)
@@ -85,9 +87,12 @@ class Context:
         self._h = C.c_void_p()
         check(lib().vsc_ctx_create(device, C.byref(self._h)))
         self.device = device
+        self._children = weakref.WeakSet()  # genomes and results must go before their context
 
     def close(self):
         if self._h:
+            for child in sorted(self._children, key=lambda c: isinstance(c, Genome)):
+                child.close()  # results first, then genomes
             lib().vsc_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -139,6 +144,7 @@ class Genome:
         self._h = C.c_void_p()
         check(lib().vsc_genome_load(ctx._h, ptr(hi), ptr(lo), ptr(nm), first_word, len(hi), own_words, ptr(contigs),
                                     len(contigs), C.byref(self._h)), ctx._h)
+        ctx._children.add(self)
 
     @property
     def device_bytes(self):
@@ -155,18 +161,30 @@ class Genome:
         except Exception:
             pass
 
-    def search(self, guides, max_mismatches, extra_pam=None):
-        """guides: list of 23-nt strings or a uint64 array from pack_guides()."""
-        codes = guides if isinstance(guides, np.ndarray) else pack_guides(guides)
-        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+    @staticmethod
+    def _params(max_mismatches, extra_pam, algorithm):
         p = SearchParams()
         p.max_mismatches = max_mismatches
+        p.algorithm = {"auto": ALGO_AUTO, "scan": ALGO_SCAN, "seed": ALGO_SEED}.get(algorithm, algorithm)
         if extra_pam:
             e = extra_pam if isinstance(extra_pam, bytes) else extra_pam.encode()
             if len(e) != 2:
                 raise ValueError("the additional PAM (-P) must be 2 letters")
             p.has_extra_pam = 1
             p.extra_pam = e
+        return p
+
+    def build_index(self, extra_pam=None):
+        """Build the seed index now (vsc_genome_build_index); searches build it on demand otherwise."""
+        p = self._params(0, extra_pam, ALGO_SEED)
+        check(lib().vsc_genome_build_index(self.ctx._h, self._h, C.byref(p)), self.ctx._h)
+
+    def search(self, guides, max_mismatches, extra_pam=None, algorithm="auto"):
+        """guides: list of 23-nt strings or a uint64 array from pack_guides().
+        algorithm: "auto" | "scan" | "seed" - same records either way (see include/varscot_hip.h)."""
+        codes = guides if isinstance(guides, np.ndarray) else pack_guides(guides)
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        p = self._params(max_mismatches, extra_pam, algorithm)
         h = C.c_void_p()
         check(lib().vsc_search(self.ctx._h, self._h, ptr(codes), len(codes), C.byref(p), C.byref(h)), self.ctx._h)
         return Hits(self, h, codes)
@@ -177,6 +195,8 @@ class Hits:
 
     def __init__(self, genome, handle, codes):
         self.genome, self._h, self.codes = genome, handle, codes
+        self.ctx = genome.ctx
+        self.ctx._children.add(self)
 
     def __len__(self):
         return int(lib().vsc_hits_count(self._h))
@@ -188,7 +208,7 @@ class Hits:
     def to_numpy(self):
         n = len(self)
         p = C.c_void_p()
-        check(lib().vsc_hits_data(self._h, C.byref(p)), self.genome.ctx._h)
+        check(lib().vsc_hits_data(self._h, C.byref(p)), self.ctx._h)
         if n == 0:
             return np.zeros(0, dtype=HIT_DTYPE)
         buf = (C.c_char * (n * HIT_DTYPE.itemsize)).from_address(p.value)
@@ -196,7 +216,7 @@ class Hits:
 
     def copy_to(self, dst_ptr, dst_is_device):
         """Copy the records to caller memory (e.g. the data_ptr() of a uint8 tensor handed to RCCL)."""
-        check(lib().vsc_hits_copy(self._h, C.c_void_p(dst_ptr), int(bool(dst_is_device))), self.genome.ctx._h)
+        check(lib().vsc_hits_copy(self._h, C.c_void_p(dst_ptr), int(bool(dst_is_device))), self.ctx._h)
 
     def scores(self, first=0, count=None, mit=True, features=False):
         """(mit float64[count] | None, mit_flags uint8[count] | None, features uint8[count,442] | None)."""
@@ -225,6 +245,7 @@ class MergedHits(Hits):
 
     def __init__(self, ctx, handle):
         self.ctx, self._h, self.codes, self.genome = ctx, handle, None, None
+        ctx._children.add(self)
 
     def to_numpy(self):
         n = len(self)

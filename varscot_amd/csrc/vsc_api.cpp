@@ -3,6 +3,8 @@
 // vsc_kernels.hip.  No CPU implementation of the search exists in this library: without a HIP
 // device every compute entry point fails with VSC_ERR_NODEVICE / VSC_ERR_DEVICE.
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -37,6 +39,19 @@ struct DeviceBuf {
     }
 };
 
+// VSC_DEBUG_TIMING=1 prints host-side wall times of the phases of vsc_search to stderr
+struct HostTimer {
+    bool on = std::getenv("VSC_DEBUG_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[vsc timing] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 }  // namespace
 
 struct vsc_ctx {
@@ -44,10 +59,14 @@ struct vsc_ctx {
     int n_cus = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;
     vsc_timing timing{};
     DeviceBuf counters, guides, keys_a, keys_b, vals_a, vals_b, sort_temp, score_mit, score_flags, score_feat;
+    DeviceBuf seed_k1, seed_k2, seed_v1, seed_v2, seed_off, seed_poff, seed_lplanes, seed_lgid;  // per-search read lists
+    // record buffers of freed results, kept for the next search: hipMalloc / hipFree of tens of GB
+    // cost hundreds of milliseconds each
+    std::vector<DeviceBuf> spare_records;
 };
 
 struct vsc_genome {
@@ -58,11 +77,22 @@ struct vsc_genome {
     uint32_t n_tiles = 0, n_contigs = 0;
     uint64_t device_bytes = 0;
     uint64_t sites = 0;  // PAM-valid windows seen by the last scan (sizes the next hit buffer)
+    // seed index (vsc_seed.hip): the PAM-valid sites filed once per segment, sorted by bucket
+    bool has_index = false;
+    uint8_t index_has_extra_pam = 0;
+    char index_extra_pam[2] = {0, 0};
+    uint64_t index_sites = 0;  // S
+    uint2 *d_ix_planes = nullptr;
+    uint32_t *d_ix_pos = nullptr, *d_ix_bucket_start = nullptr, *d_ix_chunk_start = nullptr, *d_ix_chunk_bucket = nullptr;
+    uint32_t ix_chunks = 0;
+    uint64_t index_bytes = 0;
+    double index_ms = 0;
 };
 
 struct vsc_hits {
     vsc_ctx *ctx = nullptr;
     vsc_hit *d_records = nullptr;
+    DeviceBuf storage;  // owns d_records
     uint64_t n = 0;
     std::vector<vsc_hit> host;
     bool host_valid = false;
@@ -88,6 +118,28 @@ int fail(vsc_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
         hipError_t e_ = (call);                                            \
         if (e_ != hipSuccess) return fail((ctx), VSC_ERR_DEVICE, #call, e_); \
     } while (0)
+
+// Record storage for a result: the smallest spare buffer that fits, else a new allocation.
+hipError_t take_records(vsc_ctx *ctx, vsc_hits *hits, uint64_t n)
+{
+    const size_t bytes = n * sizeof(vsc_hit);
+    int best = -1;
+    for (size_t i = 0; i < ctx->spare_records.size(); ++i)
+        if (ctx->spare_records[i].cap >= bytes && (best < 0 || ctx->spare_records[i].cap < ctx->spare_records[best].cap))
+            best = (int)i;
+    if (best >= 0) {
+        hits->storage = ctx->spare_records[best];
+        ctx->spare_records.erase(ctx->spare_records.begin() + best);
+    } else {
+        // nothing fits: drop the spares first so that their memory can be reused
+        for (auto &b : ctx->spare_records) b.release();
+        ctx->spare_records.clear();
+        hipError_t e = hits->storage.ensure(bytes);
+        if (e != hipSuccess) return e;
+    }
+    hits->d_records = (vsc_hit *)hits->storage.p;
+    return hipSuccess;
+}
 
 // P[Binomial(21, 3/4) <= m]: chance that a PAM-valid random window is within m mismatches of a read
 double hit_probability(unsigned m)
@@ -179,8 +231,11 @@ int vsc_ctx_destroy(vsc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->vals_b,
-                         &ctx->sort_temp, &ctx->score_mit, &ctx->score_flags, &ctx->score_feat})
+                         &ctx->sort_temp, &ctx->score_mit, &ctx->score_flags, &ctx->score_feat, &ctx->seed_k1,
+                         &ctx->seed_k2, &ctx->seed_v1, &ctx->seed_v2, &ctx->seed_off, &ctx->seed_poff,
+                         &ctx->seed_lplanes, &ctx->seed_lgid})
         b->release();
+    for (auto &b : ctx->spare_records) b.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -277,15 +332,203 @@ int vsc_genome_free(vsc_genome *g)
 {
     if (!g) return VSC_OK;
     if (g->ctx) (void)hipSetDevice(g->ctx->device);
-    for (void *p : {(void *)g->d_hi, (void *)g->d_lo, (void *)g->d_nm, (void *)g->d_contig_off, (void *)g->d_contig_end})
+    for (void *p : {(void *)g->d_hi, (void *)g->d_lo, (void *)g->d_nm, (void *)g->d_contig_off, (void *)g->d_contig_end,
+                    (void *)g->d_ix_planes, (void *)g->d_ix_pos, (void *)g->d_ix_bucket_start, (void *)g->d_ix_chunk_start,
+                    (void *)g->d_ix_chunk_bucket})
         if (p) (void)hipFree(p);
     delete g;
     return VSC_OK;
 }
 
-uint64_t vsc_genome_device_bytes(const vsc_genome *g) { return g ? g->device_bytes : 0; }
+uint64_t vsc_genome_device_bytes(const vsc_genome *g) { return g ? g->device_bytes + g->index_bytes : 0; }
 
 // ------------------------------------------------------------------------------------------------
+namespace {
+
+#define VSC_TRY(call)                        \
+    do {                                     \
+        hipError_t e_ = (call);              \
+        if (e_ != hipSuccess) return e_;     \
+    } while (0)
+
+void fill_pam(ScanArgs &a, const vsc_search_params *params)
+{
+    a.n_pam = 2;
+    a.pam[0] = pam_masks(2, 2);  // GG  (bidir_mapping.cpp:240)
+    a.pam[1] = pam_masks(2, 0);  // GA
+    if (params && params->has_extra_pam) {  // :242-247
+        const int p0 = base_code(params->extra_pam[0]), p1 = base_code(params->extra_pam[1]);
+        // a PAM containing a non-ACGT letter can only match windows that contain N, which never
+        // pass the verification (:81-82) - it adds nothing
+        if (p0 < 4 && p1 < 4) a.pam[a.n_pam++] = pam_masks(p0, p1);
+    }
+}
+
+void fill_genome(ScanArgs &a, const vsc_ctx *ctx, const vsc_genome *genome)
+{
+    a.hi = genome->d_hi;
+    a.lo = genome->d_lo;
+    a.nm = genome->d_nm;
+    a.first_pos = (uint32_t)(genome->first_word * 32);
+    a.n_tiles = genome->n_tiles;
+    a.contig_end = genome->d_contig_end;
+    a.n_contigs = genome->n_contigs;
+    a.counters = (unsigned long long *)ctx->counters.p;
+}
+
+int scan_groups(const vsc_ctx *ctx, uint32_t n_tiles)
+{
+    const uint32_t n_waves_max = (uint32_t)ctx->n_cus * 4 * kWavesPerGroup;
+    const uint32_t n_chunks = (n_tiles + kChunkTiles - 1) / kChunkTiles;
+    const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, n_chunks));
+    return (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
+}
+
+bool index_matches(const vsc_genome *g, const vsc_search_params *p)
+{
+    if (!g->has_index) return false;
+    const bool want = p && p->has_extra_pam && base_code(p->extra_pam[0]) < 4 && base_code(p->extra_pam[1]) < 4;
+    if (want != (g->index_has_extra_pam != 0)) return false;
+    return !want || (base_code(p->extra_pam[0]) == base_code(g->index_extra_pam[0]) &&
+                     base_code(p->extra_pam[1]) == base_code(g->index_extra_pam[1]));
+}
+
+void free_index(vsc_genome *g)
+{
+    for (void **p : {(void **)&g->d_ix_planes, (void **)&g->d_ix_pos, (void **)&g->d_ix_bucket_start,
+                     (void **)&g->d_ix_chunk_start, (void **)&g->d_ix_chunk_bucket}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    g->has_index = false;
+    g->index_bytes = 0;
+    g->ix_chunks = 0;
+}
+
+// Builds the seed index of a resident genome: extract the PAM-valid sites of both strands, then file
+// them once per segment in bucket order.  All temporaries are released before returning.
+hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *params, std::string *why)
+{
+    free_index(g);
+    hipStream_t st = ctx->stream;
+    ScanArgs a{};
+    fill_pam(a, params);
+    fill_genome(a, ctx, g);
+    const int n_groups = scan_groups(ctx, a.n_tiles);
+    VSC_TRY(ctx->counters.ensure(kCntSlots * sizeof(unsigned long long)));
+    a.counters = (unsigned long long *)ctx->counters.p;
+    unsigned long long cnt[kCntSlots];
+    VSC_TRY(hipEventRecord(ctx->ev[5], st));
+    // pass 1: count (capacity 0: nothing is written, the cursor still counts)
+    VSC_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof cnt, st));
+    VSC_TRY(launch_scan(a, n_groups, true, st));
+    VSC_TRY(hipMemcpyAsync(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost, st));
+    VSC_TRY(hipStreamSynchronize(st));
+    const uint64_t S = cnt[kCntHits];
+    if (3 * S >= (1ull << 32) - (1u << 20)) {
+        *why = "too many PAM-valid sites for 32-bit table indices";
+        return hipErrorInvalidValue;
+    }
+    DeviceBuf sx, sl, sp, k1, k2, i1, i2, tmp;
+    auto release = [&]() {
+        for (DeviceBuf *b : {&sx, &sl, &sp, &k1, &k2, &i1, &i2, &tmp}) b->release();
+    };
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+    };
+    const size_t n4 = std::max<uint64_t>(S, 1) * sizeof(uint32_t);
+    for (DeviceBuf *b : {&sx, &sl, &sp, &k1, &k2, &i1, &i2}) step(b->ensure(n4));
+    size_t temp_bytes = 0;
+    step(sort32_temp_bytes(S, 2 * kSegBases, &temp_bytes));
+    step(tmp.ensure(std::max<size_t>(temp_bytes, 16)));
+    step(hipMalloc((void **)&g->d_ix_planes, std::max<uint64_t>(3 * S, 1) * sizeof(uint2)));
+    step(hipMalloc((void **)&g->d_ix_pos, std::max<uint64_t>(3 * S, 1) * sizeof(uint32_t)));
+    step(hipMalloc((void **)&g->d_ix_bucket_start, (kBuckets + 1) * sizeof(uint32_t)));
+    if (e == hipSuccess && S > 0) {
+        // pass 2: emit
+        a.site_x = (uint32_t *)sx.p;
+        a.site_l = (uint32_t *)sl.p;
+        a.site_pos = (uint32_t *)sp.p;
+        a.hit_cap = S;
+        step(hipMemsetAsync(ctx->counters.p, 0, sizeof cnt, st));
+        step(launch_scan(a, n_groups, true, st));
+    }
+    for (int s = 0; s < kSegments && e == hipSuccess; ++s) {
+        step(launch_seed_keys((const uint32_t *)sx.p, (const uint32_t *)sl.p, S, s, (uint32_t *)k1.p, (uint32_t *)i1.p, st));
+        step(launch_sort32(tmp.p, temp_bytes, (const uint32_t *)k1.p, (uint32_t *)k2.p, (const uint32_t *)i1.p,
+                           (uint32_t *)i2.p, S, 2 * kSegBases, st));
+        step(launch_seed_gather((const uint32_t *)sx.p, (const uint32_t *)sl.p, (const uint32_t *)sp.p,
+                                (const uint32_t *)i2.p, S, g->d_ix_planes + (size_t)s * S, g->d_ix_pos + (size_t)s * S, st));
+        step(launch_lower_bound((const uint32_t *)k2.p, S, kBucketsPerSeg, 0, (uint32_t)(s * S),
+                                g->d_ix_bucket_start + (size_t)s * kBucketsPerSeg, st));
+    }
+    std::vector<uint32_t> bs(kBuckets + 1, 0);
+    if (e == hipSuccess) {
+        step(hipMemcpyAsync(bs.data(), g->d_ix_bucket_start, bs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        step(hipStreamSynchronize(st));
+    }
+    release();
+    if (e != hipSuccess) {
+        free_index(g);
+        return e;
+    }
+    // chunks: at most kBatch sites of one bucket each
+    std::vector<uint32_t> cstart, cbucket;
+    cstart.reserve(3 * S / kBatch + kBuckets);
+    cbucket.reserve(3 * S / kBatch + kBuckets);
+    for (uint32_t b = 0; b < (uint32_t)kBuckets; ++b)
+        for (uint64_t p = bs[b]; p < bs[b + 1]; p += kBatch) {
+            cstart.push_back((uint32_t)p);
+            cbucket.push_back(b);
+        }
+    g->ix_chunks = (uint32_t)cstart.size();
+    const size_t cb = std::max<size_t>(cstart.size(), 1) * sizeof(uint32_t);
+    step(hipMalloc((void **)&g->d_ix_chunk_start, cb));
+    step(hipMalloc((void **)&g->d_ix_chunk_bucket, cb));
+    if (e == hipSuccess && !cstart.empty()) {
+        step(hipMemcpyAsync(g->d_ix_chunk_start, cstart.data(), cstart.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        step(hipMemcpyAsync(g->d_ix_chunk_bucket, cbucket.data(), cbucket.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+    step(hipEventRecord(ctx->ev[6], st));
+    step(hipStreamSynchronize(st));
+    if (e != hipSuccess) {
+        free_index(g);
+        return e;
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]);
+    g->index_ms = ms;
+    g->index_sites = S;
+    g->sites = S;
+    g->has_index = true;
+    g->index_has_extra_pam = a.n_pam > 2;
+    if (a.n_pam > 2) {
+        g->index_extra_pam[0] = params->extra_pam[0];
+        g->index_extra_pam[1] = params->extra_pam[1];
+    }
+    g->index_bytes = 3 * S * (sizeof(uint2) + sizeof(uint32_t)) + (kBuckets + 1) * sizeof(uint32_t) + 2 * cb;
+    return hipSuccess;
+}
+
+}  // namespace
+
+int vsc_genome_build_index(vsc_ctx *ctx, vsc_genome *genome, const vsc_search_params *params)
+{
+    if (!ctx || !genome || genome->ctx != ctx) return VSC_ERR_INVALID;
+    ctx->err.clear();
+    if (index_matches(genome, params)) return VSC_OK;
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    std::string why;
+    hipError_t e = build_index(ctx, genome, params, &why);
+    if (e != hipSuccess) {
+        if (!why.empty()) return fail(ctx, VSC_ERR_RANGE, ("vsc_genome_build_index: " + why).c_str());
+        return fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, "vsc_genome_build_index", e);
+    }
+    ctx->timing.index_ms = genome->index_ms;
+    return VSC_OK;
+}
+
 int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
                const vsc_search_params *params, vsc_hits **out)
 {
@@ -296,37 +539,21 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     if (genome->ctx != ctx) return fail(ctx, VSC_ERR_INVALID, "vsc_search: genome belongs to another context");
     if (params->max_mismatches > VSC_MAX_MISMATCHES)  // read_mapping/bidir_mapping.cpp:234-238
         return fail(ctx, VSC_ERR_INVALID, "Maximum number of mismatches must lie between 0 and 8.");
+    if (params->algorithm > VSC_ALGO_SEED) return fail(ctx, VSC_ERR_INVALID, "vsc_search: unknown algorithm");
     if (n_guides >= (1u << 31)) return fail(ctx, VSC_ERR_RANGE, "vsc_search: too many reads");
-
-    ScanArgs a{};
-    a.n_pam = 2;
-    a.pam[0] = pam_masks(2, 2);  // GG  (bidir_mapping.cpp:240)
-    a.pam[1] = pam_masks(2, 0);  // GA
-    if (params->has_extra_pam) {  // :242-247
-        const int p0 = base_code(params->extra_pam[0]), p1 = base_code(params->extra_pam[1]);
-        // a PAM containing a non-ACGT letter can only match windows that contain N, which never
-        // pass the verification (:81-82) - it adds nothing
-        if (p0 < 4 && p1 < 4) a.pam[a.n_pam++] = pam_masks(p0, p1);
-    }
 
     VSC_HIP(ctx, hipSetDevice(ctx->device));
     vsc_hits *hits = new (std::nothrow) vsc_hits();
     if (!hits) return fail(ctx, VSC_ERR_NOMEM, "vsc_search: out of host memory");
     hits->ctx = ctx;
     vsc_timing t{};
-    t.genome_bytes = (uint64_t)genome->n_tiles * kTileWords * 3 * sizeof(uint32_t);
+    t.index_ms = ctx->timing.index_ms;
     if (n_guides == 0) {
         hits->host_valid = true;
         ctx->timing = t;
         *out = hits;
         return VSC_OK;
     }
-
-    // reads as (hi, lo) plane pairs, padded to the unroll factor with reads that can never match
-    const uint32_t n_pad = (n_guides + kGuideUnroll - 1) / kGuideUnroll * kGuideUnroll;
-    std::vector<uint32_t> gp((size_t)(n_pad + kGuideUnroll) * 2, 0xFFFFFFFFu);  // + one prefetch group
-    for (uint32_t i = 0; i < n_guides; ++i) guide_planes(guides[i], &gp[2 * (size_t)i], &gp[2 * (size_t)i + 1]);
-
     auto cleanup = [&](int code) {
         vsc_hits_free(hits);
         return code;
@@ -338,55 +565,136 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
             return cleanup(fail(ctx, e_ == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, #call, e_)); \
     } while (0)
 
+    // ---- which search: streaming scan of the planes, or the seed-partitioned site tables -------------
+    const double own_bases = (double)genome->n_tiles * kTileBases;
+    int algo = params->algorithm;
+    if (algo == VSC_ALGO_AUTO) {
+        // the index costs about as much as scanning a few hundred reads; it pays for itself when it is
+        // already there or when the search is big enough
+        const bool worth_building = (double)n_guides * own_bases >= 2.0e10;
+        algo = (index_matches(genome, params) || worth_building) ? VSC_ALGO_SEED : VSC_ALGO_SCAN;
+    }
+    if (algo == VSC_ALGO_SEED && !index_matches(genome, params)) {
+        std::string why;
+        hipError_t e = build_index(ctx, const_cast<vsc_genome *>(genome), params, &why);
+        if (e != hipSuccess) {
+            if (params->algorithm == VSC_ALGO_SEED || why.empty())
+                return cleanup(fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE,
+                                    why.empty() ? "vsc_search: building the seed index" : why.c_str(), why.empty() ? e : hipSuccess));
+            algo = VSC_ALGO_SCAN;  // auto mode: a genome too large for the index is still searchable
+        } else {
+            t.index_ms = genome->index_ms;
+        }
+    }
+    t.algorithm = (uint32_t)algo;
+    HostTimer ht;
+
+    // reads as (hi, lo) plane pairs, padded to the unroll factor with reads that can never match
+    const uint32_t n_pad = (n_guides + kGuideUnroll - 1) / kGuideUnroll * kGuideUnroll;
+    std::vector<uint32_t> gp((size_t)(n_pad + kGuideUnroll) * 2, 0xFFFFFFFFu);  // + one prefetch group
+    for (uint32_t i = 0; i < n_guides; ++i) guide_planes(guides[i], &gp[2 * (size_t)i], &gp[2 * (size_t)i + 1]);
     VSC_HIP_H(ctx->guides.ensure(gp.size() * sizeof(uint32_t)));
     VSC_HIP_H(ctx->counters.ensure(kCntSlots * sizeof(unsigned long long)));
+    VSC_HIP_H(hipEventRecord(ctx->ev[0], ctx->stream));
     VSC_HIP_H(hipMemcpyAsync(ctx->guides.p, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 
-    const double own_bases = (double)genome->n_tiles * kTileBases;
     const double sites_est = genome->sites ? (double)genome->sites : own_bases / 4;
     uint64_t cap = (uint64_t)(1.5 * sites_est * n_guides * hit_probability(params->max_mismatches)) + (1u << 20);
+    unsigned long long cnt[kCntSlots] = {0, 0, 0, 0, 0};
 
-    // enough chunks that the dynamic schedule balances, but at least one tile per chunk
-    const uint32_t n_waves_max = (uint32_t)ctx->n_cus * 4 * kWavesPerGroup;
+    ScanArgs a{};
+    SeedArgs sa{};
+    int n_groups = 1;
+    if (algo == VSC_ALGO_SCAN) {
+        fill_pam(a, params);
+        fill_genome(a, ctx, genome);
+        a.guides = (const uint4 *)ctx->guides.p;
+        a.n_guides_padded = n_pad;
+        a.max_mm = params->max_mismatches;
+        a.k_half = params->max_mismatches / 2;  // bidir_mapping.cpp:129-146
+        n_groups = scan_groups(ctx, a.n_tiles);
+        t.genome_bytes = (uint64_t)genome->n_tiles * kTileWords * 3 * sizeof(uint32_t);
+        VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
+    } else {
+        // ---- per-bucket read lists: neighbourhood enumeration -> sort by bucket -> padded lists ------
+        const uint32_t k_seg = params->max_mismatches / kSegments;
+        const uint32_t n_nbr = k_seg == 0 ? 1u : (k_seg == 1 ? 22u : 211u);
+        const uint64_t n_pairs = (uint64_t)n_guides * kSegments * n_nbr;
+        if (n_pairs >= (1ull << 32) - (1u << 20)) return cleanup(fail(ctx, VSC_ERR_RANGE, "vsc_search: too many reads for one seeded pass"));
+        const uint64_t list_cap = n_pairs + (uint64_t)kBuckets * (kGuideUnroll - 1) + 2 * kGuideUnroll;
+        size_t temp_bytes = 0;
+        VSC_HIP_H(sort32_temp_bytes(n_pairs, 16, &temp_bytes));
+        VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
+        for (DeviceBuf *b : {&ctx->seed_k1, &ctx->seed_k2, &ctx->seed_v1, &ctx->seed_v2}) VSC_HIP_H(b->ensure(n_pairs * sizeof(uint32_t)));
+        VSC_HIP_H(ctx->seed_off.ensure((kBuckets + 1) * sizeof(uint32_t)));
+        VSC_HIP_H(ctx->seed_poff.ensure((kBuckets + 1) * sizeof(uint32_t)));
+        VSC_HIP_H(ctx->seed_lplanes.ensure(list_cap * sizeof(uint2)));
+        VSC_HIP_H(ctx->seed_lgid.ensure(list_cap * sizeof(uint32_t)));
+        VSC_HIP_H(hipMemsetAsync(ctx->seed_lplanes.p, 0xFF, list_cap * sizeof(uint2), ctx->stream));  // padding never matches
+        VSC_HIP_H(launch_seed_enum((const uint2 *)ctx->guides.p, n_guides, n_nbr, (uint32_t *)ctx->seed_k1.p,
+                                   (uint32_t *)ctx->seed_v1.p, ctx->stream));
+        VSC_HIP_H(launch_sort32(ctx->sort_temp.p, temp_bytes, (const uint32_t *)ctx->seed_k1.p, (uint32_t *)ctx->seed_k2.p,
+                                (const uint32_t *)ctx->seed_v1.p, (uint32_t *)ctx->seed_v2.p, n_pairs, 16, ctx->stream));
+        VSC_HIP_H(launch_seed_lists((const uint32_t *)ctx->seed_k2.p, (const uint32_t *)ctx->seed_v2.p, n_pairs,
+                                    (uint32_t *)ctx->seed_off.p, (uint32_t *)ctx->seed_poff.p, (const uint2 *)ctx->guides.p,
+                                    (uint2 *)ctx->seed_lplanes.p, (uint32_t *)ctx->seed_lgid.p, ctx->stream));
+        VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
+        sa.planes = genome->d_ix_planes;
+        sa.pos = genome->d_ix_pos;
+        sa.bucket_start = genome->d_ix_bucket_start;
+        sa.chunk_start = genome->d_ix_chunk_start;
+        sa.chunk_bucket = genome->d_ix_chunk_bucket;
+        sa.n_chunks = genome->ix_chunks;
+        sa.list_planes = (const uint4 *)ctx->seed_lplanes.p;
+        sa.list_gid = (const uint32_t *)ctx->seed_lgid.p;
+        sa.poff = (const uint32_t *)ctx->seed_poff.p;
+        sa.max_mm = params->max_mismatches;
+        sa.k_half = params->max_mismatches / 2;
+        sa.k_seg = k_seg;
+        sa.contig_end = genome->d_contig_end;
+        sa.n_contigs = genome->n_contigs;
+        sa.counters = (unsigned long long *)ctx->counters.p;
+        const uint32_t n_waves_max = (uint32_t)ctx->n_cus * 5 * kWavesPerGroup;
+        const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, (sa.n_chunks + kSeedGrab - 1) / kSeedGrab));
+        n_groups = (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
+    }
 
-    a.hi = genome->d_hi;
-    a.lo = genome->d_lo;
-    a.nm = genome->d_nm;
-    a.first_pos = (uint32_t)(genome->first_word * 32);
-    a.n_tiles = genome->n_tiles;
-    a.guides = (const uint4 *)ctx->guides.p;
-    a.n_guides_padded = n_pad;
-    a.max_mm = params->max_mismatches;
-    a.k_half = params->max_mismatches / 2;  // bidir_mapping.cpp:129-146
-    a.contig_end = genome->d_contig_end;
-    a.n_contigs = genome->n_contigs;
-    a.counters = (unsigned long long *)ctx->counters.p;
-    const uint32_t n_chunks = (a.n_tiles + kChunkTiles - 1) / kChunkTiles;
-    const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, n_chunks));
-    const int n_groups = (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
-
-    unsigned long long cnt[kCntSlots] = {0, 0, 0, 0};
-    VSC_HIP_H(hipEventRecord(ctx->ev[0], ctx->stream));
+    ht.lap("prep enqueue");
     for (;;) {
         VSC_HIP_H(ctx->keys_a.ensure(cap * sizeof(uint64_t)));
         VSC_HIP_H(ctx->vals_a.ensure(cap * sizeof(uint32_t)));
-        a.hit_keys = (uint64_t *)ctx->keys_a.p;
-        a.hit_vals = (uint32_t *)ctx->vals_a.p;
-        a.hit_cap = cap;
         VSC_HIP_H(hipMemsetAsync(ctx->counters.p, 0, kCntSlots * sizeof(unsigned long long), ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[1], ctx->stream));
-        VSC_HIP_H(launch_scan(a, n_groups, ctx->stream));
+        if (algo == VSC_ALGO_SCAN) {
+            a.hit_keys = (uint64_t *)ctx->keys_a.p;
+            a.hit_vals = (uint32_t *)ctx->vals_a.p;
+            a.hit_cap = cap;
+            VSC_HIP_H(launch_scan(a, n_groups, false, ctx->stream));
+        } else {
+            sa.hit_keys = (uint64_t *)ctx->keys_a.p;
+            sa.hit_vals = (uint32_t *)ctx->vals_a.p;
+            sa.hit_cap = cap;
+            VSC_HIP_H(launch_seed_compare(sa, n_groups, ctx->stream));
+        }
         VSC_HIP_H(hipEventRecord(ctx->ev[2], ctx->stream));
         VSC_HIP_H(hipMemcpyAsync(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
         VSC_HIP_H(hipStreamSynchronize(ctx->stream));
+        ht.lap("search kernel + sync");
         t.passes++;
         if (!cnt[kCntOverflow]) break;
         if (t.passes >= 3) return cleanup(fail(ctx, VSC_ERR_DEVICE, "vsc_search: hit buffer overflowed repeatedly"));
         cap = cnt[kCntHits] + (cnt[kCntHits] >> 6) + 4096;  // the counter holds the true total
     }
     const uint64_t n = cnt[kCntHits];
-    const_cast<vsc_genome *>(genome)->sites = cnt[kCntSites];
-    t.sites = cnt[kCntSites];
+    if (algo == VSC_ALGO_SCAN) {
+        const_cast<vsc_genome *>(genome)->sites = cnt[kCntSites];
+        t.sites = cnt[kCntSites];
+        t.pairs = cnt[kCntSites] * n_guides;
+    } else {
+        t.sites = genome->index_sites;
+        t.pairs = cnt[kCntSites];
+        t.genome_bytes = cnt[kCntVisited] * sizeof(uint2);
+    }
     t.hits = n;
 
     if (n > 0) {
@@ -398,7 +706,9 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
         VSC_HIP_H(ctx->keys_b.ensure(n * sizeof(uint64_t)));
         VSC_HIP_H(ctx->vals_b.ensure(n * sizeof(uint32_t)));
-        VSC_HIP_H(hipMalloc((void **)&hits->d_records, n * sizeof(vsc_hit)));
+        ht.lap("sort buffers ensure");
+        VSC_HIP_H(take_records(ctx, hits, n));
+        ht.lap("record storage");
         VSC_HIP_H(launch_sort(ctx->sort_temp.p, temp_bytes, (const uint64_t *)ctx->keys_a.p, (uint64_t *)ctx->keys_b.p,
                               (const uint32_t *)ctx->vals_a.p, (uint32_t *)ctx->vals_b.p, n, end_bit, ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -415,7 +725,10 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     }
     VSC_HIP_H(hipEventRecord(ctx->ev[4], ctx->stream));
     VSC_HIP_H(hipStreamSynchronize(ctx->stream));
+    ht.lap("sort + finalize + sync");
     float ms = 0;
+    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[7]));
+    t.prep_ms = ms;
     VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
     t.scan_ms = ms;
     VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
@@ -502,7 +815,7 @@ int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, uin
     step(ctx->keys_b.ensure(n * sizeof(uint32_t)));
     step(ctx->vals_a.ensure(n * sizeof(uint32_t)));
     step(ctx->vals_b.ensure(n * sizeof(uint32_t)));
-    step(hipMalloc((void **)&hits->d_records, n * sizeof(vsc_hit)));
+    step(take_records(ctx, hits, n));
     const vsc_hit *records_dev = (const vsc_hit *)records;
     if (!records_on_device) {
         step(ctx->score_feat.ensure(n * sizeof(vsc_hit)));  // staging buffer for host input
@@ -527,9 +840,14 @@ int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, uin
 int vsc_hits_free(vsc_hits *hits)
 {
     if (!hits) return VSC_OK;
-    if (hits->d_records) {
-        (void)hipSetDevice(hits->ctx->device);
-        (void)hipFree(hits->d_records);
+    if (hits->storage.p) {
+        vsc_ctx *ctx = hits->ctx;
+        if (ctx->spare_records.size() < 2) {
+            ctx->spare_records.push_back(hits->storage);  // reused by the next search
+        } else {
+            (void)hipSetDevice(ctx->device);
+            hits->storage.release();
+        }
     }
     delete hits;
     return VSC_OK;

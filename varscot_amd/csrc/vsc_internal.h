@@ -21,10 +21,21 @@ constexpr int kTileBases = kTileWords * 32;
 constexpr int kChunkTiles = 8;                  // tiles a wave takes per grab of the work counter
 constexpr int kGuideUnroll = 4;                 // guides per inner iteration (guide table is padded to it)
 constexpr uint32_t kMask23 = 0x7FFFFFu;
+constexpr int kSiteStrandBit = 23;              // site word x: bit 23 = '-' strand
+constexpr int kSiteEdgeBit = 24;                // site word x: bit 24 = the position after the window is N
 constexpr uint32_t kPadWords = 4;               // words the device planes are padded with past the shard
 
+// ---- seed-partitioned search (vsc_seed.hip) -------------------------------------------------------
+constexpr int kSegments = 3;                    // read positions [0,7) [7,14) [14,21); the PAM is in no segment
+constexpr int kSegBases = 7;
+constexpr int kBucketsPerSeg = 1 << (2 * kSegBases);  // 16384 seven-mers
+constexpr int kBuckets = kSegments * kBucketsPerSeg;
+constexpr int kSeedTokCap = 512;                // per-wave LDS buffer of pending hit tokens
+constexpr int kSeedHitCap = 256;                // per-wave LDS buffer of resolved hits
+constexpr int kSeedGrab = 8;                    // chunks (<= 512 sites of one bucket) per grab of the work counter
+
 // counters[] slots of one scan launch
-enum { kCntHits = 0, kCntChunk = 1, kCntSites = 2, kCntOverflow = 3, kCntSlots = 4 };
+enum { kCntHits = 0, kCntChunk = 1, kCntSites = 2, kCntOverflow = 3, kCntVisited = 4, kCntSlots = 5 };
 
 // Required plane bits of the two PAM letters, expanded to all-ones / all-zero words.
 struct PamMasks {
@@ -48,6 +59,9 @@ struct ScanArgs {
     uint32_t *hit_vals;            // out: NM << 23 | mismatch mask (window coordinates)
     unsigned long long hit_cap;
     unsigned long long *counters;  // kCntSlots values, zeroed before the launch
+    // extract mode only: PAM-valid sites of both strands (x = hi plane | strand | edge, l = lo plane);
+    // the append cursor is counters[kCntHits], the capacity hit_cap
+    uint32_t *site_x, *site_l, *site_pos;
 };
 
 struct FinalizeArgs {
@@ -72,13 +86,48 @@ struct ScoreArgs {
     uint8_t *features;    // may be null; n * 442 bytes
 };
 
+struct SeedArgs {
+    const uint2 *planes;           // [3 S] sites (x = hi plane | strand | edge, y = lo plane), bucket-sorted per segment
+    const uint32_t *pos;           // [3 S] global window starts, same order
+    const uint32_t *bucket_start;  // [kBuckets + 1] first site of every bucket
+    const uint32_t *chunk_start;   // [n_chunks] first site of the chunk
+    const uint32_t *chunk_bucket;  // [n_chunks]
+    uint32_t n_chunks;
+    const uint4 *list_planes;      // padded per-bucket read lists: two reads per uint4 (hi0, lo0, hi1, lo1)
+    const uint32_t *list_gid;      // read index of every list entry
+    const uint32_t *poff;          // [kBuckets + 1] first list entry of every bucket (multiples of kGuideUnroll)
+    uint32_t max_mm, k_half, k_seg;
+    const uint32_t *contig_end;
+    uint32_t n_contigs;
+    uint64_t *hit_keys;
+    uint32_t *hit_vals;
+    unsigned long long hit_cap;
+    unsigned long long *counters;  // kCntHits, kCntChunk, kCntSites (= pairs compared), kCntOverflow
+};
+
 // Launch wrappers implemented in vsc_kernels.hip.  They only enqueue work on `stream`.
-hipError_t launch_scan(const ScanArgs &args, int n_groups, hipStream_t stream);
+hipError_t launch_scan(const ScanArgs &args, int n_groups, bool extract, hipStream_t stream);
 hipError_t sort_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
 hipError_t launch_sort(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
                        const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream);
 hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream);
 hipError_t launch_score(const ScoreArgs &args, hipStream_t stream);
+hipError_t sort32_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
+hipError_t launch_sort32(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
+                         const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream);
+// vsc_seed.hip
+hipError_t launch_seed_keys(const uint32_t *x, const uint32_t *l, uint64_t n, int seg, uint32_t *keys, uint32_t *idx,
+                            hipStream_t stream);
+hipError_t launch_seed_gather(const uint32_t *x, const uint32_t *l, const uint32_t *pos, const uint32_t *idx, uint64_t n,
+                              uint2 *planes_out, uint32_t *pos_out, hipStream_t stream);
+hipError_t launch_lower_bound(const uint32_t *sorted_keys, uint64_t n, uint32_t n_buckets, uint32_t key_offset,
+                              uint32_t base, uint32_t *out, hipStream_t stream);
+hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *keys, uint32_t *gids,
+                            hipStream_t stream);
+hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted_gids, uint64_t n_pairs, uint32_t *off,
+                             uint32_t *poff, const uint2 *guides, uint2 *list_planes, uint32_t *list_gid,
+                             hipStream_t stream);
+hipError_t launch_seed_compare(const SeedArgs &args, int n_groups, hipStream_t stream);
 hipError_t merge_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
 hipError_t launch_merge(void *temp, size_t temp_bytes, const vsc_hit *in, uint64_t n, unsigned end_bit, uint32_t *keys_a,
                         uint32_t *keys_b, uint32_t *idx_a, uint32_t *idx_b, vsc_hit *out, hipStream_t stream);

@@ -10,6 +10,7 @@
 // Integer / bitwise work on the VALU (v_alignbit, v_xor, v_or, v_bcnt, v_min3, ballot / mbcnt);
 // no MFMA: the comparison is not a dense contraction.
 #include "vsc_internal.h"
+#include "vsc_device.h"
 
 #include <cstring>
 
@@ -18,43 +19,15 @@
 namespace vsc {
 
 // ------------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)
-{
-    return __builtin_amdgcn_alignbit(hi, lo, sh);  // ({hi,lo} >> sh)[31:0], sh in 0..31
-}
-
-__device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-// The four waves of a workgroup never exchange data; lanes of one wave exchange data through their
-// wave's LDS slice.  DS operations of one wave execute in order, so all that is needed is to stop
-// the compiler from moving LDS accesses across the hand-off.
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// reverse complement of a 23-base plane: reverse the bit order, complement (A<->T, C<->G = NOT both planes)
-__device__ __forceinline__ uint32_t revcomp_plane(uint32_t p) { return (~__brev(p)) >> 9; }
-__device__ __forceinline__ uint32_t reverse23(uint32_t p) { return __brev(p) >> 9; }
-
-// reads are fetched through the constant address space so that the (wave-uniform) loads are scalar
-typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) v4u *const_v4u_ptr;
-
-// ------------------------------------------------------------------------------------------------
 // scan kernel
 // ------------------------------------------------------------------------------------------------
+// A queued site is three words: x = hi plane (bits 0..22) | strand << 23 | edge << 24, l = lo plane,
+// pos = global position of the window start.  "edge" marks windows whose successor position is N
+// (the only windows the right-edge rule can concern).  Planes are in READ orientation: sites of the
+// '-' strand are stored reverse-complemented so that both strands compare against the same read.
 struct WaveState {
-    uint32_t *qsh, *qsl, *qpos;  // this wave's LDS site queue: hi plane (| strand << 23), lo plane, global position
-    uint64_t *hkey;              // this wave's LDS hit staging buffer
+    uint32_t *qx, *ql, *qpos;  // this wave's LDS site queue
+    uint64_t *hkey;            // this wave's LDS hit staging buffer
     uint32_t *hval;
     uint32_t q;       // queue fill (wave-uniform)
     uint32_t hn;      // staged hits (wave-uniform)
@@ -80,17 +53,6 @@ __device__ __forceinline__ void flush_hits(const ScanArgs &a, WaveState &w)
     w.hn = 0;
 }
 
-// Is global position p the end (offset + length) of a contig?
-__device__ __forceinline__ bool is_contig_end(const ScanArgs &a, uint32_t p)
-{
-    uint32_t lo = 0, hi = a.n_contigs;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (a.contig_end[mid] < p) lo = mid + 1; else hi = mid;
-    }
-    return lo < a.n_contigs && a.contig_end[lo] == p;
-}
-
 // Slow path of the guide loop: stage the hits of one (read, site slot) pair.
 // t = mismatch mask in READ orientation, c = popcount(t); lanes with c > max_mm do not take part.
 __device__ __forceinline__ void emit_hits(const ScanArgs &a, WaveState &w, uint32_t guide, uint32_t slot, uint32_t t,
@@ -99,20 +61,21 @@ __device__ __forceinline__ void emit_hits(const ScanArgs &a, WaveState &w, uint3
     bool hit = c <= a.max_mm;
     uint32_t pos = 0, strand = 0, mask = 0;
     if (hit) {
-        uint32_t idx = slot * kWave + w.lane;
+        const uint32_t idx = slot * kWave + w.lane;
+        const uint32_t x = w.qx[idx];
         pos = w.qpos[idx];
-        strand = (w.qsh[idx] >> 23) & 1u;
+        strand = (x >> kSiteStrandBit) & 1u;
         // mismatch positions in forward-genome window coordinates: on '-' the site was stored
         // reverse-complemented, so read position j is window position 22 - j
         mask = strand ? reverse23(t) : t;
         // Right-edge rule (bidir_mapping.cpp:51-52): a window that ends exactly at its contig's end is
         // never reported through the first-half route; the second-half route needs
         // HD(fullRead[11..23), window[11..23)) <= k.  The separator after a contig is N, so only
-        // windows followed by an N position can be affected.
-        uint32_t e = pos + VSC_READ_LEN;
-        uint32_t rel = e - a.first_pos;
-        if ((a.nm[rel >> 5] >> (rel & 31u)) & 1u) {
-            if (__popc(mask >> (VSC_READ_LEN / 2)) > a.k_half && is_contig_end(a, e)) hit = false;
+        // windows followed by an N position (edge flag) can be affected.
+        if ((x >> kSiteEdgeBit) & 1u) {
+            if ((uint32_t)__popc(mask >> (VSC_READ_LEN / 2)) > a.k_half &&
+                is_contig_end(a.contig_end, a.n_contigs, pos + VSC_READ_LEN))
+                hit = false;
         }
     }
     uint64_t b = __ballot(hit);
@@ -128,6 +91,27 @@ __device__ __forceinline__ void emit_hits(const ScanArgs &a, WaveState &w, uint3
     if (w.hn > kHitCap - kWave) flush_hits(a, w);
 }
 
+// Drops the first `take` queue entries (what is left, at most 63 entries, moves to the front).
+__device__ __forceinline__ void queue_consume(WaveState &w, uint32_t take)
+{
+    wave_sync();
+    const uint32_t left = w.q - take;
+    uint32_t vx = 0, vl = 0, vp = 0;
+    if (w.lane < left) {
+        vx = w.qx[take + w.lane];
+        vl = w.ql[take + w.lane];
+        vp = w.qpos[take + w.lane];
+    }
+    wave_sync();
+    if (w.lane < left) {
+        w.qx[w.lane] = vx;
+        w.ql[w.lane] = vl;
+        w.qpos[w.lane] = vp;
+    }
+    wave_sync();
+    w.q = left;
+}
+
 // Compares the first min(q, kBatch) queued sites of this wave against every read.
 __device__ __forceinline__ void process_batch(const ScanArgs &a, WaveState &w)
 {
@@ -139,9 +123,12 @@ __device__ __forceinline__ void process_batch(const ScanArgs &a, WaveState &w)
         bool live = idx < take;
         // an empty slot can never match: its upper bits differ from every read's (zero) upper bits,
         // and from the padding reads (all ones) in the lo plane
-        sh[j] = live ? (w.qsh[idx] & kMask23) : 0xFFFFFFFFu;
-        sl[j] = live ? w.qsl[idx] : 0u;
+        sh[j] = live ? (w.qx[idx] & kMask23) : 0xFFFFFFFFu;
+        sl[j] = live ? w.ql[idx] : 0u;
     }
+    // Reads are fetched through the constant address space, i.e. as scalar loads into SGPRs.  (Tried:
+    // wave-uniform vector loads into VGPRs, because tools/valu_rate.hip shows SGPR operands at half
+    // rate in isolation - the whole loop got 7 % slower, three-VGPR v_bitop3 pays for it elsewhere.)
     const const_v4u_ptr gp = (const_v4u_ptr)(uintptr_t)a.guides;
     const uint32_t m = a.max_mm;
     // the read table ends with one extra (never matching) group so that the next group can always be
@@ -179,38 +166,45 @@ __device__ __forceinline__ void process_batch(const ScanArgs &a, WaveState &w)
             }
         }
     }
-    // keep what the batch did not take (at most 63 entries) at the front of the queue
-    wave_sync();
-    uint32_t left = w.q - take;
-    uint32_t vh = 0, vl = 0, vp = 0;
-    if (w.lane < left) {
-        vh = w.qsh[take + w.lane];
-        vl = w.qsl[take + w.lane];
-        vp = w.qpos[take + w.lane];
-    }
-    wave_sync();
-    if (w.lane < left) {
-        w.qsh[w.lane] = vh;
-        w.qsl[w.lane] = vl;
-        w.qpos[w.lane] = vp;
-    }
-    wave_sync();
-    w.q = left;
+    queue_consume(w, take);
 }
 
+// Extract mode: appends the first min(q, kBatch) queued sites to the global site arrays.
+__device__ __forceinline__ void flush_sites(const ScanArgs &a, WaveState &w)
+{
+    const uint32_t take = w.q < (uint32_t)kBatch ? w.q : (uint32_t)kBatch;
+    unsigned long long base = 0;
+    if (w.lane == 0) base = atomicAdd(&a.counters[kCntHits], (unsigned long long)take);
+    base = ((unsigned long long)uniform((uint32_t)(base >> 32)) << 32) | uniform((uint32_t)base);
+    if (base + take <= a.hit_cap) {
+        for (uint32_t i = w.lane; i < take; i += kWave) {
+            a.site_x[base + i] = w.qx[i];
+            a.site_l[base + i] = w.ql[i];
+            a.site_pos[base + i] = w.qpos[i];
+        }
+    } else if (w.lane == 0) {
+        atomicMax(&a.counters[kCntOverflow], 1ull);
+    }
+    queue_consume(w, take);
+}
+
+// kExtract = false: the streaming search (every PAM-valid window against every read).
+// kExtract = true : only the guide-independent front end - writes the PAM-valid, N-free windows of
+//                   both strands to site_x / site_l / site_pos (input of the seed index, vsc_seed.hip).
+template <bool kExtract>
 __global__ __launch_bounds__(kWave *kWavesPerGroup) void scan_kernel(const ScanArgs a)
 {
-    __shared__ uint32_t s_qsh[kWavesPerGroup][kQueueCap];
-    __shared__ uint32_t s_qsl[kWavesPerGroup][kQueueCap];
+    __shared__ uint32_t s_qx[kWavesPerGroup][kQueueCap];
+    __shared__ uint32_t s_ql[kWavesPerGroup][kQueueCap];
     __shared__ uint32_t s_qpos[kWavesPerGroup][kQueueCap];
-    __shared__ uint64_t s_hkey[kWavesPerGroup][kHitCap];
-    __shared__ uint32_t s_hval[kWavesPerGroup][kHitCap];
+    __shared__ uint64_t s_hkey[kWavesPerGroup][kExtract ? 1 : kHitCap];
+    __shared__ uint32_t s_hval[kWavesPerGroup][kExtract ? 1 : kHitCap];
 
     const uint32_t wave = threadIdx.x / kWave;
     WaveState w;
     w.lane = threadIdx.x % kWave;
-    w.qsh = s_qsh[wave];
-    w.qsl = s_qsl[wave];
+    w.qx = s_qx[wave];
+    w.ql = s_ql[wave];
     w.qpos = s_qpos[wave];
     w.hkey = s_hkey[wave];
     w.hval = s_hval[wave];
@@ -233,13 +227,15 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void scan_kernel(const ScanA
             const uint32_t L0 = a.lo[wi], L1 = a.lo[wi + 1];
             const uint32_t N0 = a.nm[wi], N1 = a.nm[wi + 1];
             // windows (32 starts per lane) that contain an N: OR of the N plane shifted by 0..22
-            uint64_t nn = ((uint64_t)N1 << 32) | N0;
+            const uint64_t nraw = ((uint64_t)N1 << 32) | N0;
+            uint64_t nn = nraw;
             nn |= nn >> 1;
             nn |= nn >> 2;
             nn |= nn >> 4;
             nn |= nn >> 8;   // bit i covers positions i .. i+15
             nn |= nn >> 7;   // bit i covers positions i .. i+22
             const uint32_t clean = ~(uint32_t)nn;
+            const uint32_t edge = (uint32_t)(nraw >> VSC_READ_LEN);  // bit i: position i+23 is N
             // PAM test, 32 window starts at a time (bidir_mapping.cpp:71-76, 240-247)
             const uint32_t H21 = funnel(H1, H0, 21), L21 = funnel(L1, L0, 21);
             const uint32_t H22 = funnel(H1, H0, 22), L22 = funnel(L1, L0, 22);
@@ -268,31 +264,39 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void scan_kernel(const ScanA
                 uint32_t ph = funnel(H1, H0, b) & kMask23;
                 uint32_t pl = funnel(L1, L0, b) & kMask23;
                 if (is_rev) {
-                    ph = revcomp_plane(ph) | (1u << 23);
+                    ph = revcomp_plane(ph) | (1u << kSiteStrandBit);
                     pl = revcomp_plane(pl);
                 }
+                ph |= ((edge >> b) & 1u) << kSiteEdgeBit;
                 if (has) {
                     const uint32_t at = w.q + lanes_below(act);
-                    w.qsh[at] = ph;
-                    w.qsl[at] = pl;
+                    w.qx[at] = ph;
+                    w.ql[at] = pl;
                     w.qpos[at] = base_pos + b;
                 }
                 const uint32_t added = (uint32_t)__popcll(act);
                 w.q += added;
                 sites += added;
                 wave_sync();
-                if (w.q >= (uint32_t)kBatch) process_batch(a, w);
+                if (w.q >= (uint32_t)kBatch) {
+                    if (kExtract) flush_sites(a, w); else process_batch(a, w);
+                }
             }
         }
     }
-    if (w.q > 0) process_batch(a, w);
-    flush_hits(a, w);
+    if (w.q > 0) {
+        if (kExtract) flush_sites(a, w); else process_batch(a, w);
+    }
+    if (!kExtract) flush_hits(a, w);
     if (w.lane == 0 && sites) atomicAdd(&a.counters[kCntSites], sites);
 }
 
-hipError_t launch_scan(const ScanArgs &args, int n_groups, hipStream_t stream)
+hipError_t launch_scan(const ScanArgs &args, int n_groups, bool extract, hipStream_t stream)
 {
-    hipLaunchKernelGGL(scan_kernel, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
+    if (extract)
+        hipLaunchKernelGGL(scan_kernel<true>, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
+    else
+        hipLaunchKernelGGL(scan_kernel<false>, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
     return hipGetLastError();
 }
 
@@ -369,12 +373,22 @@ __global__ __launch_bounds__(256) void gather_kernel(const vsc_hit *in, const ui
     out[i] = in[idx[i]];
 }
 
-hipError_t merge_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes)
+hipError_t sort32_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes)
 {
     *bytes = 0;
     return rocprim::radix_sort_pairs((void *)nullptr, *bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                      (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, end_bit);
 }
+
+hipError_t launch_sort32(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
+                         const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit,
+                                     stream);
+}
+
+hipError_t merge_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes) { return sort32_temp_bytes(n, end_bit, bytes); }
 
 hipError_t launch_merge(void *temp, size_t temp_bytes, const vsc_hit *in, uint64_t n, unsigned end_bit, uint32_t *keys_a,
                         uint32_t *keys_b, uint32_t *idx_a, uint32_t *idx_b, vsc_hit *out, hipStream_t stream)
@@ -384,8 +398,7 @@ hipError_t launch_merge(void *temp, size_t temp_bytes, const vsc_hit *in, uint64
     hipLaunchKernelGGL(merge_key_kernel, dim3(blocks), dim3(256), 0, stream, in, n, keys_a, idx_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_a, keys_b, (const uint32_t *)idx_a, idx_b,
-                                  (size_t)n, 0u, end_bit, stream);
+    e = launch_sort32(temp, temp_bytes, keys_a, keys_b, idx_a, idx_b, n, end_bit, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, stream, in, (const uint32_t *)idx_b, n, out);
     return hipGetLastError();

@@ -1,0 +1,365 @@
+// vsc_seed.hip - the seed-partitioned search: an exact pigeonhole pre-partition of the PAM-valid
+// sites, kept resident in HBM, so that a read is only compared with the sites that can still be
+// within its mismatch budget.
+//
+// The reference prunes with a pigeonhole split as well (two halves, floor(m/2) errors each,
+// VARSCOT_pipeline/read_mapping/bidir_mapping.cpp:129-146,157-162) but walks an FM index for it.
+// Here the 21 non-PAM read positions are cut into three 7-base segments.  A window within m
+// mismatches of a read has at most k = floor(m/3) mismatches in at least one segment (otherwise it
+// would have >= 3(k+1) > m).  Every PAM-valid site is filed three times, once per segment, under the
+// 14-bit code of its 7 segment bases ("bucket").  A search enumerates, per read and segment, the
+// 1 / 22 / 211 seven-mers within k substitutions of the read's segment, which turns into one list of
+// reads per bucket; a wave then compares a chunk of one bucket's sites only with that bucket's reads:
+// 3 * 211 / 16384 = 3.9 % of all (site, read) pairs at m = 6..8.  The comparison itself is the full
+// 23-position one of the streaming scan, so the accepted set is identical; a pair that qualifies in
+// several segments is reported by the first one only.
+#include "vsc_internal.h"
+#include "vsc_device.h"
+
+namespace vsc {
+
+__device__ __forceinline__ uint32_t segment_key(uint32_t x, uint32_t l, int s)
+{
+    return (((x >> (kSegBases * s)) & 0x7Fu) << kSegBases) | ((l >> (kSegBases * s)) & 0x7Fu);
+}
+
+// ------------------------------------------------------------------------------------------------
+// index build
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seed_key_kernel(const uint32_t *x, const uint32_t *l, uint64_t n, int seg,
+                                                       uint32_t *keys, uint32_t *idx)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = segment_key(x[i], l[i], seg);
+    idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void seed_gather_kernel(const uint32_t *x, const uint32_t *l, const uint32_t *pos,
+                                                          const uint32_t *idx, uint64_t n, uint2 *planes_out,
+                                                          uint32_t *pos_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = idx[i];
+    planes_out[i] = make_uint2(x[j], l[j]);
+    pos_out[i] = pos[j];
+}
+
+// out[b] = base + (first index i with sorted_keys[i] >= b), b = 0 .. n_buckets (inclusive)
+__global__ __launch_bounds__(256) void lower_bound_kernel(const uint32_t *sorted_keys, uint64_t n, uint32_t n_buckets,
+                                                          uint32_t key_offset, uint32_t base, uint32_t *out)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets) return;
+    const uint32_t want = b + key_offset;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (sorted_keys[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    out[b] = base + (uint32_t)lo;
+}
+
+hipError_t launch_seed_keys(const uint32_t *x, const uint32_t *l, uint64_t n, int seg, uint32_t *keys, uint32_t *idx,
+                            hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(seed_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, l, n, seg, keys, idx);
+    return hipGetLastError();
+}
+
+hipError_t launch_seed_gather(const uint32_t *x, const uint32_t *l, const uint32_t *pos, const uint32_t *idx, uint64_t n,
+                              uint2 *planes_out, uint32_t *pos_out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(seed_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, l, pos, idx, n,
+                       planes_out, pos_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_lower_bound(const uint32_t *sorted_keys, uint64_t n, uint32_t n_buckets, uint32_t key_offset,
+                              uint32_t base, uint32_t *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lower_bound_kernel, dim3((n_buckets + 1 + 255) / 256), dim3(256), 0, stream, sorted_keys, n,
+                       n_buckets, key_offset, base, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-search: neighbourhood enumeration and the per-bucket read lists
+// ------------------------------------------------------------------------------------------------
+// the 21 position pairs (p < q) of a 7-base segment
+__constant__ uint8_t kPairP[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+__constant__ uint8_t kPairQ[21] = {1, 2, 3, 4, 5, 6, 2, 3, 4, 5, 6, 3, 4, 5, 6, 4, 5, 6, 5, 6, 6};
+
+__device__ __forceinline__ void substitute(uint32_t &h, uint32_t &l, uint32_t p, uint32_t alt)
+{
+    const uint32_t c = (((h >> p) & 1u) << 1) | ((l >> p) & 1u);
+    const uint32_t d = (c + alt) & 3u;  // alt in 1..3: the three other bases
+    h = (h & ~(1u << p)) | ((d >> 1) << p);
+    l = (l & ~(1u << p)) | ((d & 1u) << p);
+}
+
+// One thread per (read, segment, neighbour): the bucket of the neighbour 7-mer.
+// Neighbour numbering: 0 = the segment itself; 1..21 = one substitution (position * 3 + alt);
+// 22..210 = two substitutions (pair * 9 + alt1 * 3 + alt2).  n_nbr = 1, 22 or 211 for k = 0, 1, 2.
+__global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr,
+                                                        uint32_t *keys, uint32_t *gids)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = (uint64_t)n_guides * kSegments * n_nbr;
+    if (i >= total) return;
+    const uint32_t n = (uint32_t)(i % n_nbr);
+    const uint32_t s = (uint32_t)((i / n_nbr) % kSegments);
+    const uint32_t g = (uint32_t)(i / ((uint64_t)n_nbr * kSegments));
+    const uint2 gp = guides[g];
+    uint32_t h = (gp.x >> (kSegBases * s)) & 0x7Fu, l = (gp.y >> (kSegBases * s)) & 0x7Fu;
+    if (n >= 22) {
+        const uint32_t e = n - 22, pi = e / 9, alts = e % 9;
+        substitute(h, l, kPairP[pi], alts / 3 + 1);
+        substitute(h, l, kPairQ[pi], alts % 3 + 1);
+    } else if (n >= 1) {
+        const uint32_t e = n - 1;
+        substitute(h, l, e / 3, e % 3 + 1);
+    }
+    keys[i] = s * kBucketsPerSeg + ((h << kSegBases) | l);
+    gids[i] = g;
+}
+
+// poff[b] = sum over b' < b of roundup4(off[b'+1] - off[b']); one workgroup, kBuckets + 1 outputs
+__global__ __launch_bounds__(1024) void seed_pad_scan_kernel(const uint32_t *off, uint32_t *poff)
+{
+    __shared__ uint32_t partial[1024];
+    constexpr uint32_t per = kBuckets / 1024;  // 48
+    const uint32_t t = threadIdx.x;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per; ++i) {
+        const uint32_t b = t * per + i;
+        sum += (off[b + 1] - off[b] + (kGuideUnroll - 1)) & ~(uint32_t)(kGuideUnroll - 1);
+    }
+    partial[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = t >= d ? partial[t - d] : 0;
+        __syncthreads();
+        partial[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = partial[t] - sum;  // exclusive prefix of this thread's range
+    for (uint32_t i = 0; i < per; ++i) {
+        const uint32_t b = t * per + i;
+        poff[b] = run;
+        run += (off[b + 1] - off[b] + (kGuideUnroll - 1)) & ~(uint32_t)(kGuideUnroll - 1);
+    }
+    if (t == 1023) poff[kBuckets] = run;
+}
+
+// Scatters the sorted (bucket, read) pairs into the padded per-bucket lists.
+__global__ __launch_bounds__(256) void seed_list_kernel(const uint32_t *sorted_keys, const uint32_t *sorted_gids,
+                                                        uint64_t n_pairs, const uint32_t *off, const uint32_t *poff,
+                                                        const uint2 *guides, uint2 *list_planes, uint32_t *list_gid)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const uint32_t b = sorted_keys[i], g = sorted_gids[i];
+    const uint32_t dst = poff[b] + ((uint32_t)i - off[b]);
+    list_planes[dst] = guides[g];
+    list_gid[dst] = g;
+}
+
+hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *keys, uint32_t *gids,
+                            hipStream_t stream)
+{
+    const uint64_t total = (uint64_t)n_guides * kSegments * n_nbr;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(seed_enum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, guides, n_guides, n_nbr,
+                       keys, gids);
+    return hipGetLastError();
+}
+
+hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted_gids, uint64_t n_pairs, uint32_t *off,
+                             uint32_t *poff, const uint2 *guides, uint2 *list_planes, uint32_t *list_gid,
+                             hipStream_t stream)
+{
+    hipError_t e = launch_lower_bound(sorted_keys, n_pairs, kBuckets, 0, 0, off, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(seed_pad_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)off, poff);
+    e = hipGetLastError();
+    if (e != hipSuccess || n_pairs == 0) return e;
+    hipLaunchKernelGGL(seed_list_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, sorted_keys,
+                       sorted_gids, n_pairs, (const uint32_t *)off, (const uint32_t *)poff, guides, list_planes, list_gid);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// compare kernel
+// ------------------------------------------------------------------------------------------------
+struct SeedWave {
+    uint64_t *tok;   // pending hits of the current chunk: t | slot << 23 | lane << 26  |  list index << 32
+    uint64_t *hkey;  // resolved hits waiting for the global append
+    uint32_t *hval;
+    uint32_t ntok, hn, lane;
+};
+
+__device__ __forceinline__ void seed_flush_hits(const SeedArgs &a, SeedWave &w)
+{
+    if (w.hn == 0) return;
+    unsigned long long base = 0;
+    if (w.lane == 0) base = atomicAdd(&a.counters[kCntHits], (unsigned long long)w.hn);
+    base = ((unsigned long long)uniform((uint32_t)(base >> 32)) << 32) | uniform((uint32_t)base);
+    if (base + w.hn <= a.hit_cap) {
+        for (uint32_t i = w.lane; i < w.hn; i += kWave) {
+            a.hit_keys[base + i] = w.hkey[i];
+            a.hit_vals[base + i] = w.hval[i];
+        }
+    } else if (w.lane == 0) {
+        atomicMax(&a.counters[kCntOverflow], 1ull);
+    }
+    wave_sync();
+    w.hn = 0;
+}
+
+// Dense second half of the hit path: every lane resolves one pending token of the current chunk.
+__device__ __forceinline__ void seed_resolve(const SeedArgs &a, SeedWave &w, uint32_t chunk_first, uint32_t seg)
+{
+    wave_sync();
+    for (uint32_t base = 0; base < w.ntok; base += kWave) {
+        const uint32_t i = base + w.lane;
+        bool hit = i < w.ntok;
+        uint64_t key = 0;
+        uint32_t val = 0;
+        if (hit) {
+            const uint64_t tk = w.tok[i];
+            const uint32_t lo = (uint32_t)tk;
+            const uint32_t t = lo & kMask23;
+            const uint32_t site = chunk_first + ((lo >> 23) & 7u) * kWave + (lo >> 26);
+            const uint32_t x = a.planes[site].x;
+            const uint32_t pos = a.pos[site];
+            const uint32_t gid = a.list_gid[(uint32_t)(tk >> 32)];
+            const uint32_t strand = (x >> kSiteStrandBit) & 1u;
+            // a pair that also qualifies in an earlier segment was reported there
+            for (uint32_t s = 0; s < seg; ++s)
+                if ((uint32_t)__popc(t & (0x7Fu << (kSegBases * s))) <= a.k_seg) hit = false;
+            const uint32_t mask = strand ? reverse23(t) : t;
+            // right-edge rule, bidir_mapping.cpp:51-52 (see emit_hits in vsc_kernels.hip)
+            if (hit && ((x >> kSiteEdgeBit) & 1u)) {
+                if ((uint32_t)__popc(mask >> (VSC_READ_LEN / 2)) > a.k_half &&
+                    is_contig_end(a.contig_end, a.n_contigs, pos + VSC_READ_LEN))
+                    hit = false;
+            }
+            key = ((uint64_t)gid << 33) | ((uint64_t)strand << 32) | pos;
+            val = ((uint32_t)__popc(t) << 23) | mask;
+        }
+        const uint64_t b = __ballot(hit);
+        if (hit) {
+            const uint32_t at = w.hn + lanes_below(b);
+            w.hkey[at] = key;
+            w.hval[at] = val;
+        }
+        wave_sync();
+        w.hn += (uint32_t)__popcll(b);
+        if (w.hn > kSeedHitCap - kWave) seed_flush_hits(a, w);
+    }
+    w.ntok = 0;
+}
+
+__global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(const SeedArgs a)
+{
+    __shared__ uint64_t s_tok[kWavesPerGroup][kSeedTokCap];
+    __shared__ uint64_t s_hkey[kWavesPerGroup][kSeedHitCap];
+    __shared__ uint32_t s_hval[kWavesPerGroup][kSeedHitCap];
+
+    const uint32_t wave = threadIdx.x / kWave;
+    SeedWave w;
+    w.lane = threadIdx.x % kWave;
+    w.tok = s_tok[wave];
+    w.hkey = s_hkey[wave];
+    w.hval = s_hval[wave];
+    w.ntok = 0;
+    w.hn = 0;
+
+    const const_v4u_ptr gp = (const_v4u_ptr)(uintptr_t)a.list_planes;
+    const uint32_t m = a.max_mm;
+    unsigned long long pairs = 0, visited = 0;
+
+    for (;;) {
+        uint32_t first = 0;
+        if (w.lane == 0) first = (uint32_t)atomicAdd(&a.counters[kCntChunk], (unsigned long long)kSeedGrab);
+        first = uniform(first);
+        if (first >= a.n_chunks) break;
+        const uint32_t last = min(first + (uint32_t)kSeedGrab, a.n_chunks);
+        for (uint32_t c = first; c < last; ++c) {
+            const uint32_t bucket = uniform(a.chunk_bucket[c]);
+            const uint32_t g0 = uniform(a.poff[bucket]), g1 = uniform(a.poff[bucket + 1]);
+            if (g0 == g1) continue;  // no read has this bucket in its neighbourhood
+            const uint32_t st = uniform(a.chunk_start[c]);
+            const uint32_t cnt = min((uint32_t)kBatch, uniform(a.bucket_start[bucket + 1]) - st);
+            const uint32_t seg = bucket / kBucketsPerSeg;
+            uint32_t sh[kSitesPerLane], sl[kSitesPerLane];
+#pragma unroll
+            for (int j = 0; j < kSitesPerLane; ++j) {
+                const uint32_t idx = j * kWave + w.lane;
+                uint2 v = make_uint2(0xFFFFFFFFu, 0u);  // empty slot: never matches (see process_batch)
+                if (idx < cnt) v = a.planes[st + idx];
+                sh[j] = idx < cnt ? (v.x & kMask23) : 0xFFFFFFFFu;
+                sl[j] = v.y;
+            }
+            pairs += (unsigned long long)cnt * (g1 - g0);
+            visited += cnt;
+            v4u na = gp[g0 >> 1], nb = gp[(g0 >> 1) + 1];
+            for (uint32_t g = g0; g < g1; g += kGuideUnroll) {
+                const v4u ga = na, gb = nb;
+                na = gp[(g >> 1) + 2];  // the list is allocated with one spare group
+                nb = gp[(g >> 1) + 3];
+                const uint32_t gh[kGuideUnroll] = {ga.x, ga.z, gb.x, gb.z};
+                const uint32_t gl[kGuideUnroll] = {ga.y, ga.w, gb.y, gb.w};
+                uint32_t best[kGuideUnroll];
+#pragma unroll
+                for (int u = 0; u < kGuideUnroll; ++u) {
+                    uint32_t cm = 32;
+#pragma unroll
+                    for (int j = 0; j < kSitesPerLane; ++j) {
+                        const uint32_t t = (sh[j] ^ gh[u]) | (sl[j] ^ gl[u]);
+                        cm = min(cm, (uint32_t)__popc(t));
+                    }
+                    best[u] = cm;
+                }
+                const uint32_t any = min(min(best[0], best[1]), min(best[2], best[3]));
+                if (__ballot(any <= m) != 0) {
+                    // sparse first half of the hit path: one 8-byte token per hit into LDS
+#pragma unroll
+                    for (int u = 0; u < kGuideUnroll; ++u) {
+                        if (__ballot(best[u] <= m) == 0) continue;
+#pragma unroll
+                        for (int j = 0; j < kSitesPerLane; ++j) {
+                            const uint32_t t = (sh[j] ^ gh[u]) | (sl[j] ^ gl[u]);
+                            const bool hit = (uint32_t)__popc(t) <= m;
+                            const uint64_t b = __ballot(hit);
+                            if (b == 0) continue;
+                            if (hit)
+                                w.tok[w.ntok + lanes_below(b)] =
+                                    ((uint64_t)(g + u) << 32) | (w.lane << 26) | ((uint32_t)j << 23) | t;
+                            w.ntok += (uint32_t)__popcll(b);
+                            if (w.ntok > kSeedTokCap - kWave) seed_resolve(a, w, st, seg);
+                        }
+                    }
+                }
+            }
+            if (w.ntok) seed_resolve(a, w, st, seg);
+        }
+    }
+    seed_flush_hits(a, w);
+    if (w.lane == 0 && pairs) {
+        atomicAdd(&a.counters[kCntSites], pairs);
+        atomicAdd(&a.counters[kCntVisited], visited);
+    }
+}
+
+hipError_t launch_seed_compare(const SeedArgs &args, int n_groups, hipStream_t stream)
+{
+    hipLaunchKernelGGL(seed_compare_kernel, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace vsc

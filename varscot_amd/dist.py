@@ -50,11 +50,12 @@ def gather_records(local, group=None, dst=0):
     return out, counts
 
 
-def sharded_search(ctx, genome_shard, codes, max_mismatches, extra_pam=None, group=None, device=None):
+def sharded_search(ctx, genome_shard, codes, max_mismatches, extra_pam=None, group=None, device=None,
+                   algorithm="auto"):
     """Search all reads on this rank's shard, gather to rank 0, merge there.
 
     Returns (merged hits on rank 0 | None, local Hits)."""
-    hits = genome_shard.search(codes, max_mismatches, extra_pam)
+    hits = genome_shard.search(codes, max_mismatches, extra_pam, algorithm=algorithm)
     n = len(hits)
     local = torch.empty(n * RECORD_BYTES, dtype=torch.uint8, device=device)
     if n:
