@@ -21,14 +21,22 @@ namespace {
 struct DeviceBuf {
     void *p = nullptr;
     size_t cap = 0;
+    // hipMalloc / hipFree of multi-GB buffers cost hundreds of milliseconds: grow with 1/8 headroom so
+    // that result sizes that wobble from search to search do not reallocate every time
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e == hipSuccess) cap = bytes;
+        size_t want = bytes + bytes / 8;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess && want != bytes) {
+            (void)hipGetLastError();
+            want = bytes;
+            e = hipMalloc(&p, want);
+        }
+        if (e == hipSuccess) cap = want;
         return e;
     }
     void release()
@@ -83,7 +91,8 @@ struct vsc_genome {
     char index_extra_pam[2] = {0, 0};
     uint64_t index_sites = 0;  // S
     uint2 *d_ix_planes = nullptr;
-    uint32_t *d_ix_pos = nullptr, *d_ix_bucket_start = nullptr, *d_ix_chunk_start = nullptr, *d_ix_chunk_bucket = nullptr;
+    uint32_t *d_ix_pos = nullptr, *d_ix_bucket_start = nullptr;
+    uint4 *d_ix_chunk_tab = nullptr;
     uint32_t ix_chunks = 0;
     uint64_t index_bytes = 0;
     double index_ms = 0;
@@ -333,8 +342,7 @@ int vsc_genome_free(vsc_genome *g)
     if (!g) return VSC_OK;
     if (g->ctx) (void)hipSetDevice(g->ctx->device);
     for (void *p : {(void *)g->d_hi, (void *)g->d_lo, (void *)g->d_nm, (void *)g->d_contig_off, (void *)g->d_contig_end,
-                    (void *)g->d_ix_planes, (void *)g->d_ix_pos, (void *)g->d_ix_bucket_start, (void *)g->d_ix_chunk_start,
-                    (void *)g->d_ix_chunk_bucket})
+                    (void *)g->d_ix_planes, (void *)g->d_ix_pos, (void *)g->d_ix_bucket_start, (void *)g->d_ix_chunk_tab})
         if (p) (void)hipFree(p);
     delete g;
     return VSC_OK;
@@ -396,7 +404,7 @@ bool index_matches(const vsc_genome *g, const vsc_search_params *p)
 void free_index(vsc_genome *g)
 {
     for (void **p : {(void **)&g->d_ix_planes, (void **)&g->d_ix_pos, (void **)&g->d_ix_bucket_start,
-                     (void **)&g->d_ix_chunk_start, (void **)&g->d_ix_chunk_bucket}) {
+                     (void **)&g->d_ix_chunk_tab}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -474,22 +482,20 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         return e;
     }
     // chunks: at most kBatch sites of one bucket each
-    std::vector<uint32_t> cstart, cbucket;
-    cstart.reserve(3 * S / kBatch + kBuckets);
-    cbucket.reserve(3 * S / kBatch + kBuckets);
+    std::vector<uint32_t> ctab;  // {first site, site count, bucket, 0} per chunk
+    ctab.reserve(4 * (3 * S / kBatch + kBuckets));
     for (uint32_t b = 0; b < (uint32_t)kBuckets; ++b)
         for (uint64_t p = bs[b]; p < bs[b + 1]; p += kBatch) {
-            cstart.push_back((uint32_t)p);
-            cbucket.push_back(b);
+            ctab.push_back((uint32_t)p);
+            ctab.push_back((uint32_t)std::min<uint64_t>(kBatch, bs[b + 1] - p));
+            ctab.push_back(b);
+            ctab.push_back(0);
         }
-    g->ix_chunks = (uint32_t)cstart.size();
-    const size_t cb = std::max<size_t>(cstart.size(), 1) * sizeof(uint32_t);
-    step(hipMalloc((void **)&g->d_ix_chunk_start, cb));
-    step(hipMalloc((void **)&g->d_ix_chunk_bucket, cb));
-    if (e == hipSuccess && !cstart.empty()) {
-        step(hipMemcpyAsync(g->d_ix_chunk_start, cstart.data(), cstart.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        step(hipMemcpyAsync(g->d_ix_chunk_bucket, cbucket.data(), cbucket.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    }
+    g->ix_chunks = (uint32_t)(ctab.size() / 4);
+    const size_t cb = std::max<size_t>(ctab.size(), 4) * sizeof(uint32_t);
+    step(hipMalloc((void **)&g->d_ix_chunk_tab, cb));
+    if (e == hipSuccess && !ctab.empty())
+        step(hipMemcpyAsync(g->d_ix_chunk_tab, ctab.data(), ctab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     step(hipEventRecord(ctx->ev[6], st));
     step(hipStreamSynchronize(st));
     if (e != hipSuccess) {
@@ -507,7 +513,7 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         g->index_extra_pam[0] = params->extra_pam[0];
         g->index_extra_pam[1] = params->extra_pam[1];
     }
-    g->index_bytes = 3 * S * (sizeof(uint2) + sizeof(uint32_t)) + (kBuckets + 1) * sizeof(uint32_t) + 2 * cb;
+    g->index_bytes = 3 * S * (sizeof(uint2) + sizeof(uint32_t)) + (kBuckets + 1) * sizeof(uint32_t) + cb;
     return hipSuccess;
 }
 
@@ -600,7 +606,7 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
 
     const double sites_est = genome->sites ? (double)genome->sites : own_bases / 4;
     uint64_t cap = (uint64_t)(1.5 * sites_est * n_guides * hit_probability(params->max_mismatches)) + (1u << 20);
-    unsigned long long cnt[kCntSlots] = {0, 0, 0, 0, 0};
+    unsigned long long cnt[kCntSlots] = {0, 0, 0, 0, 0, 0, 0};
 
     ScanArgs a{};
     SeedArgs sa{};
@@ -642,8 +648,7 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         sa.planes = genome->d_ix_planes;
         sa.pos = genome->d_ix_pos;
         sa.bucket_start = genome->d_ix_bucket_start;
-        sa.chunk_start = genome->d_ix_chunk_start;
-        sa.chunk_bucket = genome->d_ix_chunk_bucket;
+        sa.chunk_tab = genome->d_ix_chunk_tab;
         sa.n_chunks = genome->ix_chunks;
         sa.list_planes = (const uint4 *)ctx->seed_lplanes.p;
         sa.list_gid = (const uint32_t *)ctx->seed_lgid.p;
@@ -657,6 +662,12 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         const uint32_t n_waves_max = (uint32_t)ctx->n_cus * 5 * kWavesPerGroup;
         const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, (sa.n_chunks + kSeedGrab - 1) / kSeedGrab));
         n_groups = (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
+        // block of records a wave reserves per atomic: large when many hits are expected, small otherwise
+        // (the unused tail of every wave's last block is sorted along as sentinels)
+        const uint64_t per_wave = cap / ((uint64_t)n_groups * kWavesPerGroup * 8);
+        sa.reserve = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(kSeedHitCap, per_wave / kWave * kWave));
+        if (const char *o = std::getenv("VSC_SEED_RESERVE")) sa.reserve = (uint32_t)std::atoi(o);
+        cap += (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
     }
 
     ht.lap("prep enqueue");
@@ -674,7 +685,11 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
             sa.hit_keys = (uint64_t *)ctx->keys_a.p;
             sa.hit_vals = (uint32_t *)ctx->vals_a.p;
             sa.hit_cap = cap;
-            VSC_HIP_H(launch_seed_compare(sa, n_groups, ctx->stream));
+            // the per-pair test beats the min-tree variant at every m measured (fewer registers, no
+            // re-derivation of hits); VSC_SEED_DENSE=0 selects the min-tree variant for experiments
+            bool dense = true;
+            if (const char *o = std::getenv("VSC_SEED_DENSE")) dense = o[0] == '1';
+            VSC_HIP_H(launch_seed_compare(sa, n_groups, dense, ctx->stream));
         }
         VSC_HIP_H(hipEventRecord(ctx->ev[2], ctx->stream));
         VSC_HIP_H(hipMemcpyAsync(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
@@ -683,9 +698,14 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         t.passes++;
         if (!cnt[kCntOverflow]) break;
         if (t.passes >= 3) return cleanup(fail(ctx, VSC_ERR_DEVICE, "vsc_search: hit buffer overflowed repeatedly"));
-        cap = cnt[kCntHits] + (cnt[kCntHits] >> 6) + 4096;  // the counter holds the true total
+        // the counters hold the true total (SEED: records placed + records lost, + one block per wave)
+        cap = cnt[kCntHits] + cnt[kCntLost];
+        cap += (cap >> 6) + 4096 + (algo == VSC_ALGO_SEED ? (uint64_t)n_groups * kWavesPerGroup * sa.reserve : 0);
     }
-    const uint64_t n = cnt[kCntHits];
+    // SEED: counters[kCntHits] counts reserved records, kCntPad of them are sentinels (key = all ones)
+    // that the sort moves behind the n real hits
+    const uint64_t n_sort = cnt[kCntHits];
+    const uint64_t n = n_sort - cnt[kCntPad];
     if (algo == VSC_ALGO_SCAN) {
         const_cast<vsc_genome *>(genome)->sites = cnt[kCntSites];
         t.sites = cnt[kCntSites];
@@ -700,17 +720,17 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     if (n > 0) {
         unsigned guide_bits = 1;
         while (guide_bits < 31 && (1ull << guide_bits) < n_guides) ++guide_bits;
-        const unsigned end_bit = 33 + guide_bits;
+        const unsigned end_bit = 33 + guide_bits + (n_sort != n ? 1 : 0);  // one more bit separates the sentinels
         size_t temp_bytes = 0;
-        VSC_HIP_H(sort_temp_bytes(n, end_bit, &temp_bytes));
+        VSC_HIP_H(sort_temp_bytes(n_sort, end_bit, &temp_bytes));
         VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
-        VSC_HIP_H(ctx->keys_b.ensure(n * sizeof(uint64_t)));
-        VSC_HIP_H(ctx->vals_b.ensure(n * sizeof(uint32_t)));
+        VSC_HIP_H(ctx->keys_b.ensure(n_sort * sizeof(uint64_t)));
+        VSC_HIP_H(ctx->vals_b.ensure(n_sort * sizeof(uint32_t)));
         ht.lap("sort buffers ensure");
         VSC_HIP_H(take_records(ctx, hits, n));
         ht.lap("record storage");
         VSC_HIP_H(launch_sort(ctx->sort_temp.p, temp_bytes, (const uint64_t *)ctx->keys_a.p, (uint64_t *)ctx->keys_b.p,
-                              (const uint32_t *)ctx->vals_a.p, (uint32_t *)ctx->vals_b.p, n, end_bit, ctx->stream));
+                              (const uint32_t *)ctx->vals_a.p, (uint32_t *)ctx->vals_b.p, n_sort, end_bit, ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
         FinalizeArgs f{};
         f.keys = (const uint64_t *)ctx->keys_b.p;

@@ -32,10 +32,10 @@ constexpr int kBucketsPerSeg = 1 << (2 * kSegBases);  // 16384 seven-mers
 constexpr int kBuckets = kSegments * kBucketsPerSeg;
 constexpr int kSeedTokCap = 512;                // per-wave LDS buffer of pending hit tokens
 constexpr int kSeedHitCap = 256;                // per-wave LDS buffer of resolved hits
-constexpr int kSeedGrab = 8;                    // chunks (<= 512 sites of one bucket) per grab of the work counter
+constexpr int kSeedGrab = 16;                   // chunks (<= 512 sites of one bucket) per grab of the work counter
 
 // counters[] slots of one scan launch
-enum { kCntHits = 0, kCntChunk = 1, kCntSites = 2, kCntOverflow = 3, kCntVisited = 4, kCntSlots = 5 };
+enum { kCntHits = 0, kCntChunk = 1, kCntSites = 2, kCntOverflow = 3, kCntVisited = 4, kCntPad = 5, kCntLost = 6, kCntSlots = 7 };
 
 // Required plane bits of the two PAM letters, expanded to all-ones / all-zero words.
 struct PamMasks {
@@ -90,8 +90,7 @@ struct SeedArgs {
     const uint2 *planes;           // [3 S] sites (x = hi plane | strand | edge, y = lo plane), bucket-sorted per segment
     const uint32_t *pos;           // [3 S] global window starts, same order
     const uint32_t *bucket_start;  // [kBuckets + 1] first site of every bucket
-    const uint32_t *chunk_start;   // [n_chunks] first site of the chunk
-    const uint32_t *chunk_bucket;  // [n_chunks]
+    const uint4 *chunk_tab;        // [n_chunks] {first site, site count, bucket, 0}
     uint32_t n_chunks;
     const uint4 *list_planes;      // padded per-bucket read lists: two reads per uint4 (hi0, lo0, hi1, lo1)
     const uint32_t *list_gid;      // read index of every list entry
@@ -102,7 +101,9 @@ struct SeedArgs {
     uint64_t *hit_keys;
     uint32_t *hit_vals;
     unsigned long long hit_cap;
-    unsigned long long *counters;  // kCntHits, kCntChunk, kCntSites (= pairs compared), kCntOverflow
+    uint32_t reserve;              // records a wave reserves per atomic on counters[kCntHits]
+    unsigned long long *counters;  // kCntHits (reserved records), kCntPad (sentinels among them), kCntChunk,
+                                   // kCntSites (= pairs compared), kCntVisited, kCntOverflow
 };
 
 // Launch wrappers implemented in vsc_kernels.hip.  They only enqueue work on `stream`.
@@ -127,7 +128,7 @@ hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_n
 hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted_gids, uint64_t n_pairs, uint32_t *off,
                              uint32_t *poff, const uint2 *guides, uint2 *list_planes, uint32_t *list_gid,
                              hipStream_t stream);
-hipError_t launch_seed_compare(const SeedArgs &args, int n_groups, hipStream_t stream);
+hipError_t launch_seed_compare(const SeedArgs &args, int n_groups, bool dense, hipStream_t stream);
 hipError_t merge_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
 hipError_t launch_merge(void *temp, size_t temp_bytes, const vsc_hit *in, uint64_t n, unsigned end_bit, uint32_t *keys_a,
                         uint32_t *keys_b, uint32_t *idx_a, uint32_t *idx_b, vsc_hit *out, hipStream_t stream);

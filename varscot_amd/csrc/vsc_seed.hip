@@ -200,24 +200,56 @@ struct SeedWave {
     uint64_t *hkey;  // resolved hits waiting for the global append
     uint32_t *hval;
     uint32_t ntok, hn, lane;
+    unsigned long long res_base;  // this wave's reserved range of the global hit arrays
+    uint32_t res_left;
 };
 
+// Moves the resolved hits of this wave to the global hit arrays.  A single device-wide cursor
+// sustains only ~90 atomics/us (MI355X_MICROARCH.md, "dequeue"), which at 1.6e9 hits and ~200 hits
+// per flush would cost as much as the whole comparison; so a wave reserves a block of a.reserve
+// records per atomic and fills it over several flushes.  What is left of the last block at the end
+// of the kernel is filled with sentinel keys that sort behind every real hit.
 __device__ __forceinline__ void seed_flush_hits(const SeedArgs &a, SeedWave &w)
 {
-    if (w.hn == 0) return;
-    unsigned long long base = 0;
-    if (w.lane == 0) base = atomicAdd(&a.counters[kCntHits], (unsigned long long)w.hn);
-    base = ((unsigned long long)uniform((uint32_t)(base >> 32)) << 32) | uniform((uint32_t)base);
-    if (base + w.hn <= a.hit_cap) {
-        for (uint32_t i = w.lane; i < w.hn; i += kWave) {
-            a.hit_keys[base + i] = w.hkey[i];
-            a.hit_vals[base + i] = w.hval[i];
+    uint32_t done = 0;
+    while (done < w.hn) {
+        if (w.res_left == 0) {
+            const uint32_t want = a.reserve ? a.reserve : w.hn - done;  // reserve == 0: exact appends
+            unsigned long long base = 0;
+            if (w.lane == 0) base = atomicAdd(&a.counters[kCntHits], (unsigned long long)want);
+            base = ((unsigned long long)uniform((uint32_t)(base >> 32)) << 32) | uniform((uint32_t)base);
+            if (base + want > a.hit_cap) {
+                // buffer too small: undo the reservation, count what is lost; the host re-runs with room
+                // for counters[kCntHits] + counters[kCntLost] records (+ one block per wave)
+                if (w.lane == 0) {
+                    atomicAdd(&a.counters[kCntHits], 0ull - (unsigned long long)want);
+                    atomicAdd(&a.counters[kCntLost], (unsigned long long)(w.hn - done));
+                    atomicMax(&a.counters[kCntOverflow], 1ull);
+                }
+                break;
+            }
+            w.res_base = base;
+            w.res_left = want;
         }
-    } else if (w.lane == 0) {
-        atomicMax(&a.counters[kCntOverflow], 1ull);
+        const uint32_t take = min(w.hn - done, w.res_left);
+        for (uint32_t i = w.lane; i < take; i += kWave) {
+            a.hit_keys[w.res_base + i] = w.hkey[done + i];
+            a.hit_vals[w.res_base + i] = w.hval[done + i];
+        }
+        w.res_base += take;
+        w.res_left -= take;
+        done += take;
     }
     wave_sync();
     w.hn = 0;
+}
+
+__device__ __forceinline__ void seed_finish_hits(const SeedArgs &a, SeedWave &w)
+{
+    seed_flush_hits(a, w);
+    for (uint32_t i = w.lane; i < w.res_left; i += kWave) a.hit_keys[w.res_base + i] = ~0ull;
+    if (w.lane == 0 && w.res_left) atomicAdd(&a.counters[kCntPad], (unsigned long long)w.res_left);
+    w.res_left = 0;
 }
 
 // Dense second half of the hit path: every lane resolves one pending token of the current chunk.
@@ -264,6 +296,25 @@ __device__ __forceinline__ void seed_resolve(const SeedArgs &a, SeedWave &w, uin
     w.ntok = 0;
 }
 
+// One chunk = at most kBatch sites of one bucket, to be compared with that bucket's read list.
+// chunk_tab[c] = {first site, site count, bucket, 0}; the bucket's read list is poff[bucket .. bucket+1).
+typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
+
+__device__ __forceinline__ void seed_load_sites(const SeedArgs &a, uint32_t first, uint32_t count, uint32_t lane,
+                                                uint2 (&v)[kSitesPerLane])
+{
+#pragma unroll
+    for (int j = 0; j < kSitesPerLane; ++j) {
+        const uint32_t idx = j * kWave + lane;
+        v[j] = make_uint2(0xFFFFFFFFu, 0u);  // empty slot: never matches (see process_batch)
+        if (idx < count) v[j] = a.planes[first + idx];
+    }
+}
+
+// kDense = false: one v_min3 tree + one test per four reads, hits (rare) re-derived in a slow path.
+// kDense = true : one test per (read, site slot); hits are appended where they are found.  Chosen by
+//                 the host when most iterations are expected to contain hits (m >= 7).
+template <bool kDense>
 __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(const SeedArgs a)
 {
     __shared__ uint64_t s_tok[kWavesPerGroup][kSeedTokCap];
@@ -278,10 +329,16 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(con
     w.hval = s_hval[wave];
     w.ntok = 0;
     w.hn = 0;
+    w.res_base = 0;
+    w.res_left = 0;
 
     const const_v4u_ptr gp = (const_v4u_ptr)(uintptr_t)a.list_planes;
     const uint32_t m = a.max_mm;
+    const uint32_t lane_bits = w.lane << 26;
     unsigned long long pairs = 0, visited = 0;
+
+    const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
+    const const_u32_ptr poff = (const_u32_ptr)(uintptr_t)a.poff;
 
     for (;;) {
         uint32_t first = 0;
@@ -289,48 +346,49 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(con
         first = uniform(first);
         if (first >= a.n_chunks) break;
         const uint32_t last = min(first + (uint32_t)kSeedGrab, a.n_chunks);
+        // Three-stage software pipeline over the chunks of this grab, all stages one chunk apart:
+        //   A  chunk table entry (scalar load)   B  its read-list bounds poff[bucket..] (scalar load)
+        //   C  its sites (vector loads, one HBM round trip per 4 KB)           then the comparison.
+        // Without it a wave idles for three dependent memory latencies per chunk.
+        v4u t0 = ctab[first];                           // chunk c     : A done
+        v4u t1 = ctab[min(first + 1, last - 1)];        // chunk c + 1 : A in flight
+        uint32_t p0a = poff[t0.z], p0b = poff[t0.z + 1];  // chunk c : B done
+        uint2 nv[kSitesPerLane];
+        if (p0a != p0b) seed_load_sites(a, t0.x, t0.y, w.lane, nv);  // chunk c : C in flight
+        uint32_t p1a = poff[t1.z], p1b = poff[t1.z + 1];  // chunk c + 1 : B in flight
+        v4u t2 = ctab[min(first + 2, last - 1)];         // chunk c + 2 : A in flight
         for (uint32_t c = first; c < last; ++c) {
-            const uint32_t bucket = uniform(a.chunk_bucket[c]);
-            const uint32_t g0 = uniform(a.poff[bucket]), g1 = uniform(a.poff[bucket + 1]);
-            if (g0 == g1) continue;  // no read has this bucket in its neighbourhood
-            const uint32_t st = uniform(a.chunk_start[c]);
-            const uint32_t cnt = min((uint32_t)kBatch, uniform(a.bucket_start[bucket + 1]) - st);
-            const uint32_t seg = bucket / kBucketsPerSeg;
+            struct {
+                uint32_t first, count, g0, g1, seg;
+            } cur = {t0.x, t0.y, p0a, p0b, t0.z / (uint32_t)kBucketsPerSeg};
             uint32_t sh[kSitesPerLane], sl[kSitesPerLane];
 #pragma unroll
             for (int j = 0; j < kSitesPerLane; ++j) {
-                const uint32_t idx = j * kWave + w.lane;
-                uint2 v = make_uint2(0xFFFFFFFFu, 0u);  // empty slot: never matches (see process_batch)
-                if (idx < cnt) v = a.planes[st + idx];
-                sh[j] = idx < cnt ? (v.x & kMask23) : 0xFFFFFFFFu;
-                sl[j] = v.y;
+                sh[j] = nv[j].x == 0xFFFFFFFFu ? 0xFFFFFFFFu : (nv[j].x & kMask23);
+                sl[j] = nv[j].y;
             }
-            pairs += (unsigned long long)cnt * (g1 - g0);
-            visited += cnt;
-            v4u na = gp[g0 >> 1], nb = gp[(g0 >> 1) + 1];
-            for (uint32_t g = g0; g < g1; g += kGuideUnroll) {
+            // advance the pipeline before the comparison so that its loads overlap it
+            t0 = t1;
+            p0a = p1a;
+            p0b = p1b;
+            if (c + 1 < last && p0a != p0b) seed_load_sites(a, t0.x, t0.y, w.lane, nv);
+            t1 = t2;
+            p1a = poff[t1.z];
+            p1b = poff[t1.z + 1];
+            t2 = ctab[min(c + 3, last - 1)];
+            if (cur.g0 == cur.g1) continue;  // no read has this bucket in its neighbourhood
+            pairs += (unsigned long long)cur.count * (cur.g1 - cur.g0);
+            visited += cur.count;
+            v4u na = gp[cur.g0 >> 1], nb = gp[(cur.g0 >> 1) + 1];
+            for (uint32_t g = cur.g0; g < cur.g1; g += kGuideUnroll) {
                 const v4u ga = na, gb = nb;
                 na = gp[(g >> 1) + 2];  // the list is allocated with one spare group
                 nb = gp[(g >> 1) + 3];
                 const uint32_t gh[kGuideUnroll] = {ga.x, ga.z, gb.x, gb.z};
                 const uint32_t gl[kGuideUnroll] = {ga.y, ga.w, gb.y, gb.w};
-                uint32_t best[kGuideUnroll];
-#pragma unroll
-                for (int u = 0; u < kGuideUnroll; ++u) {
-                    uint32_t cm = 32;
-#pragma unroll
-                    for (int j = 0; j < kSitesPerLane; ++j) {
-                        const uint32_t t = (sh[j] ^ gh[u]) | (sl[j] ^ gl[u]);
-                        cm = min(cm, (uint32_t)__popc(t));
-                    }
-                    best[u] = cm;
-                }
-                const uint32_t any = min(min(best[0], best[1]), min(best[2], best[3]));
-                if (__ballot(any <= m) != 0) {
-                    // sparse first half of the hit path: one 8-byte token per hit into LDS
+                if (kDense) {
 #pragma unroll
                     for (int u = 0; u < kGuideUnroll; ++u) {
-                        if (__ballot(best[u] <= m) == 0) continue;
 #pragma unroll
                         for (int j = 0; j < kSitesPerLane; ++j) {
                             const uint32_t t = (sh[j] ^ gh[u]) | (sl[j] ^ gl[u]);
@@ -338,27 +396,60 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(con
                             const uint64_t b = __ballot(hit);
                             if (b == 0) continue;
                             if (hit)
-                                w.tok[w.ntok + lanes_below(b)] =
-                                    ((uint64_t)(g + u) << 32) | (w.lane << 26) | ((uint32_t)j << 23) | t;
+                                w.tok[w.ntok + lanes_below(b)] = ((uint64_t)(g + u) << 32) | lane_bits | ((uint32_t)j << 23) | t;
                             w.ntok += (uint32_t)__popcll(b);
-                            if (w.ntok > kSeedTokCap - kWave) seed_resolve(a, w, st, seg);
+                            if (w.ntok > kSeedTokCap - kWave) seed_resolve(a, w, cur.first, cur.seg);
+                        }
+                    }
+                } else {
+                    uint32_t best[kGuideUnroll];
+#pragma unroll
+                    for (int u = 0; u < kGuideUnroll; ++u) {
+                        uint32_t cm = 32;
+#pragma unroll
+                        for (int j = 0; j < kSitesPerLane; ++j) {
+                            const uint32_t t = (sh[j] ^ gh[u]) | (sl[j] ^ gl[u]);
+                            cm = min(cm, (uint32_t)__popc(t));
+                        }
+                        best[u] = cm;
+                    }
+                    const uint32_t any = min(min(best[0], best[1]), min(best[2], best[3]));
+                    if (__ballot(any <= m) != 0) {
+                        // sparse first half of the hit path: one 8-byte token per hit into LDS
+#pragma unroll
+                        for (int u = 0; u < kGuideUnroll; ++u) {
+                            if (__ballot(best[u] <= m) == 0) continue;
+#pragma unroll
+                            for (int j = 0; j < kSitesPerLane; ++j) {
+                                const uint32_t t = (sh[j] ^ gh[u]) | (sl[j] ^ gl[u]);
+                                const bool hit = (uint32_t)__popc(t) <= m;
+                                const uint64_t b = __ballot(hit);
+                                if (b == 0) continue;
+                                if (hit)
+                                    w.tok[w.ntok + lanes_below(b)] = ((uint64_t)(g + u) << 32) | lane_bits | ((uint32_t)j << 23) | t;
+                                w.ntok += (uint32_t)__popcll(b);
+                                if (w.ntok > kSeedTokCap - kWave) seed_resolve(a, w, cur.first, cur.seg);
+                            }
                         }
                     }
                 }
             }
-            if (w.ntok) seed_resolve(a, w, st, seg);
+            if (w.ntok) seed_resolve(a, w, cur.first, cur.seg);
         }
     }
-    seed_flush_hits(a, w);
+    seed_finish_hits(a, w);
     if (w.lane == 0 && pairs) {
         atomicAdd(&a.counters[kCntSites], pairs);
         atomicAdd(&a.counters[kCntVisited], visited);
     }
 }
 
-hipError_t launch_seed_compare(const SeedArgs &args, int n_groups, hipStream_t stream)
+hipError_t launch_seed_compare(const SeedArgs &args, int n_groups, bool dense, hipStream_t stream)
 {
-    hipLaunchKernelGGL(seed_compare_kernel, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
+    if (dense)
+        hipLaunchKernelGGL(seed_compare_kernel<true>, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
+    else
+        hipLaunchKernelGGL(seed_compare_kernel<false>, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
     return hipGetLastError();
 }
 
