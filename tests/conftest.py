@@ -14,6 +14,7 @@ def _ensure_built():
     need = [os.path.join(ROOT, "varscot_amd", "libvarscot_hip.so"),
             os.path.join(ROOT, "varscot_amd", "bin", "bidir_index"),
             os.path.join(ROOT, "varscot_amd", "bin", "bidir_mapping"),
+            os.path.join(ROOT, "varscot_amd", "bin", "vcf_loader"),
             os.path.join(ROOT, "oracle", "libvsc_oracle.so")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__

@@ -1,0 +1,121 @@
+"""Alt-allele expansion (row R8): the C++ `vcf_loader` drop-in against the pure-Python restatement of
+variant_processing/{process_vcf,overlap_sequences,write_fasta}.h on seeded synthetic VCFs."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import random_seq
+from oracle import variants_oracle as vo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "varscot_amd", "bin", "vcf_loader")
+
+
+def synth_vcf(seed, genome, n_records, n_samples=2, header_contigs=None, indel_rate=0.3, cluster=True):
+    rng = np.random.default_rng(seed)
+    names = list(genome)
+    lines = ["##fileformat=VCFv4.2"]
+    for c in header_contigs or []:
+        lines.append("##contig=<ID=%s,length=%d>" % (c, len(genome[c])))
+    lines.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join("S%d" % i for i in range(n_samples)))
+    gts = ["0|1", "1|0", "1|1", "0/1", "1/1", "0|0", "./.", "1|2", "2|1", "1/2", "0|2", "1", ".|1", "1|.", "2/2"]
+    recs = []
+    for _ in range(n_records):
+        c = names[int(rng.integers(0, len(names)))]
+        L = len(genome[c])
+        if cluster and recs and rng.random() < 0.5 and recs[-1][0] == c:
+            pos = min(L - 12, recs[-1][1] + int(rng.integers(1, 30)))  # chains of nearby variants
+        else:
+            pos = int(rng.integers(1, L - 12))
+        kind = rng.random()
+        ref = genome[c][pos - 1]
+        if ref == "N":
+            continue
+        def other(b):
+            return rng.choice([x for x in "ACGT" if x != b])
+        if kind < indel_rate / 2:      # deletion
+            ln = int(rng.integers(1, 9))
+            r, a = genome[c][pos - 1:pos + ln], ref
+        elif kind < indel_rate:        # insertion
+            r, a = ref, ref + random_seq(rng, int(rng.integers(1, 7)))
+        else:
+            r, a = ref, other(ref)
+        alts = [a]
+        if rng.random() < 0.25:        # second alt allele
+            alts.append(r[0] + random_seq(rng, int(rng.integers(1, 4))) if rng.random() < 0.5 else other(r[0]))
+        if rng.random() < 0.03:
+            alts[0] = "."
+        fmt = "GT:DP" if rng.random() < 0.7 else "DP:GT"
+        cols = []
+        for _s in range(n_samples):
+            gt = gts[int(rng.integers(0, len(gts)))]
+            if len(alts) == 1:
+                gt = gt.replace("2", "1")
+            cols.append(gt + ":7" if fmt == "GT:DP" else "7:" + gt)
+        recs.append((c, pos, "%s\t%d\t.\t%s\t%s\t.\tPASS\t.\t%s\t%s" % (c, pos, r, ",".join(alts), fmt, "\t".join(cols))))
+    order = rng.permutation(len(recs))  # the sweep sorts by position itself
+    lines += [recs[i][2] for i in order]
+    return "\n".join(lines) + "\n"
+
+
+def run_tool(tmp_path, vcf_text, genome, sample):
+    (tmp_path / "in.vcf").write_text(vcf_text)
+    with open(tmp_path / "genome.fa", "w") as f:
+        for name, seq in genome.items():
+            f.write(">%s some description\n" % name)
+            for i in range(0, len(seq), 60):
+                f.write(seq[i:i + 60] + "\n")
+    r = subprocess.run([BIN, str(tmp_path / "in.vcf"), str(tmp_path / "snp.fa"), str(tmp_path / "genome.fa"), str(sample),
+                        "23", "2"], capture_output=True, text=True, timeout=300)
+    return r, (tmp_path / "snp.fa").read_text() if (tmp_path / "snp.fa").exists() else None
+
+
+@pytest.mark.parametrize("seed,sample,indel_rate", [(1, 0, 0.0), (2, 1, 0.0), (3, 0, 0.3), (4, 1, 0.5), (5, 0, 0.8), (6, 0, 0.3)])
+def test_vcf_loader_matches_restatement(tmp_path, seed, sample, indel_rate):
+    rng = np.random.default_rng(1000 + seed)
+    genome = {"chr1": random_seq(rng, 4000), "chr2": random_seq(rng, 2500), "chrUn_x": random_seq(rng, 600)}
+    genome["chr2"] = genome["chr2"][:700] + "N" * 40 + genome["chr2"][740:]
+    vcf = synth_vcf(seed, genome, 260, header_contigs=["chr2", "chr1"] if seed % 2 else None, indel_rate=indel_rate)
+    r, got = run_tool(tmp_path, vcf, genome, sample)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.splitlines() == ["Process records", "Compute overlap sequences", "Write fasta"]
+    want = vo.format_fasta(vo.vcf_loader(vcf, genome, sample, 23))
+    assert got.count(">") > 100
+    assert got == want
+
+
+def test_isolated_snp_window_and_ids(tmp_path):
+    """An isolated SNP gives the 45-base window [pos-22, pos+23) in a REF and an ALT version
+    (SURVEY.md 8.3); ids are chr_start_REF / chr_start_ALT_pos_ref_alt with 0-based positions."""
+    rng = np.random.default_rng(9)
+    genome = {"chrA": random_seq(rng, 300)}
+    ref = genome["chrA"][99]
+    alt = "A" if ref != "A" else "C"
+    vcf = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\nchrA\t100\t.\t%s\t%s\t.\t.\t.\tGT\t0|1\n" % (ref, alt)
+    r, got = run_tool(tmp_path, vcf, genome, 0)
+    assert r.returncode == 0
+    w = genome["chrA"][77:122]
+    assert got == ">chrA_77_REF\n%s\n>chrA_77_ALT_99_%s_%s\n%s\n" % (w, ref, alt, w[:22] + alt + w[23:])
+
+
+def test_variant_near_contig_start_wraps_like_the_reference(tmp_path):
+    rng = np.random.default_rng(10)
+    genome = {"c": random_seq(rng, 200)}
+    ref = genome["c"][4]
+    alt = "G" if ref != "G" else "T"
+    vcf = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\nc\t5\t.\t%s\t%s\t.\t.\t.\tGT\t1|1\n" % (ref, alt)
+    r, got = run_tool(tmp_path, vcf, genome, 0)
+    want = vo.format_fasta(vo.vcf_loader(vcf, genome, 0, 23))
+    assert r.returncode == 0 and got == want
+    assert got.startswith(">c_%d_ALT_4_" % ((4 - 23 + 1) % (1 << 32)))  # unsigned start, overlap_sequences.h:158
+
+
+def test_cli_errors(tmp_path):
+    assert subprocess.run([BIN], capture_output=True).returncode == 1
+    r = subprocess.run([BIN, "a.vcf", "o.fa", "g.fa", "x", "23", "1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Cannot cast x into an unsigned" in r.stderr
+    r = subprocess.run([BIN, str(tmp_path / "missing.vcf"), str(tmp_path / "o.fa"), str(tmp_path / "g.fa"), "0", "23", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1
