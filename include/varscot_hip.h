@@ -209,6 +209,15 @@ int vsc_score_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits,
                    uint32_t n_guides, uint64_t first, uint64_t count, double *mit, uint8_t *mit_flags,
                    uint8_t *features);
 #define VSC_N_FEATURES 442
+/*
+ * The same scores for n explicit (on-target, off-target) pairs: both 23-mers as vsc_pack_guide codes
+ * in read orientation, masks[i] = the mismatch positions calcMitScore is given for row i (bit p =
+ * position p).  This is the form the mergers need: they score what they re-derived from the SAM
+ * records (variant_processing/merge_output_bam.h:156,187,389,437,549,696), where the positions
+ * come from the MD tag (filter_output_bam.h:330-349) and the sequences from the FASTA (:399,484).
+ */
+int vsc_score_pairs(vsc_ctx *ctx, const uint64_t *on_targets, const uint64_t *off_targets, const uint32_t *masks,
+                    uint64_t n, double *mit, uint8_t *mit_flags, uint8_t *features);
 
 /* ---- host-side formatting helpers (no device needed) ------------------------------------------ */
 /*

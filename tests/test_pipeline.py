@@ -1,0 +1,144 @@
+"""End-to-end drop-in pipeline on the GPU box: bidir_index -> bidir_mapping (reference and SNP
+genome) -> vcf_loader -> bam_merger_ref_only / bam_merger, every stage's text output compared with
+the oracle's restatement of the reference stage."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import mutate, random_seq, revcomp
+from oracle import merge_oracle as mo
+from oracle import variants_oracle as vo
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "varscot_amd", "bin")
+
+
+def run(tool, *args):
+    r = subprocess.run([os.path.join(BIN, tool)] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (tool, r.stdout, r.stderr)
+    return r
+
+
+def write_fasta(path, records):
+    with open(path, "w") as f:
+        for name, seq in records:
+            f.write(">%s\n" % name)
+            for i in range(0, len(seq), 60):
+                f.write(seq[i:i + 60] + "\n")
+
+
+def read_fasta(path):
+    recs, name = [], None
+    for line in open(path):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            name = line[1:]
+            recs.append([name, ""])
+        elif line:
+            recs[-1][1] += line
+    return [(a, b) for a, b in recs]
+
+
+@pytest.fixture(scope="module")
+def scenario(tmp_path_factory):
+    d = tmp_path_factory.mktemp("pipeline")
+    rng = np.random.default_rng(20240)
+    contigs = {"chr1": random_seq(rng, 30000), "chr2": random_seq(rng, 18000), "chrM": random_seq(rng, 3000)}
+    # on-targets: 23-mers ending in GG taken from the genome (forward) or placed as reverse complement
+    targets = []
+    for i, (c, p, strand) in enumerate([("chr1", 5000, "+"), ("chr1", 12000, "-"), ("chr2", 3000, "+"),
+                                        ("chr2", 9000, "-"), ("chr1", 20000, "+")]):
+        g = random_seq(rng, 21) + "GG"
+        site = g if strand == "+" else revcomp(g)
+        s = contigs[c]
+        contigs[c] = s[:p] + site + s[p + 23:]
+        targets.append(("site%d" % i, c, p, strand, g))
+    # off-targets: mutated copies, some of them next to variants
+    planted = []
+    for k in range(60):
+        name, c0, p0, st0, g = targets[k % len(targets)]
+        c = ["chr1", "chr2", "chrM"][k % 3]
+        p = 200 + 400 * k % (len(contigs[c]) - 300)
+        site = mutate(rng, g, int(rng.integers(0, 5)), 0, 20)
+        if k % 2:
+            site = revcomp(site)
+        s = contigs[c]
+        if any(c == tc and abs(p - tp) < 60 for _, tc, tp, _, _ in targets):
+            continue
+        contigs[c] = s[:p] + site + s[p + 23:]
+        planted.append((c, p))
+    # variants: SNPs and small indels inside / next to planted sites
+    vcf = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS0"]
+    gts = ["0|1", "1|0", "1|1", "0/1"]
+    used = set()
+    for k, (c, p) in enumerate(planted[:40]):
+        q = p + int(rng.integers(-5, 30))
+        if q < 30 or q > len(contigs[c]) - 40 or any(abs(q - u) < 3 and uc == c for uc, u in used):
+            continue
+        used.add((c, q))
+        ref = contigs[c][q]
+        kind = k % 5
+        if kind == 3:
+            r, a = contigs[c][q:q + 3], ref              # deletion of 2
+        elif kind == 4:
+            r, a = ref, ref + random_seq(rng, 2)         # insertion of 2
+        else:
+            r, a = ref, [x for x in "ACGT" if x != ref][k % 3]
+        vcf.append("%s\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT\t%s" % (c, q + 1, r, a, gts[k % 4]))
+    records = [(n, s) for n, s in contigs.items()]
+    write_fasta(d / "genome.fa", records)
+    (d / "in.vcf").write_text("\n".join(vcf) + "\n")
+    bed = "".join("%s\t%d\t%d\t%s\t7\t%s\n" % (c, p, p + 23, name, strand) for name, c, p, strand, g in targets)
+    (d / "targets.bed").write_text(bed)
+    write_fasta(d / "targets.fa", [(name, g) for name, c, p, strand, g in targets])
+    tus = "ID   Sequence   Score   Dir\n" + "".join("%s %s %.6f +\n" % (name, "A" * 30, 0.5 + 0.25 * i)
+                                                    for i, (name, *_r) in enumerate(targets))
+    (d / "activity.txt").write_text(tus)
+    return d, records, bed, tus, targets
+
+
+def test_reference_only_pipeline(scenario):
+    d, records, bed, tus, targets = scenario
+    run("bidir_index", "-G", d / "genome.fa", "-I", d / "ref_idx")
+    run("bidir_mapping", "-G", d / "genome.fa", "-I", d / "ref_idx", "-R", d / "targets.fa", "-M", 5, "-O", d / "ref.sam")
+    sam = (d / "ref.sam").read_text()
+    assert len(sam.splitlines()) > 30
+    for mit in (0, 1):
+        run("bam_merger_ref_only", d / "out.txt", d / "feat.txt", d / "ref.sam", d / "targets.bed", d / "genome.fa",
+            d / "activity.txt", 5, 23, mit)
+        want_tsv, want_fm = mo.process_ref_only(sam, bed, records, tus, bool(mit))
+        assert (d / "out.txt").read_text() == want_tsv
+        if mit:
+            assert (d / "feat.txt").read_text() == want_fm
+    # the on-target loci themselves are not reported
+    tsv = (d / "out.txt").read_text().splitlines()[1:]
+    for name, c, p, strand, g in targets:
+        assert not any(l.split("\t")[0] == c and int(l.split("\t")[1]) == p and l.split("\t")[3].startswith(name + "_")
+                       and l.split("\t")[7] == "0" for l in tsv)
+
+
+def test_variant_aware_pipeline(scenario):
+    d, records, bed, tus, targets = scenario
+    run("vcf_loader", d / "in.vcf", d / "snp.fa", d / "genome.fa", 0, 23, 4)
+    genome = dict(records)
+    assert (d / "snp.fa").read_text() == vo.format_fasta(vo.vcf_loader((d / "in.vcf").read_text(), genome, 0, 23))
+    snp_records = read_fasta(d / "snp.fa")
+    assert len(snp_records) > 20
+    run("bidir_index", "-G", d / "genome.fa", "-I", d / "ref_idx")
+    run("bidir_mapping", "-G", d / "genome.fa", "-I", d / "ref_idx", "-R", d / "targets.fa", "-M", 5, "-O", d / "ref.sam")
+    run("bidir_index", "-G", d / "snp.fa", "-I", d / "snp_idx")
+    run("bidir_mapping", "-G", d / "snp.fa", "-I", d / "snp_idx", "-R", d / "targets.fa", "-M", 5, "-O", d / "snp.sam")
+    ref_sam, snp_sam = (d / "ref.sam").read_text(), (d / "snp.sam").read_text()
+    assert len(snp_sam.splitlines()) > 10
+    for mit in (0, 1):
+        run("bam_merger", d / "merged.txt", d / "mfeat.txt", d / "ref.sam", d / "snp.sam", d / "targets.bed", d / "genome.fa",
+            d / "snp.fa", d / "activity.txt", 5, 23, 4, mit)
+        want_tsv, want_fm = mo.merge_results(ref_sam, snp_sam, bed, records, snp_records, tus, 23, bool(mit))
+        assert (d / "merged.txt").read_text() == want_tsv
+        if mit:
+            assert (d / "mfeat.txt").read_text() == want_fm
+    rows = (d / "merged.txt").read_text().splitlines()[1:]
+    assert any(r.split("\t")[-1].startswith("VAR_") for r in rows) and any(r.split("\t")[-1] == "REF" for r in rows)

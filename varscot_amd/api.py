@@ -113,6 +113,19 @@ class Context:
     def load_genome(self, packed, rank=0, world=1):
         return Genome(self, packed, rank, world)
 
+    def score_pairs(self, on_targets, off_targets, masks, mit=True, features=False):
+        """vsc_score_pairs: MIT score / feature rows of explicit (on-target, off-target) 23-mer pairs."""
+        on = np.ascontiguousarray(on_targets if isinstance(on_targets, np.ndarray) else pack_guides(on_targets), dtype=np.uint64)
+        off = np.ascontiguousarray(off_targets if isinstance(off_targets, np.ndarray) else pack_guides(off_targets), dtype=np.uint64)
+        mk = np.ascontiguousarray(masks, dtype=np.uint32)
+        n = len(on)
+        assert len(off) == n and len(mk) == n
+        m = np.empty(n, dtype=np.float64) if mit else None
+        fl = np.empty(n, dtype=np.uint8) if mit else None
+        ft = np.empty((n, N_FEATURES), dtype=np.uint8) if features else None
+        check(lib().vsc_score_pairs(self._h, ptr(on), ptr(off), ptr(mk), n, ptr(m), ptr(fl), ptr(ft)), self._h)
+        return m, fl, ft
+
 
 class Genome:
     """(A shard of) a packed genome resident in HBM (vsc_genome)."""

@@ -1,0 +1,364 @@
+// merge_host.hpp - host side of the result mergers: SAM records -> potential off-targets, on-target /
+// variant-window filters, TSV + feature-matrix text.  Semantics follow
+// VARSCOT_pipeline/variant_processing/filter_output_bam.h:40-496 and merge_output_bam.h:46-720.
+// Scores come from the GPU library (vsc_score_pairs); nothing is scored on the host.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "varscot_hip.h"
+#include "vsc_host.hpp"
+
+namespace vsc_merge {
+
+struct OffTarget {  // PotentialOffTarget, filter_output_bam.h:28-37
+    std::string chr, target, snp_type, sequence;
+    std::vector<int> mm;  // mismatch positions, {-1} for a perfect match
+    uint32_t pos = 0;
+    char strand = '+';
+};
+
+inline bool same(const OffTarget &a, const OffTarget &b)  // comp(), :40-49
+{
+    return a.target == b.target && a.chr == b.chr && a.pos == b.pos && a.strand == b.strand && a.sequence == b.sequence &&
+           a.mm == b.mm && a.snp_type == b.snp_type;
+}
+
+// Sequences of a FASTA addressable by full id and by first word (FAI rule).
+struct Genome {
+    std::vector<vsc_host::FastaRecord> recs;
+    std::unordered_map<std::string, size_t> by_name;
+    explicit Genome(const std::string &path) : recs(vsc_host::read_fasta(path))
+    {
+        for (size_t i = 0; i < recs.size(); ++i) {
+            by_name.emplace(recs[i].id, i);
+            by_name.emplace(recs[i].id.substr(0, recs[i].id.find_first_of(" \t")), i);
+        }
+    }
+    // extractSequenceFromIndex(..., flanking = false), extract_fasta_ontargets.h:33-76
+    std::string region(const std::string &chr, uint32_t start, uint32_t end, char strand) const
+    {
+        auto it = by_name.find(chr);
+        if (it == by_name.end()) throw std::out_of_range("ERROR: Index out of range.");
+        const std::string &s = recs[it->second].seq;
+        uint64_t b = std::min<uint64_t>(start, s.size()), e = std::min<uint64_t>(end, s.size());
+        if (b > e) e = b;
+        std::string out = s.substr(b, e - b);
+        for (auto &c : out) {
+            switch (c) {
+            case 'A': case 'a': c = 'A'; break;
+            case 'C': case 'c': c = 'C'; break;
+            case 'G': case 'g': c = 'G'; break;
+            case 'T': case 't': c = 'T'; break;
+            default: c = 'N';
+            }
+        }
+        if (strand == '-') {
+            std::reverse(out.begin(), out.end());
+            for (auto &c : out) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+        }
+        return out;
+    }
+};
+
+// getMismatchPositions, filter_output_bam.h:330-349: while (is >> num >> base) pos += num + 1
+inline std::vector<int> md_positions(const std::string &md)
+{
+    std::vector<int> out;
+    std::istringstream is(md);
+    unsigned num = 0, pos = 0;
+    char base = 0;
+    while (is >> num >> base) {
+        pos += num + 1;
+        out.push_back((int)pos - 1);
+    }
+    if (out.empty()) out.push_back(-1);
+    return out;
+}
+
+// readBamFile, filter_output_bam.h:362-418 (header-less SAM text as bidir_mapping writes it)
+inline std::vector<OffTarget> read_sam(const std::string &path, const Genome &genome)
+{
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("ERROR: Could not open BAM file.");
+    std::vector<OffTarget> out;
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.empty() || line[0] == '@') continue;
+        std::vector<std::string> f;
+        size_t b = 0;
+        for (;;) {
+            size_t e = line.find('\t', b);
+            f.push_back(line.substr(b, e == std::string::npos ? std::string::npos : e - b));
+            if (e == std::string::npos) break;
+            b = e + 1;
+        }
+        if (f.size() < 11) continue;
+        OffTarget p;
+        p.target = f[0];
+        p.chr = f[2];
+        p.pos = (uint32_t)(std::strtoul(f[3].c_str(), nullptr, 10) - 1);
+        p.strand = (std::strtoul(f[1].c_str(), nullptr, 10) & 16u) ? '-' : '+';
+        p.sequence = genome.region(p.chr, p.pos, p.pos + 23, p.strand);
+        p.snp_type = "REF";
+        std::string md;
+        for (size_t i = 11; i < f.size(); ++i)
+            if (f[i].compare(0, 5, "MD:Z:") == 0) md = f[i].substr(5);
+        p.mm = md_positions(md);
+        out.push_back(std::move(p));
+    }
+    return out;
+}
+
+// readOntargets, filter_output_bam.h:462-496 (BED6)
+inline void read_ontargets(const std::string &path, const Genome &genome, std::map<std::string, OffTarget> &on,
+                           std::map<std::string, unsigned> &count)
+{
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("ERROR: Could not open BED file.");
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream is(line);
+        std::string chr, name, score, strand;
+        unsigned long start = 0, end = 0;
+        if (!(is >> chr >> start >> end >> name >> score >> strand)) continue;
+        OffTarget p;
+        p.target = name;
+        p.chr = chr;
+        p.pos = (uint32_t)start;
+        p.strand = strand.empty() ? '+' : strand[0];
+        p.sequence = genome.region(chr, p.pos, p.pos + 23, p.strand);
+        p.mm = {-1};
+        p.snp_type = "REF";
+        on.emplace(name, p);
+        count.emplace(name, 0u);
+    }
+}
+
+// readTuscanResult, feature_matrix.h:206-230
+inline std::map<std::string, double> read_tuscan(const std::string &path)
+{
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("ERROR: Could not open on-target activity file.");
+    std::map<std::string, double> out;
+    std::string line, target, sequence;
+    double score;
+    while (std::getline(in, line)) {
+        std::istringstream is(line);
+        if (is >> target >> sequence >> score) out.emplace(target, score);
+    }
+    return out;
+}
+
+inline int c_atoi(const std::string &s) { return (int)std::strtol(s.c_str(), nullptr, 10); }
+
+inline std::vector<std::string> split_id(const std::string &id)
+{
+    std::vector<std::string> out;
+    size_t b = 0;
+    for (;;) {
+        size_t e = id.find('_', b);
+        out.push_back(id.substr(b, e == std::string::npos ? std::string::npos : e - b));
+        if (e == std::string::npos) break;
+        b = e + 1;
+    }
+    return out;
+}
+
+// Variant windows per chromosome for the shadow filter (filterRefAlignment, :70-124): a reference hit
+// is dropped if it lies fully inside any window of its chromosome.  The reference scans all windows
+// per hit; here windows are sorted by start with a running maximum of their ends.
+struct WindowIndex {
+    struct Chr {
+        std::vector<int64_t> start, max_end;
+    };
+    std::unordered_map<std::string, Chr> chrs;
+    explicit WindowIndex(const std::vector<vsc_host::FastaRecord> &snp)
+    {
+        std::unordered_map<std::string, std::vector<std::pair<int64_t, int64_t>>> tmp;
+        for (const auto &r : snp) {
+            const auto parts = split_id(r.id);
+            if (parts.size() < 2) continue;
+            const int s = c_atoi(parts[1]);
+            // `pos >= atoi(start)` (:102) compares unsigned with int: a negative start (a window whose
+            // start wrapped around the contig start) is huge as unsigned and never <= pos
+            if (s < 0) continue;
+            tmp[parts[0]].push_back({(int64_t)s, (int64_t)s + (int64_t)r.seq.size()});
+        }
+        for (auto &kv : tmp) {
+            std::sort(kv.second.begin(), kv.second.end());
+            Chr c;
+            int64_t m = INT64_MIN;
+            for (auto &w : kv.second) {
+                m = std::max(m, w.second);
+                c.start.push_back(w.first);
+                c.max_end.push_back(m);
+            }
+            chrs.emplace(kv.first, std::move(c));
+        }
+    }
+    bool shadows(const std::string &chr, uint32_t pos, unsigned seq_len) const
+    {
+        auto it = chrs.find(chr);
+        if (it == chrs.end()) return false;
+        const auto &c = it->second;
+        const size_t n = std::upper_bound(c.start.begin(), c.start.end(), (int64_t)pos) - c.start.begin();
+        return n > 0 && (int64_t)pos + seq_len <= c.max_end[n - 1];
+    }
+};
+
+// getSnpType, filter_output_bam.h:189-263
+inline void snp_type(std::string &type, const std::vector<std::string> &id, uint32_t &pos, unsigned seq_len)
+{
+    std::string tag = "VAR_" + id[0] + "_";
+    bool any = false, start_found = false;
+    int count = 0;
+    for (size_t i = 3; i + 2 < id.size(); i += 3) {
+        const int p = c_atoi(id[i]);
+        const size_t lr = id[i + 1].size(), la = id[i + 2].size();
+        auto inside = [&](long q) { return (long)pos <= q && (long)pos + (long)seq_len > q; };
+        if (lr == la) {
+            if (inside(p)) {
+                tag += id[i] + ",";
+                any = start_found = true;
+            }
+        } else if (lr < la) {
+            if (inside((long)p + 1) || inside((long)p + (long)la - 1)) {
+                tag += id[i] + ",";
+                any = start_found = true;
+            } else if (!start_found) {
+                count -= (int)(la - lr);
+            }
+        } else {
+            if (inside((long)p + 1) || inside((long)p + (long)lr - 1)) {
+                tag += id[i] + ",";
+                any = start_found = true;
+            } else if (!start_found) {
+                count += (int)(lr - la);
+            }
+        }
+    }
+    pos += (uint32_t)count;
+    if (any) type = tag.substr(0, tag.size() - 1);
+}
+
+inline std::string mm_columns(const OffTarget &p, bool merged)
+{
+    std::string s;
+    if (p.mm.size() == 1 && p.mm[0] == -1) return merged ? "0\t\t" : "0\t";
+    s = std::to_string(p.mm.size()) + "\t";
+    for (size_t j = 0; j + 1 < p.mm.size(); ++j) s += std::to_string(p.mm[j]) + ",";
+    s += std::to_string(p.mm.back());
+    if (merged) s += "\t";
+    return s;
+}
+
+inline uint32_t mm_mask(const OffTarget &p)
+{
+    uint32_t m = 0;
+    for (int q : p.mm)
+        if (q >= 0 && q < 32) m |= 1u << q;
+    return m;
+}
+
+inline std::string fmt_double(double v)  // operator<<(ostream, double) with default precision
+{
+    std::ostringstream os;
+    os << v;
+    return os.str();
+}
+
+// getFeatureNames, feature_matrix.h:140-204
+inline std::vector<std::string> feature_names()
+{
+    static const char *types[12] = {"AtoC", "AtoG", "AtoT", "CtoA", "CtoG", "CtoT", "GtoA", "GtoC", "GtoT", "TtoA", "TtoC", "TtoG"};
+    static const char *letters[4] = {"A", "C", "G", "T"};
+    std::vector<std::string> n(443);
+    n[0] = "totalMismatches";
+    for (int i = 1; i < 22; ++i) n[i] = "mismatchPos" + std::to_string(i);
+    for (int i = 0; i < 12; ++i) n[22 + i] = types[i];
+    n[34] = "transitionNumber";
+    n[35] = "transversionNumber";
+    for (int i = 1; i < 21; ++i)
+        for (int j = 0; j < 4; ++j) n[36 + (i - 1) * 4 + j] = std::string(letters[j]) + std::to_string(i);
+    n[116] = "PAMA", n[117] = "PAMC", n[118] = "PAMG", n[119] = "PAMT";
+    for (int i = 1; i < 20; ++i)
+        for (int j = 0; j < 16; ++j) n[120 + (i - 1) * 16 + j] = std::string(letters[j / 4]) + letters[j % 4] + std::to_string(i);
+    for (int j = 0; j < 16; ++j) n[424 + j] = std::string(letters[j / 4]) + letters[j % 4];
+    n[440] = "adjacentMismatches";
+    n[441] = "seedMismatches";
+    n[442] = "ontargetActivity";
+    return n;
+}
+
+// Scores rows on the GPU and writes TSV (+ feature matrix) text.  `merged` selects the 10-column
+// layout of mergeResults (Variants column) over the 9-column one of processRefOnly.
+inline void write_outputs(const std::string &out_path, const std::string *feature_path, bool merged,
+                          const std::vector<const OffTarget *> &rows, const std::map<std::string, OffTarget> &on,
+                          std::map<std::string, unsigned> &count, const std::map<std::string, double> &activity, int device)
+{
+    std::ofstream out(out_path);
+    std::ofstream fout;
+    if (feature_path) fout.open(*feature_path);
+    if (!out.is_open() || (feature_path && !fout.is_open())) throw std::runtime_error("ERROR: Could not open output file.");
+    out << "#Chr\tStart\tEnd\tTargetsite\tScore\tStrand\tSequence\tMismatch_Number\tMismatch_Positions" << (merged ? "\tVariants\n" : "\n");
+    if (feature_path) {
+        const auto names = feature_names();
+        for (size_t i = 0; i + 1 < names.size(); ++i) fout << names[i] << "\t";
+        fout << names.back() << "\n";
+    }
+    const size_t n = rows.size();
+    std::vector<double> mit(n);
+    std::vector<uint8_t> feat(feature_path ? n * VSC_N_FEATURES : 0);
+    if (n) {
+        std::vector<uint64_t> on_codes(n), off_codes(n);
+        std::vector<uint32_t> masks(n);
+        for (size_t i = 0; i < n; ++i) {
+            const OffTarget &p = *rows[i];
+            const OffTarget &t = on.at(p.target);
+            if (feature_path && (t.sequence.size() != VSC_READ_LEN || p.sequence.size() != VSC_READ_LEN))
+                throw std::runtime_error("ERROR: a sequence is not 23 nt long.");
+            std::string a = t.sequence, b = p.sequence;
+            a.resize(VSC_READ_LEN, 'A');
+            b.resize(VSC_READ_LEN, 'A');
+            on_codes[i] = vsc_pack_guide(a.c_str());
+            off_codes[i] = vsc_pack_guide(b.c_str());
+            masks[i] = mm_mask(p);
+        }
+        vsc_ctx *ctx = nullptr;
+        int st = vsc_ctx_create(device, &ctx);
+        if (st != VSC_OK) throw std::runtime_error(st == VSC_ERR_NODEVICE ? "ERROR: no HIP device available (there is no CPU fallback)." : "ERROR: could not create the device context.");
+        st = vsc_score_pairs(ctx, on_codes.data(), off_codes.data(), masks.data(), n, feature_path ? nullptr : mit.data(), nullptr,
+                             feature_path ? feat.data() : nullptr);
+        const std::string err = st == VSC_OK ? "" : vsc_last_error(ctx);
+        vsc_ctx_destroy(ctx);
+        if (st != VSC_OK) throw std::runtime_error("ERROR: " + err);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        const OffTarget &p = *rows[i];
+        const std::string name = p.target + "_" + std::to_string(++count.at(p.target));
+        out << p.chr << "\t" << p.pos << "\t" << (p.pos + 23) << "\t" << name << "\t";
+        if (feature_path) out << ".\t"; else out << fmt_double(mit[i]) << "\t";
+        out << p.strand << "\t" << p.sequence << "\t" << mm_columns(p, merged);
+        if (merged) out << p.snp_type;
+        out << "\n";
+        if (feature_path) {
+            fout << name << "\t";
+            for (int k = 0; k < VSC_N_FEATURES; ++k) fout << (unsigned)feat[i * VSC_N_FEATURES + k] << "\t";
+            fout << fmt_double(activity.at(p.target)) << "\n";
+        }
+    }
+}
+
+}  // namespace vsc_merge

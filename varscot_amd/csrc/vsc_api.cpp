@@ -924,4 +924,51 @@ int vsc_score_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits,
     return VSC_OK;
 }
 
+int vsc_score_pairs(vsc_ctx *ctx, const uint64_t *on_targets, const uint64_t *off_targets, const uint32_t *masks,
+                    uint64_t n, double *mit, uint8_t *mit_flags, uint8_t *features)
+{
+    if (!ctx) return VSC_ERR_INVALID;
+    ctx->err.clear();
+    if (n && (!on_targets || !off_targets || !masks)) return fail(ctx, VSC_ERR_INVALID, "vsc_score_pairs: null argument");
+    ctx->timing.score_ms = 0;
+    if (n == 0 || (!mit && !mit_flags && !features)) return VSC_OK;
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> planes((size_t)n * 4);
+    for (uint64_t i = 0; i < n; ++i) {
+        guide_planes(on_targets[i], &planes[2 * i], &planes[2 * i + 1]);
+        guide_planes(off_targets[i], &planes[2 * (n + i)], &planes[2 * (n + i) + 1]);
+    }
+    VSC_HIP(ctx, ctx->guides.ensure(planes.size() * sizeof(uint32_t) + n * sizeof(uint32_t)));
+    uint32_t *d_planes = (uint32_t *)ctx->guides.p;
+    uint32_t *d_masks = d_planes + planes.size();
+    VSC_HIP(ctx, hipMemcpyAsync(d_planes, planes.data(), planes.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    VSC_HIP(ctx, hipMemcpyAsync(d_masks, masks, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    double *d_mit = nullptr;
+    uint8_t *d_flags = nullptr, *d_feat = nullptr;
+    if (mit) {
+        VSC_HIP(ctx, ctx->score_mit.ensure(n * sizeof(double)));
+        d_mit = (double *)ctx->score_mit.p;
+    }
+    if (mit_flags) {
+        VSC_HIP(ctx, ctx->score_flags.ensure(n));
+        d_flags = (uint8_t *)ctx->score_flags.p;
+    }
+    if (features) {
+        VSC_HIP(ctx, ctx->score_feat.ensure(n * VSC_N_FEATURES));
+        d_feat = (uint8_t *)ctx->score_feat.p;
+    }
+    VSC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    VSC_HIP(ctx, launch_score_pairs((const uint2 *)d_planes, (const uint2 *)(d_planes + 2 * n), d_masks, n, d_mit, d_flags,
+                                    d_feat, ctx->stream));
+    VSC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (mit) VSC_HIP(ctx, hipMemcpyAsync(mit, d_mit, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (mit_flags) VSC_HIP(ctx, hipMemcpyAsync(mit_flags, d_flags, n, hipMemcpyDeviceToHost, ctx->stream));
+    if (features) VSC_HIP(ctx, hipMemcpyAsync(features, d_feat, n * VSC_N_FEATURES, hipMemcpyDeviceToHost, ctx->stream));
+    VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    VSC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timing.score_ms = ms;
+    return VSC_OK;
+}
+
 }  // extern "C"

@@ -113,6 +113,8 @@ hipError_t launch_sort(void *temp, size_t temp_bytes, const uint64_t *keys_in, u
                        const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream);
 hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream);
 hipError_t launch_score(const ScoreArgs &args, hipStream_t stream);
+hipError_t launch_score_pairs(const uint2 *on, const uint2 *off, const uint32_t *masks, uint64_t n, double *mit,
+                              uint8_t *mit_flags, uint8_t *features, hipStream_t stream);
 hipError_t sort32_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
 hipError_t launch_sort32(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
                          const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream);

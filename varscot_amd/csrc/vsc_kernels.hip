@@ -507,6 +507,35 @@ __global__ __launch_bounds__(256) void score_kernel(const ScoreArgs a)
     }
 }
 
+// The same two scores for explicit (read, site) pairs: planes of both 23-mers in read orientation and
+// the mismatch mask the MIT score is taken of (the mergers pass the MD-derived positions).
+__global__ __launch_bounds__(256) void score_pairs_kernel(const uint2 *on, const uint2 *off, const uint32_t *masks,
+                                                          uint64_t n, double *mit, uint8_t *mit_flags, uint8_t *features)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (mit || mit_flags) {
+        int ub;
+        const double s = mit_score(masks[i] & kMask23, &ub);
+        if (mit) mit[i] = s;
+        if (mit_flags) mit_flags[i] = (uint8_t)ub;
+    }
+    if (features) {
+        uint8_t *f = features + i * VSC_N_FEATURES;
+        for (int k = 0; k < VSC_N_FEATURES; ++k) f[k] = 0;
+        feature_row(on[i].x, on[i].y, off[i].x, off[i].y, f);
+    }
+}
+
+hipError_t launch_score_pairs(const uint2 *on, const uint2 *off, const uint32_t *masks, uint64_t n, double *mit,
+                              uint8_t *mit_flags, uint8_t *features, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(score_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, on, off, masks, n, mit,
+                       mit_flags, features);
+    return hipGetLastError();
+}
+
 hipError_t launch_score(const ScoreArgs &args, hipStream_t stream)
 {
     if (args.n == 0) return hipSuccess;
