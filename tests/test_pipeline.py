@@ -142,3 +142,28 @@ def test_variant_aware_pipeline(scenario):
             assert (d / "mfeat.txt").read_text() == want_fm
     rows = (d / "merged.txt").read_text().splitlines()[1:]
     assert any(r.split("\t")[-1].startswith("VAR_") for r in rows) and any(r.split("\t")[-1] == "REF" for r in rows)
+
+
+def test_driver_end_to_end(scenario, tmp_path):
+    """The VARSCOT driver (same flags as the reference's) over the drop-in tools, with and without a
+    VCF; its TSV must equal the merger's rows sorted on the name column."""
+    d, records, bed, tus, targets = scenario
+    driver = os.path.join(ROOT, "varscot_amd", "driver", "VARSCOT")
+    for vcf in (None, d / "in.vcf"):
+        out = tmp_path / ("res_%s.txt" % ("vcf" if vcf else "ref"))
+        cmd = ["bash", driver, "-b", str(d / "targets.bed"), "-o", str(out), "-g", str(d / "genome.fa"), "-i",
+               str(tmp_path / "idx"), "-m", "5", "-t", "2", "-T", str(tmp_path / "tmp"), "-a", str(d / "activity.txt")]
+        if vcf:
+            cmd += ["-f", str(vcf), "-s", "0"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = out.read_text().splitlines()
+        assert lines[0].startswith("#Chr\tStart\tEnd\tTargetsite\tScore")
+        names = [l.split("\t")[3] for l in lines[1:]]
+        assert names == sorted(names) and len(names) > 20
+        assert not (tmp_path / "tmp").exists()  # temp dir removed unless -v
+    r = subprocess.run(["bash", driver, "-b", "x.bed", "-o", "o.txt", "-g", "g.fa", "-i", "i", "-m", "9", "-T", str(tmp_path / "t2")],
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "between 0 and 8" in r.stdout
+    r = subprocess.run(["bash", driver, "-o", "o.txt", "-T", str(tmp_path / "t3")], capture_output=True, text=True)
+    assert r.returncode == 2 and "No on-target file path" in r.stdout

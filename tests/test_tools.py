@@ -84,3 +84,19 @@ def test_bidir_mapping_unwritable_output(workdir):
     r = run("bidir_mapping", "-G", str(d / "genome.fa"), "-I", str(d / "idx"), "-R", str(d / "reads.fa"), "-M", "2",
             "-O", str(d / "no_such_dir" / "out.sam"))
     assert r.returncode == 1 and "Could not open output path" in r.stderr
+
+
+def test_fasta_writer(tmp_path):
+    """BED6 -> 23-mers and 30-mers with strand-aware flanks (extract_fasta_ontargets.h:44-53)."""
+    from helpers import random_seq, revcomp
+    rng = np.random.default_rng(4)
+    seq = random_seq(rng, 500)
+    write_fasta(tmp_path / "g.fa", ["chrZ extra words"], [seq])
+    (tmp_path / "t.bed").write_text("chrZ\t100\t123\tfwd\t7\t+\nchrZ\t200\t223\trev\t7\t-\nchrZ\t2\t25\tedge\t1\t+\n")
+    r = run("fasta_writer", str(tmp_path / "a.fa"), str(tmp_path / "b.fa"), str(tmp_path / "t.bed"), str(tmp_path / "g.fa"))
+    assert r.returncode == 0
+    assert (tmp_path / "a.fa").read_text() == ">fwd\n%s\n>rev\n%s\n>edge\n%s\n" % (seq[100:123], revcomp(seq[200:223]), seq[2:25])
+    # '+': 4 upstream + 3 downstream; '-': 3 before + 4 after on the forward strand, then revcomp;
+    # start 2 - 4 wraps (unsigned) and is clamped to the contig length -> empty sequence, as in the reference
+    assert (tmp_path / "b.fa").read_text() == ">fwd\n%s\n>rev\n%s\n>edge\n\n" % (seq[96:126], revcomp(seq[197:227]))
+    assert run("fasta_writer", "a", "b").returncode == 1
