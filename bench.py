@@ -27,6 +27,8 @@ WORKLOADS = {
     "c1": (10, 1_000_000, 4, "10 guides, 1 Mbp synthetic genome, <=4 mismatches"),
     "c2": (1_000, 3_000_000_000, 6, "1 000 guides, hg38-sized 3 Gbp synthetic ref, <=6 mismatches"),
     "c3": (10_000, 3_000_000_000, 8, "10 000 guides, 3 Gbp synthetic ref, <=8 mismatches, genome-sharded"),
+    "c5": (100_000, 3_000_000_000, 8, "100 000 guides streamed in batches, 3 Gbp ref, <=8 mismatches + packed per-hit "
+                                      "feature rows and MIT scores"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz (32-bit integer lane-ops / s)
@@ -44,6 +46,7 @@ def parse():
     ap.add_argument("--mismatches", type=int, default=None)
     ap.add_argument("--algorithm", default="auto", choices=["auto", "scan", "seed"],
                     help="scan = stream the packed planes; seed = resident pigeonhole site tables; auto = seed")
+    ap.add_argument("--batch", type=int, default=5_000, help="reads per search call for the streamed workload c5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL gather/merge path even with one rank")
     ap.add_argument("--cpu-sample-bases", type=int, default=192_000_000)
@@ -135,11 +138,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
+    streamed = args.workload == "c5"
+    score_ms = []
+
+    def search_batch(batch_codes):
         if not use_dist:
-            return genome.search(codes, max_mm, algorithm=algorithm), None
-        merged, local = vdist.sharded_search(ctx, genome, codes, max_mm, device=device, algorithm=algorithm)
+            return genome.search(batch_codes, max_mm, algorithm=algorithm), None
+        merged, local = vdist.sharded_search(ctx, genome, batch_codes, max_mm, device=device, algorithm=algorithm)
         return local, merged
+
+    def step():
+        """One pass over the workload.  c5: the reads are streamed in batches; every batch's hits get
+        their packed feature rows + MIT scores on the GPU that owns the shard, before any gather."""
+        if not streamed:
+            return search_batch(codes)
+        total, last = 0, None
+        acc = {"scan_ms": 0.0, "sort_ms": 0.0, "finalize_ms": 0.0, "prep_ms": 0.0, "score_ms": 0.0, "hits": 0, "pairs": 0,
+               "genome_bytes": 0}
+        for b in range(0, n_guides, args.batch):
+            if last is not None:
+                last[0].close()
+                if last[1] is not None:
+                    last[1].close()
+            last = search_batch(codes[b:b + args.batch])
+            t = ctx.timing()
+            last[0].packed_features(to_host=False, mit=False)
+            t2 = ctx.timing()
+            for k in ("scan_ms", "sort_ms", "finalize_ms", "prep_ms"):
+                acc[k] += t[k]
+            acc["score_ms"] += t2["score_ms"]
+            for k in ("hits", "pairs", "genome_bytes"):
+                acc[k] += t[k]
+            total += len(last[1]) if last[1] is not None else len(last[0])
+        step.acc, step.total = acc, total
+        return last
 
     scan_ms, sort_ms, fin_ms, prep_ms, hits_local, sites_local, passes = [], [], [], [], 0, 0, 0
     pairs_local, stream_bytes = 0, 0
@@ -153,14 +185,17 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         h, m = step()
-        t = ctx.timing()
+        t = dict(ctx.timing())
+        if streamed:
+            t.update(step.acc)
+            score_ms.append(step.acc["score_ms"])
         scan_ms.append(t["scan_ms"])
         sort_ms.append(t["sort_ms"])
         fin_ms.append(t["finalize_ms"])
         prep_ms.append(t["prep_ms"])
         hits_local, sites_local, passes = t["hits"], t["sites"], max(passes, t["passes"])
         pairs_local, stream_bytes = t["pairs"], t["genome_bytes"]
-        total_hits = len(m) if m is not None else len(h)
+        total_hits = step.total if streamed else (len(m) if m is not None else len(h))
         h.close()
         if m is not None:
             m.close()
@@ -192,7 +227,7 @@ def main():
             # site records of the visited buckets (8 B each, read once) + the per-bucket read lists
             # (12 B per entry) + 12 B per hit written
             k_seg = max_mm // 3
-            list_entries = n_guides * 3 * (1, 22, 211)[k_seg]
+            list_entries = n_guides * 3 * (1, 22, 211)[k_seg]  # summed over the batches of a streamed run
             alg_bytes = float(stream_bytes) + 12.0 * list_entries + 12.0 * hits_local
         achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
         compares = float(pairs_local)
@@ -212,7 +247,8 @@ def main():
             "config": {"workload": "%s: %s" % (args.workload, desc), "guides": n_guides, "genome_bases": total_bases,
                        "max_mismatches": max_mm, "parallelism": "genome-shard x%d" % world, "algorithm": algorithm,
                        "hits_per_step": int(total_hits), "candidate_sites_per_s": total_hits * args.steps / dt,
-                       "pam_valid_sites": int(total_sites), "scan_passes": passes},
+                       "pam_valid_sites": int(total_sites), "scan_passes": passes,
+                       "batch": args.batch if streamed else n_guides},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel, "launch_ms": scan_avg_ms, "algorithmic_bytes": alg_bytes,
@@ -222,7 +258,7 @@ def main():
                                   "lane_ops_per_compare": LANE_OPS_PER_COMPARE, "achieved_lane_ops_per_s": lane_ops,
                                   "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK, "frac": lane_ops / VALU_LANE_OPS_PEAK}},
             "kernels_ms": {"search": scan_avg_ms, "prep": float(np.mean(prep_ms)), "sort": float(np.mean(sort_ms)),
-                           "finalize": float(np.mean(fin_ms))},
+                           "finalize": float(np.mean(fin_ms)), "score": float(np.mean(score_ms)) if score_ms else None},
             "setup": {"genome_generate_s": t_gen, "genome_hbm_bytes": genome.device_bytes, "index_build_ms": index_ms},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -210,6 +210,22 @@ int vsc_score_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits,
                    uint8_t *features);
 #define VSC_N_FEATURES 442
 /*
+ * Feature rows in packed form, 64 bytes (16 little-endian 32-bit words) per hit instead of 442:
+ *   w0      bits 0..20 mismatchPos1..21 | 21..25 totalMismatches | 26..30 adjacentMismatches
+ *   w1      bits 0..11 AtoC..TtoG | 12..16 transitionNumber | 17..21 transversionNumber | 22..25 seedMismatches
+ *   w2..w4  A1..T20, PAMA..PAMT one-hots (bit 4 i + base)
+ *   w5..w14 AA1..TT19 one-hots (bit 16 i + pair); the 16 dinucleotide counts are their column sums
+ *   w15     0
+ * The rows are written to packed_dev (device memory, count * 64 bytes; NULL = library scratch) and,
+ * if packed_host is not NULL, copied to the host; mit_host (optional) receives the MIT scores.
+ * vsc_unpack_features expands rows to the dense 442-byte form of vsc_score_hits.
+ */
+int vsc_score_hits_packed(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, const uint64_t *guides,
+                          uint32_t n_guides, uint64_t first, uint64_t count, void *packed_dev, uint32_t *packed_host,
+                          double *mit_host);
+#define VSC_PACKED_FEATURE_BYTES 64
+void vsc_unpack_features(const uint32_t *packed, uint64_t n, uint8_t *features);
+/*
  * The same scores for n explicit (on-target, off-target) pairs: both 23-mers as vsc_pack_guide codes
  * in read orientation, masks[i] = the mismatch positions calcMitScore is given for row i (bit p =
  * position p).  This is the form the mergers need: they score what they re-derived from the SAM

@@ -187,6 +187,10 @@ def test_mit_and_features_match_oracle(ctx, oracle):
         off = revcomp(off) if s else off
         assert np.array_equal(feat[i].astype(np.uint32), oracle.feature_row(guides[gi], off))
     assert n_ub > 0  # '-' hits with PAM-side mismatches exercise the reference's out-of-bounds case
+    # packed 64-byte rows expand to the same dense rows; MIT identical
+    rows, m3 = hits.packed_features(mit=True)
+    assert rows.shape == (len(rec), 16)
+    assert np.array_equal(va.unpack_features(rows), feat) and np.array_equal(m3, mit)
     # sub-range scoring
     m2, _, f2 = hits.scores(first=5, count=7, mit=True, features=True)
     assert np.array_equal(m2, mit[5:12]) and np.array_equal(f2, feat[5:12])
@@ -307,3 +311,32 @@ def test_auto_uses_an_existing_index_and_rebuilds_for_another_pam(ctx, oracle):
     assert h.to_numpy().tobytes() == a.tobytes()
     h.close()
     gen.close()
+
+
+def test_score_pairs_on_reference_fixtures(ctx, oracle, golden_dir):
+    """vsc_score_pairs: the reference's 6960 golden feature rows directly, and the 4443 SITE-seq pairs
+    (non-GG PAMs, up to 14 mismatches) against the oracle, MIT scores bit-exact."""
+    g = np.load(os.path.join(golden_dir, "features_golden.npz"))
+    on, off = [str(s) for s in g["on"]], [str(s) for s in g["off"]]
+    masks = [sum(1 << i for i in range(23) if a[i] != b[i]) for a, b in zip(on, off)]
+    mit, flags, feat = ctx.score_pairs(on, off, masks, mit=True, features=True)
+    assert np.array_equal(feat, g["feat"])
+    for i in range(0, len(on), 37):
+        pos = [b for b in range(23) if (masks[i] >> b) & 1] or [-1]
+        want, ub = oracle.mit_score(pos)
+        assert mit[i] == want and bool(flags[i]) == ub
+    on2, off2 = [], []
+    with open(os.path.join(golden_dir, "siteseq_pairs.tsv")) as f:
+        next(f)
+        for line in f:
+            a, b, nm, strand = line.split()
+            on2.append(a)
+            off2.append(b)
+    masks2 = [sum(1 << i for i in range(23) if a[i] != b[i]) for a, b in zip(on2, off2)]
+    mit2, flags2, feat2 = ctx.score_pairs(on2, off2, masks2, mit=True, features=True)
+    assert len(on2) == 4443
+    for i in range(len(on2)):
+        assert np.array_equal(feat2[i].astype(np.uint32), oracle.feature_row(on2[i], off2[i]))
+        pos = [b for b in range(23) if (masks2[i] >> b) & 1] or [-1]
+        want, ub = oracle.mit_score(pos)
+        assert mit2[i] == want and bool(flags2[i]) == ub

@@ -241,6 +241,16 @@ class Hits:
                                    first, count, ptr(m), ptr(fl), ptr(ft)), self.genome.ctx._h)
         return m, fl, ft
 
+    def packed_features(self, first=0, count=None, to_host=True, mit=False):
+        """vsc_score_hits_packed: 64-byte feature rows (uint32[count, 16]) and optionally MIT scores.
+        With to_host=False the rows stay in library scratch on the device (timing / streaming runs)."""
+        count = len(self) - first if count is None else count
+        rows = np.empty((count, 16), dtype=np.uint32) if to_host else None
+        m = np.empty(count, dtype=np.float64) if mit else None
+        check(lib().vsc_score_hits_packed(self.genome.ctx._h, self.genome._h, self._h, ptr(self.codes), len(self.codes),
+                                          first, count, None, ptr(rows), ptr(m)), self.genome.ctx._h)
+        return rows, m
+
     def close(self):
         if self._h:
             lib().vsc_hits_free(self._h)
@@ -277,6 +287,14 @@ def merge_shard_records(ctx, records_ptr, on_device, n, n_guides):
     h = C.c_void_p()
     check(lib().vsc_hits_merge(ctx._h, C.c_void_p(records_ptr), int(bool(on_device)), n, n_guides, C.byref(h)), ctx._h)
     return MergedHits(ctx, h)
+
+
+def unpack_features(rows):
+    """Packed 64-byte feature rows -> dense uint8[n, 442] (vsc_unpack_features)."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint32).reshape(-1, 16)
+    out = np.empty((len(rows), N_FEATURES), dtype=np.uint8)
+    lib().vsc_unpack_features(ptr(rows), len(rows), ptr(out))
+    return out
 
 
 def sam_order(hits):

@@ -81,6 +81,7 @@ struct vsc_genome {
     vsc_ctx *ctx = nullptr;
     uint32_t *d_hi = nullptr, *d_lo = nullptr, *d_nm = nullptr;
     uint32_t *d_contig_off = nullptr, *d_contig_end = nullptr;
+    uint2 *d_hl = nullptr;  // interleaved planes, built on first scoring call
     uint64_t first_word = 0, own_words = 0, dev_words = 0;
     uint32_t n_tiles = 0, n_contigs = 0;
     uint64_t device_bytes = 0;
@@ -127,6 +128,17 @@ int fail(vsc_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
         hipError_t e_ = (call);                                            \
         if (e_ != hipSuccess) return fail((ctx), VSC_ERR_DEVICE, #call, e_); \
     } while (0)
+
+// Scoring reads the genome at random hit positions: give it the interleaved copy of the planes.
+hipError_t ensure_hl(vsc_ctx *ctx, const vsc_genome *genome)
+{
+    vsc_genome *g = const_cast<vsc_genome *>(genome);
+    if (g->d_hl) return hipSuccess;
+    hipError_t e = hipMalloc((void **)&g->d_hl, g->dev_words * sizeof(uint2));
+    if (e != hipSuccess) return e;
+    g->device_bytes += g->dev_words * sizeof(uint2);
+    return launch_interleave(g->d_hi, g->d_lo, g->dev_words, g->d_hl, ctx->stream);
+}
 
 // Record storage for a result: the smallest spare buffer that fits, else a new allocation.
 hipError_t take_records(vsc_ctx *ctx, vsc_hits *hits, uint64_t n)
@@ -341,7 +353,7 @@ int vsc_genome_free(vsc_genome *g)
 {
     if (!g) return VSC_OK;
     if (g->ctx) (void)hipSetDevice(g->ctx->device);
-    for (void *p : {(void *)g->d_hi, (void *)g->d_lo, (void *)g->d_nm, (void *)g->d_contig_off, (void *)g->d_contig_end,
+    for (void *p : {(void *)g->d_hi, (void *)g->d_lo, (void *)g->d_nm, (void *)g->d_contig_off, (void *)g->d_contig_end, (void *)g->d_hl,
                     (void *)g->d_ix_planes, (void *)g->d_ix_pos, (void *)g->d_ix_bucket_start, (void *)g->d_ix_chunk_tab})
         if (p) (void)hipFree(p);
     delete g;
@@ -892,8 +904,8 @@ int vsc_score_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits,
     ScoreArgs s{};
     s.hits = hits->d_records + first;
     s.n = count;
-    s.hi = genome->d_hi;
-    s.lo = genome->d_lo;
+    VSC_HIP(ctx, ensure_hl(ctx, genome));
+    s.hl = genome->d_hl;
     s.first_pos = (uint32_t)(genome->first_word * 32);
     s.n_plane_words = genome->dev_words;
     s.contig_off = genome->d_contig_off;
@@ -964,6 +976,51 @@ int vsc_score_pairs(vsc_ctx *ctx, const uint64_t *on_targets, const uint64_t *of
     if (mit) VSC_HIP(ctx, hipMemcpyAsync(mit, d_mit, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (mit_flags) VSC_HIP(ctx, hipMemcpyAsync(mit_flags, d_flags, n, hipMemcpyDeviceToHost, ctx->stream));
     if (features) VSC_HIP(ctx, hipMemcpyAsync(features, d_feat, n * VSC_N_FEATURES, hipMemcpyDeviceToHost, ctx->stream));
+    VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    VSC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timing.score_ms = ms;
+    return VSC_OK;
+}
+
+int vsc_score_hits_packed(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, const uint64_t *guides,
+                          uint32_t n_guides, uint64_t first, uint64_t count, void *packed_dev, uint32_t *packed_host,
+                          double *mit_host)
+{
+    if (!ctx) return VSC_ERR_INVALID;
+    ctx->err.clear();
+    if (!genome || !hits || (n_guides && !guides)) return fail(ctx, VSC_ERR_INVALID, "vsc_score_hits_packed: null argument");
+    if (first > hits->n || count > hits->n - first) return fail(ctx, VSC_ERR_INVALID, "vsc_score_hits_packed: row range outside the result");
+    ctx->timing.score_ms = 0;
+    if (count == 0) return VSC_OK;
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> gp((size_t)std::max<uint32_t>(n_guides, 1) * 2, 0);
+    for (uint32_t i = 0; i < n_guides; ++i) guide_planes(guides[i], &gp[2 * (size_t)i], &gp[2 * (size_t)i + 1]);
+    VSC_HIP(ctx, ctx->guides.ensure(gp.size() * sizeof(uint32_t)));
+    VSC_HIP(ctx, hipMemcpyAsync(ctx->guides.p, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    ScoreArgs s{};
+    s.hits = hits->d_records + first;
+    s.n = count;
+    VSC_HIP(ctx, ensure_hl(ctx, genome));
+    s.hl = genome->d_hl;
+    s.first_pos = (uint32_t)(genome->first_word * 32);
+    s.n_plane_words = genome->dev_words;
+    s.contig_off = genome->d_contig_off;
+    s.guides = (const uint2 *)ctx->guides.p;
+    if (mit_host) {
+        VSC_HIP(ctx, ctx->score_mit.ensure(count * sizeof(double)));
+        s.mit = (double *)ctx->score_mit.p;
+    }
+    uint4 *dst = (uint4 *)packed_dev;
+    if (!dst) {
+        VSC_HIP(ctx, ctx->score_feat.ensure(count * 64));
+        dst = (uint4 *)ctx->score_feat.p;
+    }
+    VSC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    VSC_HIP(ctx, launch_score_packed(s, dst, ctx->stream));
+    VSC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (packed_host) VSC_HIP(ctx, hipMemcpyAsync(packed_host, dst, count * 64, hipMemcpyDeviceToHost, ctx->stream));
+    if (mit_host) VSC_HIP(ctx, hipMemcpyAsync(mit_host, s.mit, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0;
     VSC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));

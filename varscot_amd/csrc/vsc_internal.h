@@ -76,7 +76,7 @@ struct FinalizeArgs {
 struct ScoreArgs {
     const vsc_hit *hits;  // device records, already offset to the first row to score
     uint64_t n;
-    const uint32_t *hi, *lo;  // planes of the shard that holds the hits
+    const uint2 *hl;          // interleaved (hi, lo) plane words of the shard that holds the hits
     uint32_t first_pos;
     uint64_t n_plane_words;
     const uint32_t *contig_off;
@@ -112,7 +112,9 @@ hipError_t sort_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
 hipError_t launch_sort(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
                        const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream);
 hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream);
+hipError_t launch_interleave(const uint32_t *hi, const uint32_t *lo, uint64_t n, uint2 *hl, hipStream_t stream);
 hipError_t launch_score(const ScoreArgs &args, hipStream_t stream);
+hipError_t launch_score_packed(const ScoreArgs &args, uint4 *packed, hipStream_t stream);
 hipError_t launch_score_pairs(const uint2 *on, const uint2 *off, const uint32_t *masks, uint64_t n, double *mit,
                               uint8_t *mit_flags, uint8_t *features, hipStream_t stream);
 hipError_t sort32_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);

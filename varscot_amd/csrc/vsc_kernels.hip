@@ -477,6 +477,37 @@ __device__ void feature_row(uint32_t on_h, uint32_t on_l, uint32_t off_h, uint32
     }
 }
 
+// hl[w] = (hi[w], lo[w]): scoring reads the four plane words of a hit with two adjacent 8-byte loads
+// (one 64-byte sector 7 times out of 8) instead of four loads from two arrays
+__global__ __launch_bounds__(256) void interleave_kernel(const uint32_t *hi, const uint32_t *lo, uint64_t n, uint2 *hl)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hl[i] = make_uint2(hi[i], lo[i]);
+}
+
+hipError_t launch_interleave(const uint32_t *hi, const uint32_t *lo, uint64_t n, uint2 *hl, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(interleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, hi, lo, n, hl);
+    return hipGetLastError();
+}
+
+// off-target planes of a hit in read orientation: genome[pos, pos+23), reverse-complemented for '-'
+// (filter_output_bam.h:399)
+__device__ __forceinline__ void site_planes(const ScoreArgs &a, const vsc_hit &h, uint32_t &oh, uint32_t &ol)
+{
+    const uint32_t rel = a.contig_off[h.contig] + h.pos - a.first_pos;
+    const uint64_t wi = rel >> 5;
+    const uint32_t sh = rel & 31u;
+    const uint2 w0 = a.hl[wi], w1 = a.hl[wi + 1];
+    oh = funnel(w1.x, w0.x, sh) & kMask23;
+    ol = funnel(w1.y, w0.y, sh) & kMask23;
+    if (VSC_HIT_STRAND(h.info)) {
+        oh = revcomp_plane(oh);
+        ol = revcomp_plane(ol);
+    }
+}
+
 __global__ __launch_bounds__(256) void score_kernel(const ScoreArgs a)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -490,21 +521,85 @@ __global__ __launch_bounds__(256) void score_kernel(const ScoreArgs a)
         if (a.mit_flags) a.mit_flags[i] = (uint8_t)ub;
     }
     if (a.features) {
-        // off-target = genome[pos, pos+23), reverse-complemented for '-' (filter_output_bam.h:399)
-        const uint32_t rel = a.contig_off[h.contig] + h.pos - a.first_pos;
-        const uint64_t wi = rel >> 5;
-        const uint32_t sh = rel & 31u;
-        uint32_t oh = funnel(a.hi[wi + 1], a.hi[wi], sh) & kMask23;
-        uint32_t ol = funnel(a.lo[wi + 1], a.lo[wi], sh) & kMask23;
-        if (VSC_HIT_STRAND(h.info)) {
-            oh = revcomp_plane(oh);
-            ol = revcomp_plane(ol);
-        }
+        uint32_t oh, ol;
+        site_planes(a, h, oh, ol);
         const uint2 g = a.guides[h.guide];
         uint8_t *f = a.features + i * VSC_N_FEATURES;
         for (int k = 0; k < VSC_N_FEATURES; ++k) f[k] = 0;
         feature_row(g.x, g.y, oh, ol, f);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed feature rows: the 442 features of feature_matrix.h:25-126 in 64 bytes per hit
+//   w0      bits 0..20 mismatch flags f[1..21] | 21..25 f[0] totalMismatches | 26..30 f[440] adjacentMismatches
+//   w1      bits 0..11 mismatch types f[22..33] | 12..16 f[34] transitions | 17..21 f[35] transversions | 22..25 f[441] seed
+//   w2..w4  single-letter one-hots f[36..119]  (bit 4 i + base)
+//   w5..w14 dinucleotide one-hots f[120..423] (bit 16 i + pair); the 16 dinucleotide counts f[424..439]
+//           are the column sums of these flags and are not stored
+//   w15     0
+// vsc_unpack_features (vsc_pack.cpp) expands a row to the 442 dense values.
+// ------------------------------------------------------------------------------------------------
+__device__ void feature_row_packed(uint32_t on_h, uint32_t on_l, uint32_t off_h, uint32_t off_l, uint32_t (&w)[16])
+{
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = 0;
+    const uint32_t m21 = 0x1FFFFFu;
+    const uint32_t mm = ((on_h ^ off_h) | (on_l ^ off_l)) & m21;  // positions 0..20 (:53)
+    const uint32_t total = __popc(mm);
+    const uint32_t adjacent = __popc(mm & (mm >> 1));             // :100-105
+    const uint32_t seed = __popc(mm & 0xFFF00u);                  // 8 <= i <= 19, :94-98
+    // transitions = mismatches whose codes differ in the hi bit only (AG, CT, GA, TC; :47)
+    const uint32_t ts = __popc(mm & (on_h ^ off_h) & ~(on_l ^ off_l));
+    uint32_t types = 0;
+    for (uint32_t r = mm; r; r &= r - 1) {
+        const int i = __ffs(r) - 1;
+        const int o = (int)(((on_h >> i) & 1u) << 1 | ((on_l >> i) & 1u));
+        const int b = (int)(((off_h >> i) & 1u) << 1 | ((off_l >> i) & 1u));
+        types |= 1u << (o * 3 + (b > o ? b - 1 : b));             // :45-46,119
+    }
+    w[0] = mm | (total << 21) | (adjacent << 26);
+    w[1] = types | (ts << 12) | ((total - ts) << 17) | (seed << 22);
+    for (int i = 0; i < 21; ++i) {
+        const uint32_t b = ((off_h >> i) & 1u) << 1 | ((off_l >> i) & 1u);
+        const uint32_t bit = 4u * i + b;                          // :64-83
+        w[2 + (bit >> 5)] |= 1u << (bit & 31u);
+        if (i < 19) {                                             // :56-60
+            const uint32_t b2 = ((off_h >> (i + 1)) & 1u) << 1 | ((off_l >> (i + 1)) & 1u);
+            const uint32_t pbit = 16u * i + b * 4u + b2;
+            w[5 + (pbit >> 5)] |= 1u << (pbit & 31u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void score_packed_kernel(const ScoreArgs a, uint4 *packed)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const vsc_hit h = a.hits[i];
+    uint32_t oh, ol;
+    site_planes(a, h, oh, ol);
+    const uint2 g = a.guides[h.guide];
+    uint32_t w[16];
+    feature_row_packed(g.x, g.y, oh, ol, w);
+    uint4 *dst = packed + i * 4;
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    dst[2] = make_uint4(w[8], w[9], w[10], w[11]);
+    dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
+    if (a.mit) {
+        int ub;
+        a.mit[i] = mit_score(VSC_HIT_MASK(h.info), &ub);
+        if (a.mit_flags) a.mit_flags[i] = (uint8_t)ub;
+    }
+}
+
+hipError_t launch_score_packed(const ScoreArgs &args, uint4 *packed, hipStream_t stream)
+{
+    if (args.n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((args.n + 255) / 256);
+    hipLaunchKernelGGL(score_packed_kernel, dim3(blocks), dim3(256), 0, stream, args, packed);
+    return hipGetLastError();
 }
 
 // The same two scores for explicit (read, site) pairs: planes of both 23-mers in read orientation and

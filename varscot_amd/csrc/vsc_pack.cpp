@@ -90,6 +90,28 @@ uint64_t vsc_pack_guide(const char *seq23)
     return g;
 }
 
+void vsc_unpack_features(const uint32_t *packed, uint64_t n, uint8_t *features)
+{
+    for (uint64_t r = 0; r < n; ++r) {
+        const uint32_t *w = packed + r * 16;
+        uint8_t *f = features + r * VSC_N_FEATURES;
+        std::memset(f, 0, VSC_N_FEATURES);
+        f[0] = (uint8_t)((w[0] >> 21) & 31u);
+        for (int i = 0; i < 21; ++i) f[1 + i] = (uint8_t)((w[0] >> i) & 1u);
+        for (int i = 0; i < 12; ++i) f[22 + i] = (uint8_t)((w[1] >> i) & 1u);
+        f[34] = (uint8_t)((w[1] >> 12) & 31u);
+        f[35] = (uint8_t)((w[1] >> 17) & 31u);
+        for (int b = 0; b < 84; ++b) f[36 + b] = (uint8_t)((w[2 + (b >> 5)] >> (b & 31)) & 1u);
+        for (int b = 0; b < 304; ++b) {
+            const uint8_t v = (uint8_t)((w[5 + (b >> 5)] >> (b & 31)) & 1u);
+            f[120 + b] = v;
+            f[424 + (b & 15)] += v;  // dinucleotide counts = column sums of the one-hots
+        }
+        f[440] = (uint8_t)((w[0] >> 26) & 31u);
+        f[441] = (uint8_t)((w[1] >> 22) & 15u);
+    }
+}
+
 void vsc_sam_order(const vsc_hit *hits, uint64_t n, uint64_t *order, uint8_t *secondary)
 {
     // read_mapping/bidir_mapping.cpp:167-187, per (read, strand) block of the ascending result:
