@@ -27,6 +27,8 @@ WORKLOADS = {
     "c1": (10, 1_000_000, 4, "10 guides, 1 Mbp synthetic genome, <=4 mismatches"),
     "c2": (1_000, 3_000_000_000, 6, "1 000 guides, hg38-sized 3 Gbp synthetic ref, <=6 mismatches"),
     "c3": (10_000, 3_000_000_000, 8, "10 000 guides, 3 Gbp synthetic ref, <=8 mismatches, genome-sharded"),
+    "c4": (1_000, 3_000_000_000, 6, "1 000 guides, 3 Gbp synthetic ref + synthetic VCF (~5 M SNPs): reference and "
+                                    "alt-allele windows (SNP genome) searched, <=6 mismatches, 1 GPU"),
     "c5": (100_000, 3_000_000_000, 8, "100 000 guides streamed in batches, 3 Gbp ref, <=8 mismatches + packed per-hit "
                                       "feature rows and MIT scores"),
 }
@@ -46,6 +48,7 @@ def parse():
     ap.add_argument("--mismatches", type=int, default=None)
     ap.add_argument("--algorithm", default="auto", choices=["auto", "scan", "seed"],
                     help="scan = stream the packed planes; seed = resident pigeonhole site tables; auto = seed")
+    ap.add_argument("--snps", type=int, default=5_000_000, help="records of the synthetic VCF (workload c4)")
     ap.add_argument("--batch", type=int, default=5_000, help="reads per search call for the streamed workload c5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL gather/merge path even with one rank")
@@ -127,11 +130,41 @@ def main():
     del hi, lo, nm
     ids, seqs = synth.synthetic_guides(n_guides)
     codes = va.pack_guides(seqs)
+    snp_genome, snp_info = None, None
+    if args.workload == "c4":
+        # variant-aware run: the alt-allele windows are produced by the vcf_loader drop-in from a
+        # synthetic VCF (file formats of the reference), packed by bidir_index, and searched as a second
+        # resident genome.  All of this is input preparation, outside the timed region.
+        if world != 1:
+            raise SystemExit("workload c4 is a single-GPU configuration")
+        import subprocess
+        import tempfile
+        t_prep = time.perf_counter()
+        full = synth.synthetic_genome(total_bases)
+        tmp = tempfile.mkdtemp(prefix="vsc_c4_")
+        bin_dir = os.path.join(ROOT, "varscot_amd", "bin")
+        synth.write_fasta(full, os.path.join(tmp, "genome.fa"))
+        n_snps = synth.synthetic_vcf(full, args.snps, os.path.join(tmp, "in.vcf"))
+        del full
+        subprocess.check_call([os.path.join(bin_dir, "vcf_loader"), os.path.join(tmp, "in.vcf"), os.path.join(tmp, "snp.fa"),
+                               os.path.join(tmp, "genome.fa"), "0", "23", "8"], stdout=subprocess.DEVNULL)
+        subprocess.check_call([os.path.join(bin_dir, "bidir_index"), "-G", os.path.join(tmp, "snp.fa"), "-I",
+                               os.path.join(tmp, "snp")], stdout=subprocess.DEVNULL)
+        snp_packed = va.PackedGenome.from_index_file(os.path.join(tmp, "snp"))
+        snp_genome = ctx.load_genome(snp_packed)
+        snp_info = {"snps": n_snps, "windows": len(snp_packed.contigs), "window_bases": snp_packed.n_bases,
+                    "prepare_s": None}
+        del snp_packed
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+        snp_info["prepare_s"] = time.perf_counter() - t_prep
     algorithm = "seed" if args.algorithm == "auto" else args.algorithm
     index_ms = None
     if algorithm == "seed":  # the resident site tables are part of the inputs, like the reference's FM index
         genome.build_index()
         index_ms = ctx.timing()["index_ms"]
+        if snp_genome is not None:
+            snp_genome.build_index()
 
     def barrier():
         if use_dist:
@@ -147,9 +180,23 @@ def main():
         merged, local = vdist.sharded_search(ctx, genome, batch_codes, max_mm, device=device, algorithm=algorithm)
         return local, merged
 
+    def step_c4():
+        """Reference genome and SNP genome, one after the other (the reference runs them as two jobs)."""
+        h_ref = genome.search(codes, max_mm, algorithm=algorithm)
+        t_ref = ctx.timing()
+        h_snp = snp_genome.search(codes, max_mm, algorithm=algorithm)
+        t_snp = ctx.timing()
+        step.acc = {k: t_ref[k] + t_snp[k] for k in ("scan_ms", "sort_ms", "finalize_ms", "prep_ms", "hits", "pairs", "genome_bytes")}
+        step.acc["score_ms"] = 0.0
+        step.total = len(h_ref) + len(h_snp)
+        h_snp.close()
+        return h_ref, None
+
     def step():
         """One pass over the workload.  c5: the reads are streamed in batches; every batch's hits get
         their packed feature rows + MIT scores on the GPU that owns the shard, before any gather."""
+        if args.workload == "c4":
+            return step_c4()
         if not streamed:
             return search_batch(codes)
         total, last = 0, None
@@ -186,7 +233,7 @@ def main():
     for i in range(args.steps):
         h, m = step()
         t = dict(ctx.timing())
-        if streamed:
+        if streamed or args.workload == "c4":
             t.update(step.acc)
             score_ms.append(step.acc["score_ms"])
         scan_ms.append(t["scan_ms"])
@@ -195,7 +242,7 @@ def main():
         prep_ms.append(t["prep_ms"])
         hits_local, sites_local, passes = t["hits"], t["sites"], max(passes, t["passes"])
         pairs_local, stream_bytes = t["pairs"], t["genome_bytes"]
-        total_hits = step.total if streamed else (len(m) if m is not None else len(h))
+        total_hits = step.total if (streamed or args.workload == "c4") else (len(m) if m is not None else len(h))
         h.close()
         if m is not None:
             m.close()
@@ -248,7 +295,7 @@ def main():
                        "max_mismatches": max_mm, "parallelism": "genome-shard x%d" % world, "algorithm": algorithm,
                        "hits_per_step": int(total_hits), "candidate_sites_per_s": total_hits * args.steps / dt,
                        "pam_valid_sites": int(total_sites), "scan_passes": passes,
-                       "batch": args.batch if streamed else n_guides},
+                       "batch": args.batch if streamed else n_guides, "variant_genome": snp_info},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel, "launch_ms": scan_avg_ms, "algorithmic_bytes": alg_bytes,

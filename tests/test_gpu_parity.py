@@ -340,3 +340,39 @@ def test_score_pairs_on_reference_fixtures(ctx, oracle, golden_dir):
         pos = [b for b in range(23) if (masks2[i] >> b) & 1] or [-1]
         want, ub = oracle.mit_score(pos)
         assert mit2[i] == want and bool(flags2[i]) == ub
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_many_tiny_contigs_like_a_variant_genome(ctx, oracle, algo):
+    """70 000 contigs of 45-60 bases (more than the reference's uint16_t key can tell apart): window
+    genome shape, contig resolution by binary search, hits at contig ends."""
+    rng = np.random.default_rng(31)
+    guides = random_guides(rng, 6)
+    contigs = []
+    for i in range(70000):
+        n = int(rng.integers(45, 61))
+        s = random_seq(rng, n)
+        if i % 97 == 0:
+            g = guides[i % len(guides)]
+            site = mutate(rng, g, int(rng.integers(0, 4)), 0, 20)
+            site = site if i % 2 else revcomp(site)
+            p = [0, n - 23, (n - 23) // 2][i % 3]
+            s = s[:p] + site + s[p + 23:]
+        contigs.append(s)
+    want = oracle.search_fast(contigs, guides, 5)
+    got = gpu_search(ctx, contigs, guides, 5, algo=algo)
+    assert len(want) > 300 and int(want["contig"].max()) > 65535
+    assert hits_as_tuples(got) == hits_as_tuples(want)
+
+
+def test_many_and_duplicate_reads_seeded(ctx, oracle):
+    """4 000 reads (long per-bucket read lists, lists padded to the unroll factor) with exact
+    duplicates among them."""
+    rng = np.random.default_rng(32)
+    guides = random_guides(rng, 3990)
+    guides += guides[:10]
+    contigs = make_genome(32, [400000, 150000], guides[:50], 6, n_plant=300, n_runs=4)
+    want = oracle.search_fast(contigs, guides, 6)
+    got = gpu_search(ctx, contigs, guides, 6, algo="seed")
+    assert len(want) > 2000
+    assert hits_as_tuples(got) == hits_as_tuples(want)

@@ -62,6 +62,22 @@ class PackedGenome:
             L.vsc_pack_bases(b, len(b), int(row["offset"]), ptr(hi), ptr(lo), ptr(nm))
         return cls(hi, lo, nm, table, names)
 
+    @classmethod
+    def from_index_file(cls, prefix):
+        """Reads <prefix>.vsc as written by the bidir_index tool (tools/vsc_host.hpp)."""
+        with open(prefix + ".vsc", "rb") as f:
+            assert f.read(8) == b"VSCIDX01", "not a packed genome"
+            nc, nw = (int(x) for x in np.frombuffer(f.read(16), dtype="<u8"))
+            table = np.frombuffer(f.read(nc * CONTIG_DTYPE.itemsize), dtype=CONTIG_DTYPE).copy()
+            names = []
+            for _ in range(nc):
+                ln = int(np.frombuffer(f.read(4), dtype="<u4")[0])
+                names.append(f.read(ln).decode())
+            hi = np.frombuffer(f.read(nw * 4), dtype="<u4").copy()
+            lo = np.frombuffer(f.read(nw * 4), dtype="<u4").copy()
+            nm = np.frombuffer(f.read(nw * 4), dtype="<u4").copy()
+        return cls(hi, lo, nm, table, names)
+
     def decode(self, pos, n):
         """n characters starting at global position pos (N outside contigs)."""
         out = C.create_string_buffer(n)

@@ -164,3 +164,59 @@ def plant_sites(packed, guides, n_sites, max_sub, seed=0x5EED0004):
                          _lib.ptr(packed.lo), _lib.ptr(packed.nmask))
         out.append((gi, c, pos, strand, nsub))
     return out
+
+
+SEED_VCF = 0x5EED0003
+
+
+def write_fasta(packed, path, width=60, chunk=1 << 24):
+    """The contigs of a packed genome as FASTA text (for tools that take the reference's file formats)."""
+    import ctypes as C
+    from ._lib import lib, ptr
+    buf = C.create_string_buffer(chunk)
+    with open(path, "wb") as f:
+        for name, row in zip(packed.names, packed.contigs):
+            f.write(b">" + name.encode() + b"\n")
+            off, ln = int(row["offset"]), int(row["length"])
+            for s in range(0, ln, chunk):
+                m = min(chunk, ln - s)
+                lib().vsc_unpack_bases(ptr(packed.hi), ptr(packed.lo), ptr(packed.nmask), off + s, m, buf)
+                a = np.frombuffer(buf, dtype=np.uint8, count=m)
+                full = (m // width) * width
+                if full:
+                    lines = np.empty((full // width, width + 1), dtype=np.uint8)
+                    lines[:, :width] = a[:full].reshape(-1, width)
+                    lines[:, width] = 10
+                    f.write(lines.tobytes())
+                if m > full:
+                    f.write(a[full:m].tobytes() + b"\n")
+
+
+def synthetic_vcf(packed, n_snps, path, seed=SEED_VCF):
+    """SNP records at distinct uniformly random positions, ALT uniform over the three
+    other bases, one sample, GT in {0|1, 1|0, 1|1, 0/1} with probabilities {.4, .4, .15, .05}."""
+    rng = np.random.default_rng(seed)
+    total = int(packed.contigs["length"].sum())
+    flat = np.unique(rng.integers(0, total, size=int(n_snps * 1.02)))[:n_snps]
+    ends = np.cumsum(packed.contigs["length"].astype(np.int64))
+    cidx = np.searchsorted(ends, flat, side="right")
+    local = flat - (ends[cidx] - packed.contigs["length"][cidx].astype(np.int64))
+    gpos = packed.contigs["offset"][cidx].astype(np.int64) + local
+    w, b = gpos >> 5, (gpos & 31).astype(np.uint32)
+    isn = (packed.nmask[w] >> b) & 1
+    code = (((packed.hi[w] >> b) & 1) << 1) | ((packed.lo[w] >> b) & 1)
+    alt = (code + rng.integers(1, 4, size=len(code)).astype(np.uint32)) & 3
+    gts = np.array(["0|1", "1|0", "1|1", "0/1"])[rng.choice(4, size=len(code), p=[.4, .4, .15, .05])]
+    letters = np.array(list("ACGT"))
+    keep = isn == 0
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.2\n")
+        for name, row in zip(packed.names, packed.contigs):
+            f.write("##contig=<ID=%s,length=%d>\n" % (name, int(row["length"])))
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS0\n")
+        names = np.array(packed.names)
+        rows = np.char.add(np.char.add(np.char.add(names[cidx[keep]], "\t"), (local[keep] + 1).astype(str)),
+                           np.char.add(np.char.add("\t.\t", letters[code[keep]]), np.char.add("\t", letters[alt[keep]])))
+        rows = np.char.add(np.char.add(rows, "\t.\tPASS\t.\tGT\t"), gts[keep])
+        f.write("\n".join(rows.tolist()) + "\n")
+    return int(keep.sum())
