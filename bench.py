@@ -90,6 +90,11 @@ def cpu_baseline(total_bases, max_mm, sample_bases, sample_guides, seqs):
 
 def main():
     args = parse()
+    # stdout carries exactly one line, the JSON result: everything else that might write to fd 1
+    # (RCCL prints a banner there) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -310,7 +315,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(total_bases, max_mm, args.cpu_sample_bases, args.cpu_sample_guides, seqs)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     genome.close()
     ctx.close()

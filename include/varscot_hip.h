@@ -186,14 +186,16 @@ int vsc_hits_data(vsc_hits *hits, const vsc_hit **out);
 int vsc_hits_copy(vsc_hits *hits, void *dst, int dst_is_device);
 /*
  * Multi-GPU: merges the results of genome shards.  records = the vsc_hit records of shard 0,
- * shard 1, ... concatenated in shard order (each as vsc_search returned them; contig and pos are
- * already global, so nothing is rewritten), in device memory when records_on_device != 0 (the buffer
- * RCCL gathered into), else in host memory (uploaded first).  Because shards partition the positions
- * in ascending order, a stable sort on (guide, strand) restores the global result order.  Replaces
- * the concatenation of per-thread output buffers, read_mapping/bidir_mapping.cpp:307-308.
+ * shard 1, ... concatenated in shard order (shard_counts[s] records each, as vsc_search returned them;
+ * contig and pos are already global, so nothing is rewritten), in device memory when
+ * records_on_device != 0 (the buffer RCCL gathered into), else in host memory (uploaded first).
+ * Shards partition the positions in ascending order, so the global result is, for every
+ * (guide, strand), shard 0's segment followed by shard 1's, ...: segments are located and copied,
+ * nothing is sorted.  Replaces the concatenation of per-thread output buffers,
+ * read_mapping/bidir_mapping.cpp:307-308.
  */
-int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, uint64_t n, uint32_t n_guides,
-                   vsc_hits **out);
+int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, const uint64_t *shard_counts,
+                   uint32_t n_shards, uint32_t n_guides, vsc_hits **out);
 int vsc_hits_free(vsc_hits *hits);
 
 /*

@@ -376,3 +376,33 @@ def test_many_and_duplicate_reads_seeded(ctx, oracle):
     got = gpu_search(ctx, contigs, guides, 6, algo="seed")
     assert len(want) > 2000
     assert hits_as_tuples(got) == hits_as_tuples(want)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_shard_merge_kernels(ctx, oracle, world):
+    """vsc_hits_merge on host-resident shard results (the gloo rehearsal path) with empty shards,
+    reads without hits and many (guide, strand) keys."""
+    from varscot_amd.api import merge_shard_records
+    rng = np.random.default_rng(60 + world)
+    guides = random_guides(rng, 40)
+    contigs = make_genome(60 + world, [60000, 20000, 33], guides[:25], 6, n_plant=300, n_runs=3)
+    packed = va.PackedGenome.from_sequences(contigs)
+    parts = []
+    for rank in range(world):
+        b, e = packed.shard_words(rank, world)
+        if e <= b:
+            parts.append(np.zeros(0, dtype=va.HIT_DTYPE))
+            continue
+        gen = ctx.load_genome(packed, rank, world)
+        h = gen.search(guides, 6)
+        parts.append(h.to_numpy())
+        h.close()
+        gen.close()
+    parts.insert(1, np.zeros(0, dtype=va.HIT_DTYPE))  # an empty shard in the middle
+    cat = np.ascontiguousarray(np.concatenate(parts))
+    merged = merge_shard_records(ctx, cat.ctypes.data, False, [len(p) for p in parts], len(guides))
+    got = merged.to_numpy()
+    merged.close()
+    want = oracle.search_fast(contigs, guides, 6)
+    assert len(want) > 200
+    assert got.tobytes() == want.tobytes()

@@ -297,11 +297,13 @@ class MergedHits(Hits):
         raise NotImplementedError("score hits on the rank that owns the shard, before the gather")
 
 
-def merge_shard_records(ctx, records_ptr, on_device, n, n_guides):
-    """records_ptr: pointer to n vsc_hit records = shard results concatenated in shard order (device
-    memory if on_device, e.g. the buffer RCCL gathered into; else host memory)."""
+def merge_shard_records(ctx, records_ptr, on_device, shard_counts, n_guides):
+    """records_ptr: pointer to the vsc_hit records of all shards concatenated in shard order
+    (shard_counts[s] each; device memory if on_device, e.g. the buffer RCCL gathered into)."""
+    counts = np.ascontiguousarray(shard_counts, dtype=np.uint64)
     h = C.c_void_p()
-    check(lib().vsc_hits_merge(ctx._h, C.c_void_p(records_ptr), int(bool(on_device)), n, n_guides, C.byref(h)), ctx._h)
+    check(lib().vsc_hits_merge(ctx._h, C.c_void_p(records_ptr), int(bool(on_device)), ptr(counts), len(counts), n_guides,
+                               C.byref(h)), ctx._h)
     return MergedHits(ctx, h)
 
 

@@ -815,14 +815,18 @@ int vsc_hits_copy(vsc_hits *hits, void *dst, int dst_is_device)
     return VSC_OK;
 }
 
-int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, uint64_t n, uint32_t n_guides,
-                   vsc_hits **out)
+int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, const uint64_t *shard_counts,
+                   uint32_t n_shards, uint32_t n_guides, vsc_hits **out)
 {
     if (!ctx || !out) return VSC_ERR_INVALID;
     *out = nullptr;
     ctx->err.clear();
+    if (!shard_counts || n_shards == 0) return fail(ctx, VSC_ERR_INVALID, "vsc_hits_merge: null argument");
+    std::vector<uint64_t> off(n_shards + 1, 0);
+    for (uint32_t s = 0; s < n_shards; ++s) off[s + 1] = off[s] + shard_counts[s];
+    const uint64_t n = off[n_shards];
     if (n && !records) return fail(ctx, VSC_ERR_INVALID, "vsc_hits_merge: null argument");
-    if (n >= (1ull << 32)) return fail(ctx, VSC_ERR_RANGE, "vsc_hits_merge: more than 2^32 records");
+    if (n_guides >= (1u << 30)) return fail(ctx, VSC_ERR_RANGE, "vsc_hits_merge: too many reads");
     VSC_HIP(ctx, hipSetDevice(ctx->device));
     vsc_hits *hits = new (std::nothrow) vsc_hits();
     if (!hits) return fail(ctx, VSC_ERR_NOMEM, "vsc_hits_merge: out of host memory");
@@ -833,20 +837,15 @@ int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, uin
         *out = hits;
         return VSC_OK;
     }
-    unsigned guide_bits = 1;
-    while (guide_bits < 31 && (1ull << guide_bits) < n_guides) ++guide_bits;
-    const unsigned end_bit = guide_bits + 1;
-    size_t temp_bytes = 0;
-    hipError_t e = merge_temp_bytes(n, end_bit, &temp_bytes);
+    const uint32_t K = 2 * std::max<uint32_t>(n_guides, 1);  // keys guide << 1 | strand
+    const uint64_t nb = (uint64_t)n_shards * (K + 1);
+    hipError_t e = hipSuccess;
     auto step = [&](hipError_t r) {
         if (e == hipSuccess) e = r;
     };
-    // the four 32-bit work arrays reuse the search scratch buffers
-    step(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
-    step(ctx->keys_a.ensure(n * sizeof(uint32_t)));
-    step(ctx->keys_b.ensure(n * sizeof(uint32_t)));
-    step(ctx->vals_a.ensure(n * sizeof(uint32_t)));
-    step(ctx->vals_b.ensure(n * sizeof(uint32_t)));
+    // small work arrays reuse the search scratch buffers
+    step(ctx->keys_b.ensure((nb + n_shards + 1) * sizeof(uint64_t)));
+    step(ctx->vals_b.ensure(((uint64_t)K + 1) * sizeof(uint64_t)));
     step(take_records(ctx, hits, n));
     const vsc_hit *records_dev = (const vsc_hit *)records;
     if (!records_on_device) {
@@ -855,10 +854,13 @@ int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, uin
             step(hipMemcpyAsync(ctx->score_feat.p, records, n * sizeof(vsc_hit), hipMemcpyHostToDevice, ctx->stream));
         records_dev = (const vsc_hit *)ctx->score_feat.p;
     }
+    uint64_t *bound = (uint64_t *)ctx->keys_b.p;
+    uint64_t *shard_off_dev = bound + nb;
+    if (e == hipSuccess)
+        step(hipMemcpyAsync(shard_off_dev, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     step(hipEventRecord(ctx->ev[0], ctx->stream));
-    step(launch_merge(ctx->sort_temp.p, temp_bytes, records_dev, n, end_bit, (uint32_t *)ctx->keys_a.p,
-                      (uint32_t *)ctx->keys_b.p, (uint32_t *)ctx->vals_a.p, (uint32_t *)ctx->vals_b.p, hits->d_records,
-                      ctx->stream));
+    if (e == hipSuccess)
+        step(launch_merge(records_dev, shard_off_dev, n_shards, K, bound, (uint64_t *)ctx->vals_b.p, hits->d_records, ctx->stream));
     step(hipEventRecord(ctx->ev[1], ctx->stream));
     step(hipStreamSynchronize(ctx->stream));
     if (e != hipSuccess) {

@@ -133,8 +133,7 @@ hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted
                              uint32_t *poff, const uint2 *guides, uint2 *list_planes, uint32_t *list_gid,
                              hipStream_t stream);
 hipError_t launch_seed_compare(const SeedArgs &args, int n_groups, bool dense, hipStream_t stream);
-hipError_t merge_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
-hipError_t launch_merge(void *temp, size_t temp_bytes, const vsc_hit *in, uint64_t n, unsigned end_bit, uint32_t *keys_a,
-                        uint32_t *keys_b, uint32_t *idx_a, uint32_t *idx_b, vsc_hit *out, hipStream_t stream);
+hipError_t launch_merge(const vsc_hit *in, const uint64_t *shard_off_dev, uint32_t n_shards, uint32_t K, uint64_t *bound,
+                        uint64_t *key_off, vsc_hit *out, hipStream_t stream);
 
 }  // namespace vsc

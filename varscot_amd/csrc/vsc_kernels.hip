@@ -355,22 +355,76 @@ hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream)
 }
 
 // ------------------------------------------------------------------------------------------------
-// merge of per-shard results: a stable sort of the concatenated records by (guide, strand) restores
-// the global (guide, strand, contig, pos) order, because shards partition the positions in order
+// merge of per-shard results.  Every shard's records are sorted by (guide, strand, contig, pos) and the
+// shards partition the positions in ascending order, so the global order is: for every (guide, strand)
+// key, the key's segment of shard 0, then of shard 1, ...  No sort is needed - three small kernels
+// find the segments, their destinations, and copy them (coalesced 16-byte moves).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void merge_key_kernel(const vsc_hit *in, uint64_t n, uint32_t *keys, uint32_t *idx)
+// bound[s * (K + 1) + k] = first record of shard s whose key (guide << 1 | strand) is >= k
+__global__ __launch_bounds__(256) void merge_bounds_kernel(const vsc_hit *in, const uint64_t *shard_off, uint32_t n_shards,
+                                                           uint32_t K, uint64_t *bound)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    keys[i] = (in[i].guide << 1) | VSC_HIT_STRAND(in[i].info);
-    idx[i] = (uint32_t)i;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n_shards * (K + 1)) return;
+    const uint32_t s = (uint32_t)(t / (K + 1)), k = (uint32_t)(t % (K + 1));
+    uint64_t lo = shard_off[s], hi = shard_off[s + 1];
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const uint32_t key = (in[mid].guide << 1) | VSC_HIT_STRAND(in[mid].info);
+        if (key < k) lo = mid + 1; else hi = mid;
+    }
+    bound[t] = lo;
 }
 
-__global__ __launch_bounds__(256) void gather_kernel(const vsc_hit *in, const uint32_t *idx, uint64_t n, vsc_hit *out)
+// key_off[k] = number of records (all shards) with key < k; one workgroup
+__global__ __launch_bounds__(1024) void merge_scan_kernel(const uint64_t *bound, uint32_t n_shards, uint32_t K, uint64_t *key_off)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    out[i] = in[idx[i]];
+    __shared__ uint64_t partial[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (K + 1023) / 1024;
+    const uint32_t k0 = min(t * per, K), k1 = min(k0 + per, K);
+    uint64_t sum = 0;
+    for (uint32_t k = k0; k < k1; ++k)
+        for (uint32_t s = 0; s < n_shards; ++s) sum += bound[(uint64_t)s * (K + 1) + k + 1] - bound[(uint64_t)s * (K + 1) + k];
+    partial[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint64_t v = t >= d ? partial[t - d] : 0;
+        __syncthreads();
+        partial[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = partial[t] - sum;
+    for (uint32_t k = k0; k < k1; ++k) {
+        key_off[k] = run;
+        for (uint32_t s = 0; s < n_shards; ++s) run += bound[(uint64_t)s * (K + 1) + k + 1] - bound[(uint64_t)s * (K + 1) + k];
+    }
+    if (t == 1023) key_off[K] = partial[1023];
+}
+
+// one workgroup per (key, shard) segment
+__global__ __launch_bounds__(256) void merge_copy_kernel(const vsc_hit *in, const uint64_t *bound, const uint64_t *key_off,
+                                                         uint32_t n_shards, uint32_t K, vsc_hit *out)
+{
+    const uint32_t k = blockIdx.x / n_shards, s = blockIdx.x % n_shards;
+    uint64_t dst = key_off[k];
+    for (uint32_t p = 0; p < s; ++p) dst += bound[(uint64_t)p * (K + 1) + k + 1] - bound[(uint64_t)p * (K + 1) + k];
+    const uint64_t b = bound[(uint64_t)s * (K + 1) + k], e = bound[(uint64_t)s * (K + 1) + k + 1];
+    const uint4 *src = (const uint4 *)in;
+    uint4 *o = (uint4 *)out;
+    for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) o[dst + (i - b)] = src[i];
+}
+
+hipError_t launch_merge(const vsc_hit *in, const uint64_t *shard_off_dev, uint32_t n_shards, uint32_t K, uint64_t *bound,
+                        uint64_t *key_off, vsc_hit *out, hipStream_t stream)
+{
+    const uint64_t nb = (uint64_t)n_shards * (K + 1);
+    hipLaunchKernelGGL(merge_bounds_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, in, shard_off_dev, n_shards,
+                       K, bound);
+    hipLaunchKernelGGL(merge_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint64_t *)bound, n_shards, K, key_off);
+    hipLaunchKernelGGL(merge_copy_kernel, dim3(K * n_shards), dim3(256), 0, stream, in, (const uint64_t *)bound,
+                       (const uint64_t *)key_off, n_shards, K, out);
+    return hipGetLastError();
 }
 
 hipError_t sort32_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes)
@@ -386,22 +440,6 @@ hipError_t launch_sort32(void *temp, size_t temp_bytes, const uint32_t *keys_in,
     if (n == 0) return hipSuccess;
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit,
                                      stream);
-}
-
-hipError_t merge_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes) { return sort32_temp_bytes(n, end_bit, bytes); }
-
-hipError_t launch_merge(void *temp, size_t temp_bytes, const vsc_hit *in, uint64_t n, unsigned end_bit, uint32_t *keys_a,
-                        uint32_t *keys_b, uint32_t *idx_a, uint32_t *idx_b, vsc_hit *out, hipStream_t stream)
-{
-    if (n == 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(merge_key_kernel, dim3(blocks), dim3(256), 0, stream, in, n, keys_a, idx_a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    e = launch_sort32(temp, temp_bytes, keys_a, keys_b, idx_a, idx_b, n, end_bit, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, stream, in, (const uint32_t *)idx_b, n, out);
-    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -65,5 +65,5 @@ def sharded_search(ctx, genome_shard, codes, max_mismatches, extra_pam=None, gro
     if gathered is not None:
         if gathered.is_cuda:
             torch.cuda.current_stream(gathered.device).synchronize()
-        merged = merge_shard_records(ctx, gathered.data_ptr(), gathered.is_cuda, sum(counts), len(codes))
+        merged = merge_shard_records(ctx, gathered.data_ptr(), gathered.is_cuda, counts, len(codes))
     return merged, hits
