@@ -237,6 +237,30 @@ void vsc_unpack_features(const uint32_t *packed, uint64_t n, uint8_t *features);
 int vsc_score_pairs(vsc_ctx *ctx, const uint64_t *on_targets, const uint64_t *off_targets, const uint32_t *masks,
                     uint64_t n, double *mit, uint8_t *mit_flags, uint8_t *features);
 
+/* ---- classifier ---------------------------------------------------------------------------------- */
+/*
+ * A trained random forest as randomForest stores it ($forest of the object in
+ * classification/rfClassifier.RData), numeric splits only, two classes ("0", "1").  All arrays have
+ * n_trees * n_nodes entries, tree-major.  feature[] = column of the dense feature row the node
+ * tests (0..441, or 442 = the on-target activity).
+ */
+typedef struct {
+    uint32_t n_trees, n_nodes;
+    const int8_t *node_status;  /* 1 = split node, -1 = terminal */
+    const uint16_t *feature;
+    const uint16_t *left, *right; /* 1-based daughter nodes */
+    const double *split;        /* x <= split goes left */
+    const uint8_t *node_class;  /* terminal nodes: 1 = class "0", 2 = class "1" */
+} vsc_rf_model;
+/*
+ * predict(rfClassifier, featureMatrix[, type = "prob"]) of classification/classificationPipeline.R:27-34
+ * for n feature rows (dense 442-byte rows as vsc_score_hits / vsc_score_pairs produce them, plus the
+ * on-target activity of each row): prob = share of trees voting class "1", cls = 1 if that share is
+ * above one half, tie = 1 where the vote is exactly split (R breaks such ties at random).
+ */
+int vsc_rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *features, const double *activity, uint64_t n,
+                   double *prob, uint8_t *cls, uint8_t *tie);
+
 /* ---- host-side formatting helpers (no device needed) ------------------------------------------ */
 /*
  * Order in which read_mapping/bidir_mapping.cpp:167-187 writes the records of one search result

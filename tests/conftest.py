@@ -17,6 +17,7 @@ def _ensure_built():
             os.path.join(ROOT, "varscot_amd", "bin", "vcf_loader"),
             os.path.join(ROOT, "varscot_amd", "bin", "bam_merger"),
             os.path.join(ROOT, "varscot_amd", "bin", "fasta_writer"),
+            os.path.join(ROOT, "varscot_amd", "bin", "classification_pipeline"),
             os.path.join(ROOT, "varscot_amd", "bin", "bam_merger_ref_only"),
             os.path.join(ROOT, "oracle", "libvsc_oracle.so")]
     if not all(os.path.exists(p) for p in need):

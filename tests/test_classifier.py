@@ -1,0 +1,77 @@
+"""Random-forest inference: vsc_rf_predict against the pure-Python
+restatement of randomForest's predict, a statistical check against the reference's own training
+labels (parity is unpinned: no R, only out-of-bag votes are stored), and the drop-in tool."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import varscot_amd as va
+from varscot_amd.classifier import Forest, feature_names
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODEL = os.path.join(ROOT, "varscot_amd", "models", "rfClassifier.vscrf")
+
+
+def test_model_file_and_feature_names(golden_dir):
+    f = Forest(MODEL)
+    assert (f.n_trees, f.n_nodes, len(f.names)) == (1000, 275, 80)
+    assert "ontargetActivity" in f.names and "seedMismatches" in f.names
+    g = np.load(os.path.join(golden_dir, "features_golden.npz"))
+    assert feature_names() == list(g["names"]) + ["ontargetActivity"]
+    # every split node tests a valid column and has two daughters inside the tree
+    split = f.status == 1
+    assert f.feature[split].max() <= 442 and f.left[split].min() >= 1 and f.right[split].max() <= 275
+
+
+@pytest.mark.gpu
+def test_rf_predict_matches_restatement_and_training_labels(golden_dir):
+    from oracle.rf_oracle import Forest as OracleForest
+    ctx = va.Context(0)
+    t = np.load(os.path.join(golden_dir, "rf_training.npz"))
+    names, x, y = list(t["names"]), t["x"], t["y"]
+    assert names == feature_names()
+    feats = x[:, :442].astype(np.uint8)
+    act = x[:, 442].astype(np.float64)
+    prob, cls, tie = Forest(MODEL).predict(ctx, feats, act)
+    of = OracleForest(MODEL)
+    for i in range(0, len(x), 5):  # every 5th row through the Python restatement: identical votes
+        p, c, ti = of.predict(dict(zip(names, x[i])))
+        assert prob[i] == p and cls[i] == c and bool(tie[i]) == ti
+    # the forest reproduces the labels it was grown on (in-bag fit); reversing the split direction
+    # would not - this is the statistical anchor of an otherwise unpinned stage
+    assert (cls == y).mean() > 0.95
+    # out-of-bag votes of the reference are a noisier estimate of the same quantity
+    oob = t["oob_votes"][:, 1]
+    assert np.corrcoef(prob, oob)[0, 1] > 0.8
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_classification_pipeline_tool(tmp_path, golden_dir):
+    """TSV + feature file in, TSV with the Score column replaced out (classificationPipeline.R:36-48)."""
+    from oracle.rf_oracle import Forest as OracleForest
+    t = np.load(os.path.join(golden_dir, "rf_training.npz"))
+    names, x = list(t["names"]), t["x"][:40]
+    with open(tmp_path / "feat.txt", "w") as f:
+        f.write("\t".join(names) + "\n")
+        for i, row in enumerate(x):
+            f.write("t_%d\t" % (i + 1) + "".join("%d\t" % v for v in row[:442]) + "%g\n" % row[442])
+    tsv_rows = ["chr1\t%d\t%d\tt_%d\t.\t+\tACGTACGTACGTACGTACGTAGG\t2\t3,7\tREF" % (100 * i, 100 * i + 23, i + 1) for i in range(40)]
+    header = "#Chr\tStart\tEnd\tTargetsite\tScore\tStrand\tSequence\tMismatch_Number\tMismatch_Positions\tVariants"
+    of = OracleForest(MODEL)
+    for flag in ("TRUE", "FALSE"):
+        (tmp_path / "out.txt").write_text("\n".join([header] + tsv_rows) + "\n")
+        r = subprocess.run([os.path.join(ROOT, "varscot_amd", "bin", "classification_pipeline"), str(tmp_path / "out.txt"),
+                            str(tmp_path / "feat.txt"), flag], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        lines = (tmp_path / "out.txt").read_text().splitlines()
+        assert lines[0] == header.replace("Targetsite", "Name")  # the R script renames the column (:39,43)
+        for i, line in enumerate(lines[1:]):
+            row = dict(zip(names, [float("%g" % v) if k == 442 else v for k, v in enumerate(x[i])]))
+            p, c, _ = of.predict(row)
+            want = ("%.15g" % p) if flag == "TRUE" else str(c)
+            assert line.split("\t")[4] == want
+            assert line.split("\t")[:4] == tsv_rows[i].split("\t")[:4]
+    assert subprocess.run([os.path.join(ROOT, "varscot_amd", "bin", "classification_pipeline")], capture_output=True).returncode == 1

@@ -162,6 +162,14 @@ def test_driver_end_to_end(scenario, tmp_path):
         names = [l.split("\t")[3] for l in lines[1:]]
         assert names == sorted(names) and len(names) > 20
         assert not (tmp_path / "tmp").exists()  # temp dir removed unless -v
+    # -e prob: the random forest replaces the MIT score (classification_pipeline on the GPU)
+    out = tmp_path / "res_prob.txt"
+    r = subprocess.run(["bash", driver, "-b", str(d / "targets.bed"), "-o", str(out), "-g", str(d / "genome.fa"), "-i",
+                        str(tmp_path / "idx"), "-m", "5", "-T", str(tmp_path / "tmp"), "-a", str(d / "activity.txt"), "-e", "prob"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    scores = [float(l.split("\t")[4]) for l in out.read_text().splitlines()[1:]]
+    assert len(scores) > 20 and all(0.0 <= s <= 1.0 for s in scores)
     r = subprocess.run(["bash", driver, "-b", "x.bed", "-o", "o.txt", "-g", "g.fa", "-i", "i", "-m", "9", "-T", str(tmp_path / "t2")],
                        capture_output=True, text=True)
     assert r.returncode == 2 and "between 0 and 8" in r.stdout

@@ -29,6 +29,11 @@ class SearchParams(C.Structure):
 ALGO_AUTO, ALGO_SCAN, ALGO_SEED = 0, 1, 2
 
 
+class RfModel(C.Structure):
+    _fields_ = [("n_trees", C.c_uint32), ("n_nodes", C.c_uint32), ("node_status", C.c_void_p), ("feature", C.c_void_p),
+                ("left", C.c_void_p), ("right", C.c_void_p), ("split", C.c_void_p), ("node_class", C.c_void_p)]
+
+
 class Timing(C.Structure):
     _fields_ = [("scan_ms", C.c_double), ("prep_ms", C.c_double), ("sort_ms", C.c_double),
                 ("finalize_ms", C.c_double), ("score_ms", C.c_double), ("total_ms", C.c_double),
@@ -71,6 +76,7 @@ SYMBOLS = [
     ("vsc_score_hits_packed", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
     ("vsc_unpack_features", None, [_vp, C.c_uint64, _vp]),
     ("vsc_score_pairs", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    ("vsc_rf_predict", C.c_int, [_vp, C.POINTER(RfModel), _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     ("vsc_sam_order", None, [_vp, C.c_uint64, _vp, _vp]),
 ]
 

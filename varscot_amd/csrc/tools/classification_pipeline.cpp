@@ -1,0 +1,172 @@
+// classification_pipeline - drop-in for `Rscript classificationPipeline.R OUT.txt FEATURES.txt TRUE|FALSE`
+// (VARSCOT_pipeline/classification/classificationPipeline.R:21-51): reads the feature matrix the
+// merger wrote, predicts every row with the reference's trained random forest on the GPU
+// (vsc_rf_predict) and overwrites the Score column of the TSV with the probability of class "1"
+// (TRUE) or the class (FALSE), as write.table(quote=FALSE, sep="\t", row.names=FALSE) formats it.
+// Model: $VARSCOT_RF_MODEL or <dir of this tool>/../models/rfClassifier.vscrf (the forest of
+// classification/rfClassifier.RData, exported by tests/golden/export_rf_model.py).
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <unistd.h>
+
+#include "merge_host.hpp"
+
+struct Forest {
+    uint32_t n_trees = 0, n_nodes = 0;
+    std::vector<std::string> names;
+    std::vector<int8_t> status;
+    std::vector<uint8_t> best_var, node_class;
+    std::vector<uint16_t> left, right, feature;
+    std::vector<double> split;
+};
+
+static Forest load_forest(const std::string &path)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in) throw std::runtime_error("Error: could not open the classifier " + path);
+    char magic[8];
+    uint32_t hdr[3];
+    in.read(magic, 8);
+    in.read((char *)hdr, 12);
+    if (!in || std::memcmp(magic, "VSCRF001", 8) != 0) throw std::runtime_error("Error: " + path + " is not a forest file");
+    Forest f;
+    f.n_trees = hdr[0];
+    f.n_nodes = hdr[1];
+    f.names.resize(hdr[2]);
+    for (auto &n : f.names) {
+        uint16_t l = 0;
+        in.read((char *)&l, 2);
+        n.resize(l);
+        in.read(&n[0], l);
+    }
+    const size_t n = (size_t)f.n_trees * f.n_nodes;
+    f.status.resize(n), f.best_var.resize(n), f.left.resize(n), f.right.resize(n), f.split.resize(n), f.node_class.resize(n);
+    in.read((char *)f.status.data(), n);
+    in.read((char *)f.best_var.data(), n);
+    in.read((char *)f.left.data(), 2 * n);
+    in.read((char *)f.right.data(), 2 * n);
+    in.read((char *)f.split.data(), 8 * n);
+    in.read((char *)f.node_class.data(), n);
+    if (!in) throw std::runtime_error("Error: truncated forest file " + path);
+    return f;
+}
+
+static std::vector<std::string> split_tabs(const std::string &line)
+{
+    std::vector<std::string> f;
+    size_t b = 0;
+    for (;;) {
+        size_t e = line.find('\t', b);
+        f.push_back(line.substr(b, e == std::string::npos ? std::string::npos : e - b));
+        if (e == std::string::npos) break;
+        b = e + 1;
+    }
+    return f;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 4) {
+        std::cerr << "Error: Wrong number of arguments supplied. Arguments must be offtarget path (pipeline output), "
+                     "feature matrix path and probability (true/false).\n";
+        return 1;
+    }
+    try {
+        const bool prob = std::string(argv[3]) == "TRUE" || std::string(argv[3]) == "true" || std::string(argv[3]) == "T";
+        std::string model = std::getenv("VARSCOT_RF_MODEL") ? std::getenv("VARSCOT_RF_MODEL") : "";
+        if (model.empty()) {
+            char exe[4096];
+            ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+            std::string dir = n > 0 ? std::string(exe, (size_t)n) : std::string(argv[0]);
+            dir = dir.substr(0, dir.find_last_of('/'));
+            model = dir + "/../models/rfClassifier.vscrf";
+        }
+        Forest forest = load_forest(model);
+
+        // feature matrix: header with 443 names, then row name + 442 integers + activity
+        std::ifstream fin(argv[2]);
+        if (!fin) throw std::runtime_error(std::string("Error: cannot open file '") + argv[2] + "'");
+        std::string line;
+        std::getline(fin, line);
+        const auto header = split_tabs(line);
+        std::map<std::string, size_t> col;
+        for (size_t i = 0; i < header.size(); ++i) col[header[i]] = i;
+        if (header.size() != VSC_N_FEATURES + 1 || !col.count("ontargetActivity"))
+            throw std::runtime_error("Error: the feature matrix does not have the 443 expected columns");
+        const auto names = vsc_merge::feature_names();
+        forest.feature.assign(forest.status.size(), 0);
+        std::vector<uint16_t> col_of_var(forest.names.size());
+        for (size_t v = 0; v < forest.names.size(); ++v) {
+            size_t c = 0;
+            while (c < names.size() && names[c] != forest.names[v]) ++c;
+            if (c == names.size() || !col.count(forest.names[v])) throw std::runtime_error("Error: variables in the training data missing in newdata");
+            col_of_var[v] = (uint16_t)c;
+        }
+        for (size_t i = 0; i < forest.status.size(); ++i)
+            if (forest.best_var[i]) forest.feature[i] = col_of_var[forest.best_var[i] - 1];
+        std::vector<uint8_t> feat;
+        std::vector<double> act;
+        while (std::getline(fin, line)) {
+            if (line.empty()) continue;
+            const auto f = split_tabs(line);
+            if (f.size() != VSC_N_FEATURES + 2) throw std::runtime_error("Error: malformed feature matrix row");
+            for (int k = 0; k < VSC_N_FEATURES; ++k) feat.push_back((uint8_t)std::strtoul(f[1 + k].c_str(), nullptr, 10));
+            act.push_back(std::strtod(f[VSC_N_FEATURES + 1].c_str(), nullptr));
+        }
+        const size_t n = act.size();
+
+        // the TSV: read.table(header = FALSE) skips the '#' header line as a comment
+        std::ifstream tin(argv[1]);
+        if (!tin) throw std::runtime_error(std::string("Error: cannot open file '") + argv[1] + "'");
+        std::vector<std::vector<std::string>> rows;
+        while (std::getline(tin, line)) {
+            if (line.empty() || line[0] == '#') continue;
+            rows.push_back(split_tabs(line));
+        }
+        tin.close();
+        if (rows.size() != n) throw std::runtime_error("Error: replacement has a different number of rows than the data");
+
+        std::vector<double> p(n);
+        std::vector<uint8_t> cls(n), tie(n);
+        if (n) {
+            vsc_ctx *ctx = nullptr;
+            int st = vsc_ctx_create(0, &ctx);
+            if (st != VSC_OK) throw std::runtime_error(st == VSC_ERR_NODEVICE ? "Error: no HIP device available (there is no CPU fallback)." : "Error: could not create the device context.");
+            vsc_rf_model m{forest.n_trees, forest.n_nodes, forest.status.data(), forest.feature.data(), forest.left.data(),
+                           forest.right.data(), forest.split.data(), forest.node_class.data()};
+            st = vsc_rf_predict(ctx, &m, feat.data(), act.data(), n, p.data(), cls.data(), tie.data());
+            const std::string err = st == VSC_OK ? "" : vsc_last_error(ctx);
+            vsc_ctx_destroy(ctx);
+            if (st != VSC_OK) throw std::runtime_error("Error: " + err);
+        }
+        std::ofstream out(argv[1]);
+        if (!out) throw std::runtime_error(std::string("Error: cannot open file '") + argv[1] + "'");
+        const size_t ncol = rows.empty() ? 9 : rows[0].size();
+        out << "#Chr\tStart\tEnd\tName\tScore\tStrand\tSequence\tMismatch_Number\tMismatch_Positions" << (ncol == 10 ? "\tVariants\n" : "\n");
+        char buf[64];
+        for (size_t i = 0; i < n; ++i) {
+            auto &r = rows[i];
+            if (r.size() < 5) continue;
+            if (prob) {
+                std::snprintf(buf, sizeof buf, "%.15g", p[i]);
+                r[4] = buf;
+            } else {
+                r[4] = cls[i] ? "1" : "0";  // an exact 500/500 vote (R: random) is reported as "0"
+            }
+            for (size_t k = 0; k < r.size(); ++k) out << (k ? "\t" : "") << r[k];
+            out << "\n";
+        }
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

@@ -1030,4 +1030,54 @@ int vsc_score_hits_packed(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits
     return VSC_OK;
 }
 
+int vsc_rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *features, const double *activity, uint64_t n,
+                   double *prob, uint8_t *cls, uint8_t *tie)
+{
+    if (!ctx) return VSC_ERR_INVALID;
+    ctx->err.clear();
+    if (!model || !model->node_status || !model->feature || !model->left || !model->right || !model->split ||
+        !model->node_class || model->n_trees == 0 || model->n_nodes == 0 || (n && (!features || !activity)))
+        return fail(ctx, VSC_ERR_INVALID, "vsc_rf_predict: null or empty argument");
+    if (n == 0) return VSC_OK;
+    const size_t nn = (size_t)model->n_trees * model->n_nodes;
+    std::vector<RfNode> nodes(nn);
+    for (size_t i = 0; i < nn; ++i) {
+        RfNode &d = nodes[i];
+        d.split = model->split[i];
+        d.feature = model->feature[i];
+        d.left = model->left[i];
+        d.right = model->right[i];
+        d.status = model->node_status[i];
+        d.node_class = model->node_class[i];
+        if (d.status != 1) d.status = -1;  // unused slots behind a tree's last node are never reached
+        if (d.status == 1 && (d.feature > VSC_N_FEATURES || d.left == 0 || d.right == 0 || d.left > model->n_nodes ||
+                               d.right > model->n_nodes))
+            return fail(ctx, VSC_ERR_INVALID, "vsc_rf_predict: malformed forest (feature or daughter index out of range)");
+    }
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    VSC_HIP(ctx, ctx->score_feat.ensure(n * VSC_N_FEATURES));
+    VSC_HIP(ctx, ctx->score_mit.ensure(n * sizeof(double)));
+    VSC_HIP(ctx, ctx->score_flags.ensure(n * sizeof(uint32_t)));
+    VSC_HIP(ctx, ctx->guides.ensure(nn * sizeof(RfNode)));
+    VSC_HIP(ctx, hipMemcpyAsync(ctx->guides.p, nodes.data(), nn * sizeof(RfNode), hipMemcpyHostToDevice, ctx->stream));
+    VSC_HIP(ctx, hipMemcpyAsync(ctx->score_feat.p, features, n * VSC_N_FEATURES, hipMemcpyHostToDevice, ctx->stream));
+    VSC_HIP(ctx, hipMemcpyAsync(ctx->score_mit.p, activity, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VSC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    VSC_HIP(ctx, launch_rf_predict((const RfNode *)ctx->guides.p, model->n_trees, model->n_nodes, (const uint8_t *)ctx->score_feat.p,
+                                   (const double *)ctx->score_mit.p, n, (uint32_t *)ctx->score_flags.p, ctx->stream));
+    VSC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    std::vector<uint32_t> votes(n);
+    VSC_HIP(ctx, hipMemcpyAsync(votes.data(), ctx->score_flags.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint64_t i = 0; i < n; ++i) {
+        if (prob) prob[i] = (double)votes[i] / (double)model->n_trees;  // type = "prob": votes / ntree
+        if (cls) cls[i] = 2 * votes[i] > model->n_trees;
+        if (tie) tie[i] = 2 * votes[i] == model->n_trees;
+    }
+    float ms = 0;
+    VSC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timing.score_ms = ms;
+    return VSC_OK;
+}
+
 }  // extern "C"

@@ -106,12 +106,23 @@ struct SeedArgs {
                                    // kCntSites (= pairs compared), kCntVisited, kCntOverflow
 };
 
+// One node of a random-forest tree, 16 bytes: a node visit is one load.
+struct RfNode {
+    double split;
+    uint16_t feature;  // column of the feature row; VSC_N_FEATURES = the on-target activity
+    uint16_t left, right;  // 1-based daughters
+    int8_t status;     // 1 split, -1 terminal
+    uint8_t node_class;  // terminal: 1 = class "0", 2 = class "1"
+};
+
 // Launch wrappers implemented in vsc_kernels.hip.  They only enqueue work on `stream`.
 hipError_t launch_scan(const ScanArgs &args, int n_groups, bool extract, hipStream_t stream);
 hipError_t sort_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
 hipError_t launch_sort(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
                        const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream);
 hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream);
+hipError_t launch_rf_predict(const RfNode *nodes, uint32_t n_trees, uint32_t n_nodes, const uint8_t *features,
+                             const double *activity, uint64_t n, uint32_t *votes_out, hipStream_t stream);
 hipError_t launch_interleave(const uint32_t *hi, const uint32_t *lo, uint64_t n, uint2 *hl, hipStream_t stream);
 hipError_t launch_score(const ScoreArgs &args, hipStream_t stream);
 hipError_t launch_score_packed(const ScoreArgs &args, uint4 *packed, hipStream_t stream);

@@ -677,4 +677,44 @@ hipError_t launch_score(const ScoreArgs &args, hipStream_t stream)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// random-forest inference (classification/classificationPipeline.R:27-34, randomForest's classForest):
+// one thread per feature row walks every tree: x[var] <= split ? left : right until a terminal node
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rf_predict_kernel(const RfNode *nodes, uint32_t n_trees, uint32_t n_nodes,
+                                                        const uint8_t *features, const double *activity, uint64_t n,
+                                                        uint32_t *votes_out)
+{
+    __shared__ uint8_t rows[64][VSC_N_FEATURES + 6];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    if (live)
+        for (int k = 0; k < VSC_N_FEATURES; ++k) rows[threadIdx.x][k] = features[i * VSC_N_FEATURES + k];
+    const double act = live ? activity[i] : 0.0;
+    if (!live) return;
+    const uint8_t *x = rows[threadIdx.x];
+    uint32_t ones = 0;
+    for (uint32_t t = 0; t < n_trees; ++t) {
+        const RfNode *tree = nodes + (size_t)t * n_nodes;
+        uint32_t k = 0;
+        RfNode nd = tree[0];
+        while (nd.status != -1) {
+            const double v = nd.feature == VSC_N_FEATURES ? act : (double)x[nd.feature];
+            k = (v <= nd.split ? nd.left : nd.right) - 1u;
+            nd = tree[k];
+        }
+        ones += nd.node_class == 2;
+    }
+    votes_out[i] = ones;
+}
+
+hipError_t launch_rf_predict(const RfNode *nodes, uint32_t n_trees, uint32_t n_nodes, const uint8_t *features,
+                             const double *activity, uint64_t n, uint32_t *votes_out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rf_predict_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, nodes, n_trees, n_nodes, features,
+                       activity, n, votes_out);
+    return hipGetLastError();
+}
+
 }  // namespace vsc
