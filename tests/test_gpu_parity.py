@@ -406,3 +406,22 @@ def test_shard_merge_kernels(ctx, oracle, world):
     want = oracle.search_fast(contigs, guides, 6)
     assert len(want) > 200
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("low_bits", ["0", "3", "8", None])
+@pytest.mark.parametrize("algo", ALGOS)
+def test_low_position_bits_left_to_finalize(ctx, oracle, algo, low_bits, monkeypatch):
+    """The sort skips the low position bits and finalize ranks each group of neighbours: homopolymer
+    runs give one read a hit at EVERY position, i.e. full groups of 2^low_bits records, also across the
+    256-record blocks of the kernel; VSC_SORT_LOW_BITS=0 is the plain full-key sort."""
+    if low_bits is None:
+        monkeypatch.delenv("VSC_SORT_LOW_BITS", raising=False)
+    else:
+        monkeypatch.setenv("VSC_SORT_LOW_BITS", low_bits)
+    rng = np.random.default_rng(77)
+    guides = ["G" * 23, "C" * 23, "G" * 11 + "A" + "G" * 11] + random_guides(rng, 5)
+    contigs = ["G" * 1500 + random_seq(rng, 300) + "C" * 900, random_seq(rng, 2000), "G" * 700]
+    want = oracle.search(contigs, guides, 3, None, mode=oracle.MODE_PREDICATE)
+    got = gpu_search(ctx, contigs, guides, 3, None, algo=algo)
+    assert len(want) > 5000
+    assert hits_as_tuples(got) == hits_as_tuples(want)

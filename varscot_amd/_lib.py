@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvarscot_hip.so")
+LIB_PATH = os.environ.get("VSC_LIB_PATH") or os.path.join(_HERE, "libvarscot_hip.so")  # override for A/B experiments
 
 VSC_OK = 0
 ERRORS = {-22: "VSC_ERR_INVALID", -12: "VSC_ERR_NOMEM", -5: "VSC_ERR_DEVICE", -34: "VSC_ERR_RANGE",

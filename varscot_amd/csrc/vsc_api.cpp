@@ -671,7 +671,9 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         sa.contig_end = genome->d_contig_end;
         sa.n_contigs = genome->n_contigs;
         sa.counters = (unsigned long long *)ctx->counters.p;
-        const uint32_t n_waves_max = (uint32_t)ctx->n_cus * 5 * kWavesPerGroup;
+        uint32_t groups_per_cu = 5;
+        if (const char *o = std::getenv("VSC_SEED_GROUPS_PER_CU")) groups_per_cu = (uint32_t)std::max(1, std::atoi(o));
+        const uint32_t n_waves_max = (uint32_t)ctx->n_cus * groups_per_cu * kWavesPerGroup;
         const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, (sa.n_chunks + kSeedGrab - 1) / kSeedGrab));
         n_groups = (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
         // block of records a wave reserves per atomic: large when many hits are expected, small otherwise
@@ -732,9 +734,14 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     if (n > 0) {
         unsigned guide_bits = 1;
         while (guide_bits < 31 && (1ull << guide_bits) < n_guides) ++guide_bits;
-        const unsigned end_bit = 33 + guide_bits + (n_sort != n ? 1 : 0);  // one more bit separates the sentinels
+        // sentinels (all ones) must sort behind every real key: one more bit when the all-ones guide id is in use
+        const unsigned end_bit = 33 + guide_bits + ((n_sort != n && n_guides == (1ull << guide_bits)) ? 1 : 0);
+        // the sort costs one pass over all pairs per 8 key bits: leave out the low position bits that
+        // make up the odd digit (<= 8 bits, a whole pass) and let finalize_kernel order those groups
+        unsigned begin_bit = end_bit > 16 ? end_bit - 8 * ((end_bit + 7) / 8 - 1) : 0;
+        if (const char *o = std::getenv("VSC_SORT_LOW_BITS")) begin_bit = std::min(8u, (unsigned)std::atoi(o));
         size_t temp_bytes = 0;
-        VSC_HIP_H(sort_temp_bytes(n_sort, end_bit, &temp_bytes));
+        VSC_HIP_H(sort_temp_bytes(n_sort, begin_bit, end_bit, &temp_bytes));
         VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
         VSC_HIP_H(ctx->keys_b.ensure(n_sort * sizeof(uint64_t)));
         VSC_HIP_H(ctx->vals_b.ensure(n_sort * sizeof(uint32_t)));
@@ -742,12 +749,13 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         VSC_HIP_H(take_records(ctx, hits, n));
         ht.lap("record storage");
         VSC_HIP_H(launch_sort(ctx->sort_temp.p, temp_bytes, (const uint64_t *)ctx->keys_a.p, (uint64_t *)ctx->keys_b.p,
-                              (const uint32_t *)ctx->vals_a.p, (uint32_t *)ctx->vals_b.p, n_sort, end_bit, ctx->stream));
+                              (const uint32_t *)ctx->vals_a.p, (uint32_t *)ctx->vals_b.p, n_sort, begin_bit, end_bit, ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
         FinalizeArgs f{};
         f.keys = (const uint64_t *)ctx->keys_b.p;
         f.vals = (const uint32_t *)ctx->vals_b.p;
         f.n = n;
+        f.low_bits = begin_bit;
         f.contig_off = genome->d_contig_off;
         f.n_contigs = genome->n_contigs;
         f.out = hits->d_records;

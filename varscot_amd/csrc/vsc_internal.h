@@ -68,6 +68,7 @@ struct FinalizeArgs {
     const uint64_t *keys;
     const uint32_t *vals;
     uint64_t n;
+    uint32_t low_bits;           // key bits [0, low_bits) were left out of the sort (<= 8)
     const uint32_t *contig_off;  // ascending global start positions of all contigs
     uint32_t n_contigs;
     vsc_hit *out;
@@ -117,9 +118,10 @@ struct RfNode {
 
 // Launch wrappers implemented in vsc_kernels.hip.  They only enqueue work on `stream`.
 hipError_t launch_scan(const ScanArgs &args, int n_groups, bool extract, hipStream_t stream);
-hipError_t sort_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
+hipError_t sort_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit, size_t *bytes);
 hipError_t launch_sort(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
-                       const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream);
+                       const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
+                       hipStream_t stream);
 hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream);
 hipError_t launch_rf_predict(const RfNode *nodes, uint32_t n_trees, uint32_t n_nodes, const uint8_t *features,
                              const double *activity, uint64_t n, uint32_t *votes_out, hipStream_t stream);

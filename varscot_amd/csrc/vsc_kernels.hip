@@ -303,18 +303,22 @@ hipError_t launch_scan(const ScanArgs &args, int n_groups, bool extract, hipStre
 // ------------------------------------------------------------------------------------------------
 // sort (rocPRIM radix sort of the 64-bit hit keys with their 32-bit payload)
 // ------------------------------------------------------------------------------------------------
-hipError_t sort_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes)
+hipError_t sort_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit, size_t *bytes)
 {
     *bytes = 0;
     return rocprim::radix_sort_pairs((void *)nullptr, *bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
-                                     (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, end_bit);
+                                     (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, begin_bit, end_bit);
 }
 
+// Sorts on key bits [begin_bit, end_bit).  The library sort moves every pair once per 8-bit digit, so
+// the host drops up to 8 low position bits to save a whole pass; finalize_kernel puts the (few)
+// records that share the remaining bits in order.
 hipError_t launch_sort(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
-                       const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream)
+                       const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
+                       hipStream_t stream)
 {
-    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit,
-                                     stream);
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, begin_bit,
+                                     end_bit, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -330,27 +334,74 @@ __device__ __forceinline__ uint32_t contig_of(const uint32_t *contig_off, uint32
     return lo;
 }
 
-__global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a)
+// The sort left records that agree in key bits [low_bits, 64) adjacent but in arbitrary order.  Such
+// a group holds at most 2^low_bits <= 256 records (keys are unique), so a block stages its 256 keys
+// plus 256 on either side in LDS and every thread ranks its key inside its group: destination =
+// group start + number of smaller keys.  With low_bits = 0 every group is one record.
+constexpr int kFinalizeBlock = 256;
+constexpr int kFinalizeItems = 8;    // records per thread
+constexpr int kFinalizeHalo = 256;   // >= the largest group
+constexpr int kFinalizeTile = kFinalizeBlock * kFinalizeItems;
+constexpr int kFinalizeContigs = 1024;
+
+__global__ __launch_bounds__(kFinalizeBlock) void finalize_kernel(const FinalizeArgs a)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const uint64_t key = a.keys[i];
-    const uint32_t pos = (uint32_t)key;
-    const uint32_t strand = (uint32_t)(key >> 32) & 1u;
-    const uint32_t c = contig_of(a.contig_off, a.n_contigs, pos);
-    vsc_hit h;
-    h.guide = (uint32_t)(key >> 33);
-    h.contig = c;
-    h.pos = pos - a.contig_off[c];
-    h.info = (strand << 31) | a.vals[i];
-    a.out[i] = h;
+    __shared__ uint64_t s_key[kFinalizeTile + 2 * kFinalizeHalo];
+    __shared__ uint32_t s_contig[kFinalizeContigs];  // contig starts: a genome has few, a variant genome millions
+    const bool contigs_staged = a.n_contigs <= (uint32_t)kFinalizeContigs;
+    if (contigs_staged)
+        for (uint32_t t = threadIdx.x; t < a.n_contigs; t += kFinalizeBlock) s_contig[t] = a.contig_off[t];
+    const uint64_t block_first = (uint64_t)blockIdx.x * kFinalizeTile;
+    // tile = records [block_first - halo, block_first + tile + halo); slots outside [0, n) get a key no group shares
+    const int lo = a.low_bits ? 0 : kFinalizeHalo, hi = a.low_bits ? kFinalizeTile + 2 * kFinalizeHalo : kFinalizeHalo + kFinalizeTile;
+    for (int t = lo + threadIdx.x; t < hi; t += kFinalizeBlock) {
+        const uint64_t j = block_first + (uint64_t)t - kFinalizeHalo;  // wraps below zero -> >= n
+        s_key[t] = j < a.n ? a.keys[j] : ~0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kFinalizeItems; ++k) {
+        const int me = kFinalizeHalo + k * kFinalizeBlock + (int)threadIdx.x;
+        const uint64_t i = block_first + (uint64_t)(me - kFinalizeHalo);
+        if (i >= a.n) break;
+        const uint64_t key = s_key[me];
+        uint64_t dst = i;
+        if (a.low_bits) {
+            const uint64_t group = key >> a.low_bits;
+            uint32_t before = 0, smaller = 0;
+            for (int t = me - 1; t >= 0 && (s_key[t] >> a.low_bits) == group; --t) {
+                ++before;
+                smaller += s_key[t] < key;
+            }
+            for (int t = me + 1; t < kFinalizeTile + 2 * kFinalizeHalo && (s_key[t] >> a.low_bits) == group; ++t)
+                smaller += s_key[t] < key;
+            dst = i - before + smaller;
+        }
+        const uint32_t pos = (uint32_t)key;
+        const uint32_t strand = (uint32_t)(key >> 32) & 1u;
+        uint32_t c, start;
+        if (contigs_staged) {
+            c = contig_of(s_contig, a.n_contigs, pos);
+            start = s_contig[c];
+        } else {
+            c = contig_of(a.contig_off, a.n_contigs, pos);
+            start = a.contig_off[c];
+        }
+        vsc_hit h;
+        h.guide = (uint32_t)(key >> 33);
+        h.contig = c;
+        h.pos = pos - start;
+        h.info = (strand << 31) | a.vals[i];
+        a.out[dst] = h;
+    }
 }
 
 hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream)
 {
     if (args.n == 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((args.n + 255) / 256);
-    hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, stream, args);
+    if ((1u << args.low_bits) > (unsigned)kFinalizeHalo) return hipErrorInvalidValue;  // a group must fit the halo
+    const unsigned blocks = (unsigned)((args.n + kFinalizeTile - 1) / kFinalizeTile);
+    hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(kFinalizeBlock), 0, stream, args);
     return hipGetLastError();
 }
 
