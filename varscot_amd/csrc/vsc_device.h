@@ -10,9 +10,10 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh
     return __builtin_amdgcn_alignbit(hi, lo, sh);  // ({hi,lo} >> sh)[31:0], sh in 0..31
 }
 
-__device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
+// base + number of set bits of `mask` below this lane (v_mbcnt adds for free)
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask, uint32_t base = 0u)
 {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, base));
 }
 
 // The four waves of a workgroup never exchange data; lanes of one wave exchange data through their

@@ -82,7 +82,7 @@ __device__ __forceinline__ void emit_hits(const ScanArgs &a, WaveState &w, uint3
     if (b == 0) return;
     uint32_t n = (uint32_t)__popcll(b);
     if (hit) {
-        uint32_t at = w.hn + lanes_below(b);
+        uint32_t at = lanes_below(b, w.hn);
         w.hkey[at] = ((uint64_t)guide << 33) | ((uint64_t)strand << 32) | pos;
         w.hval[at] = (c << 23) | mask;
     }
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void scan_kernel(const ScanA
                 }
                 ph |= ((edge >> b) & 1u) << kSiteEdgeBit;
                 if (has) {
-                    const uint32_t at = w.q + lanes_below(act);
+                    const uint32_t at = lanes_below(act, w.q);
                     w.qx[at] = ph;
                     w.ql[at] = pl;
                     w.qpos[at] = base_pos + b;

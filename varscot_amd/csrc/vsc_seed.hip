@@ -271,8 +271,11 @@ __device__ __forceinline__ void seed_resolve(const SeedArgs &a, SeedWave &w, uin
             const uint32_t gid = a.list_gid[(uint32_t)(tk >> 32)];
             const uint32_t strand = (x >> kSiteStrandBit) & 1u;
             // a pair that also qualifies in an earlier segment was reported there
-            for (uint32_t s = 0; s < seg; ++s)
-                if ((uint32_t)__popc(t & (0x7Fu << (kSegBases * s))) <= a.k_seg) hit = false;
+            // (straight-line on purpose: as a loop over `seg` the compiler unrolls it eightfold on scalars)
+            static_assert(kSegments == 3, "the duplicate test spells out segments 0 and 1");
+            const uint32_t earlier = seg == 0 ? 0u : (seg == 1 ? 0x7Fu : 0x3FFFu);  // bases of the earlier segments
+            if ((uint32_t)__popc(t & earlier & 0x7Fu) <= a.k_seg && seg >= 1) hit = false;
+            if ((uint32_t)__popc(t & earlier & 0x3F80u) <= a.k_seg && seg >= 2) hit = false;
             const uint32_t mask = strand ? reverse23(t) : t;
             // right-edge rule, bidir_mapping.cpp:51-52 (see emit_hits in vsc_kernels.hip)
             if (hit && ((x >> kSiteEdgeBit) & 1u)) {
@@ -285,7 +288,7 @@ __device__ __forceinline__ void seed_resolve(const SeedArgs &a, SeedWave &w, uin
         }
         const uint64_t b = __ballot(hit);
         if (hit) {
-            const uint32_t at = w.hn + lanes_below(b);
+            const uint32_t at = lanes_below(b, w.hn);
             w.hkey[at] = key;
             w.hval[at] = val;
         }
@@ -380,6 +383,10 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(con
             pairs += (unsigned long long)cur.count * (cur.g1 - cur.g0);
             visited += cur.count;
             v4u na = gp[cur.g0 >> 1], nb = gp[(cur.g0 >> 1) + 1];
+            // Scalar loads return out of order, so a wait for the first read group is a wait for ALL
+            // outstanding scalar loads.  Waiting here, once per chunk, keeps that wait out of the loop:
+            // otherwise it lands behind the prefetch of the next group and exposes its latency every time.
+            asm volatile("; first read group ready" ::"s"(na), "s"(nb));
             for (uint32_t g = cur.g0; g < cur.g1; g += kGuideUnroll) {
                 const v4u ga = na, gb = nb;
                 na = gp[(g >> 1) + 2];  // the list is allocated with one spare group
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(con
                             const uint64_t b = __ballot(hit);
                             if (b == 0) continue;
                             if (hit)
-                                w.tok[w.ntok + lanes_below(b)] = ((uint64_t)(g + u) << 32) | lane_bits | ((uint32_t)j << 23) | t;
+                                w.tok[lanes_below(b, w.ntok)] = ((uint64_t)(g + u) << 32) | lane_bits | ((uint32_t)j << 23) | t;
                             w.ntok += (uint32_t)__popcll(b);
                             if (w.ntok > kSeedTokCap - kWave) seed_resolve(a, w, cur.first, cur.seg);
                         }
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(con
                                 const uint64_t b = __ballot(hit);
                                 if (b == 0) continue;
                                 if (hit)
-                                    w.tok[w.ntok + lanes_below(b)] = ((uint64_t)(g + u) << 32) | lane_bits | ((uint32_t)j << 23) | t;
+                                    w.tok[lanes_below(b, w.ntok)] = ((uint64_t)(g + u) << 32) | lane_bits | ((uint32_t)j << 23) | t;
                                 w.ntok += (uint32_t)__popcll(b);
                                 if (w.ntok > kSeedTokCap - kWave) seed_resolve(a, w, cur.first, cur.seg);
                             }
