@@ -337,6 +337,8 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(con
 
     const const_v4u_ptr gp = (const_v4u_ptr)(uintptr_t)a.list_planes;
     const uint32_t m = a.max_mm;
+    uint32_t vm;  // the budget in a VGPR, see the comparison loop
+    asm("v_mov_b32 %0, %1" : "=v"(vm) : "s"(m));
     const uint32_t lane_bits = w.lane << 26;
     unsigned long long pairs = 0, visited = 0;
 
@@ -396,10 +398,16 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(con
                 if (kDense) {
 #pragma unroll
                     for (int u = 0; u < kGuideUnroll; ++u) {
+                        // VALU instructions with an SGPR operand issue at about half the rate of all-VGPR
+                        // ones on gfx950 (profiles/r01_valu_rate_microbench.txt): two copies per read buy
+                        // sixteen full-rate instructions.  The asm keeps the compiler from folding them back.
+                        uint32_t vh, vl;
+                        asm("v_mov_b32 %0, %1" : "=v"(vh) : "s"(gh[u]));
+                        asm("v_mov_b32 %0, %1" : "=v"(vl) : "s"(gl[u]));
 #pragma unroll
                         for (int j = 0; j < kSitesPerLane; ++j) {
-                            const uint32_t t = (sh[j] ^ gh[u]) | (sl[j] ^ gl[u]);
-                            const bool hit = (uint32_t)__popc(t) <= m;
+                            const uint32_t t = (sh[j] ^ vh) | (sl[j] ^ vl);
+                            const bool hit = (uint32_t)__popc(t) <= vm;
                             const uint64_t b = __ballot(hit);
                             if (b == 0) continue;
                             if (hit)
