@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""digest_profiles.py TAG - turn gpurun_out/TAG (tools/collect_profiles.sh) into the committed evidence
+under profiles/: bench lines, kernel statistics, one PMC summary, and scan_traffic.json (the measured HBM
+bytes per launch that bench.py reports as roofline.traffic)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+
+
+def counters(path_glob, kernel_substr):
+    """mean per dispatch of every counter over the dispatches of one kernel (warm-up launch included)"""
+    acc = {}
+    for path in glob.glob(path_glob, recursive=True):
+        per = {}
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if kernel_substr not in row["Kernel_Name"]:
+                    continue
+                per.setdefault((row["Counter_Name"], row["Dispatch_Id"]), 0.0)
+                per[(row["Counter_Name"], row["Dispatch_Id"])] += float(row["Counter_Value"])
+        for (name, _), v in per.items():
+            acc.setdefault(name, []).append(v)
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def kernel_avg_ms(stats_csv, kernel_substr):
+    with open(stats_csv) as f:
+        for row in csv.DictReader(f):
+            if kernel_substr in row["Name"]:
+                return float(row["AverageNs"]) * 1e-6
+    return None
+
+
+summary = {"round": tag, "kernel": "vsc::seed_compare_kernel<true>",
+           "note": "one rocprofv3 --pmc pass per counter group over `python3 bench.py --workload <w> --steps 3 --warmup 1 "
+                   "--no-cpu-baseline` (tools/collect_profiles.sh); FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE counts "
+                   "64 B per 128 B request on gfx950 (MI355X_MICROARCH.md, HBM) and is doubled; averages per launch"}
+traffic_path = os.path.join(dst, "scan_traffic.json")
+traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
+for w in ("c2", "c3"):
+    bench = json.loads(open(os.path.join(src, "bench_%s.json" % w)).read().strip().splitlines()[-1])
+    json.dump(bench, open(os.path.join(dst, "%s_bench_%s_seed.json" % (tag, w)), "w"))
+    stats = glob.glob(os.path.join(src, "stats_%s" % w, "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, "%s_%s_seed_kernel_stats.csv" % (tag, w)))
+    c = {}
+    for grp in ("sq", "fetch", "write"):
+        c.update(counters(os.path.join(src, "pmc_%s_%s" % (grp, w), "**", "*counter_collection.csv"), "seed_compare_kernel"))
+    fetch_raw = c.get("FETCH_SIZE", 0.0) * 1024.0
+    write = c.get("WRITE_SIZE", 0.0) * 1024.0
+    hbm = 2.0 * fetch_raw + write
+    launch_ms = bench["roofline"]["launch_ms"]
+    # GRBM_GUI_ACTIVE is reported once per XCD (8 rows per dispatch, summed above): busy cycles = sum / 8
+    busy = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    simd_cycles = busy * 256 * 4
+    summary[w] = {
+        "counters": c,
+        "derived": {"fetch_bytes_raw": fetch_raw, "fetch_bytes_x2": 2.0 * fetch_raw, "write_bytes": write,
+                    "hbm_traffic_bytes_per_launch": hbm,
+                    "effective_clock_GHz": busy / (launch_ms * 1e-3) / 1e9,
+                    "valu_wave_instr_per_simd_cycle": c.get("SQ_INSTS_VALU", 0.0) / simd_cycles if simd_cycles else None,
+                    "salu_per_valu": c.get("SQ_INSTS_SALU", 0.0) / max(c.get("SQ_INSTS_VALU", 1.0), 1.0),
+                    "wait_any_share_of_wave_cycles": c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0)},
+        "algorithmic_bytes": bench["roofline"]["algorithmic_bytes"], "launch_ms": launch_ms,
+        "rocprof_avg_ms": kernel_avg_ms(stats[0], "seed_compare_kernel") if stats else None,
+        "pairs": bench["config"].get("hits_per_step") and bench["roofline"]["valu"]["pair_compares_per_s"] * launch_ms * 1e-3,
+    }
+    traffic["%s/seed/1" % w] = hbm
+json.dump(summary, open(os.path.join(dst, "%s_seed_pmc.json" % tag), "w"), indent=1)
+json.dump(traffic, open(traffic_path, "w"))
+print(json.dumps({w: summary[w]["derived"] for w in ("c2", "c3")}, indent=1))

@@ -1,0 +1,21 @@
+#!/bin/bash
+# pmc_probe2.sh WORKLOAD "COUNTER LIST" - run on the GPU box: arbitrary counters of the search kernel
+set -e -o pipefail
+W=${1:-c3}; CTR=${2}
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/probe2_$W; rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc $CTR -d "$OUT/a" -o run --output-format csv -- python3 $ROOT/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/a.err"
+python3 - "$OUT" <<'PY'
+import csv, glob, sys
+acc = {}
+for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    per = {}
+    for row in csv.DictReader(open(path)):
+        if "seed_sliced_kernel" in row["Kernel_Name"] or "seed_compare_kernel" in row["Kernel_Name"]:
+            k = (row["Counter_Name"], row["Dispatch_Id"])
+            per[k] = per.get(k, 0.0) + float(row["Counter_Value"])
+    for (n, _), v in per.items():
+        acc.setdefault(n, []).append(v)
+for n, v in sorted(acc.items()):
+    print("%-36s %.4g" % (n, sum(v) / len(v)))
+PY

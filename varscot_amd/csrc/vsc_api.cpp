@@ -71,7 +71,7 @@ struct vsc_ctx {
     std::string err;
     vsc_timing timing{};
     DeviceBuf counters, guides, keys_a, keys_b, vals_a, vals_b, sort_temp, score_mit, score_flags, score_feat;
-    DeviceBuf seed_k1, seed_k2, seed_v1, seed_v2, seed_off, seed_poff, seed_lplanes, seed_lgid;  // per-search read lists
+    DeviceBuf seed_k1, seed_k2, seed_v1, seed_v2, seed_off, seed_poff, seed_lplanes, seed_lgid, seed_lrest;  // per-search read lists
     // record buffers of freed results, kept for the next search: hipMalloc / hipFree of tens of GB
     // cost hundreds of milliseconds each
     std::vector<DeviceBuf> spare_records;
@@ -94,6 +94,8 @@ struct vsc_genome {
     uint2 *d_ix_planes = nullptr;
     uint32_t *d_ix_pos = nullptr, *d_ix_bucket_start = nullptr;
     uint4 *d_ix_chunk_tab = nullptr;
+    uint32_t *d_ix_vert = nullptr;  // bit-sliced blocks of 32 sites (null: index built for the pair kernel)
+    uint4 *d_ix_sites = nullptr;    // sliced kernel: 16-byte site records (then d_ix_planes / d_ix_pos are released)
     uint32_t ix_chunks = 0;
     uint64_t index_bytes = 0;
     double index_ms = 0;
@@ -254,7 +256,7 @@ int vsc_ctx_destroy(vsc_ctx *ctx)
     for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->vals_b,
                          &ctx->sort_temp, &ctx->score_mit, &ctx->score_flags, &ctx->score_feat, &ctx->seed_k1,
                          &ctx->seed_k2, &ctx->seed_v1, &ctx->seed_v2, &ctx->seed_off, &ctx->seed_poff,
-                         &ctx->seed_lplanes, &ctx->seed_lgid})
+                         &ctx->seed_lplanes, &ctx->seed_lgid, &ctx->seed_lrest})
         b->release();
     for (auto &b : ctx->spare_records) b.release();
     for (auto &e : ctx->ev)
@@ -354,7 +356,8 @@ int vsc_genome_free(vsc_genome *g)
     if (!g) return VSC_OK;
     if (g->ctx) (void)hipSetDevice(g->ctx->device);
     for (void *p : {(void *)g->d_hi, (void *)g->d_lo, (void *)g->d_nm, (void *)g->d_contig_off, (void *)g->d_contig_end, (void *)g->d_hl,
-                    (void *)g->d_ix_planes, (void *)g->d_ix_pos, (void *)g->d_ix_bucket_start, (void *)g->d_ix_chunk_tab})
+                    (void *)g->d_ix_planes, (void *)g->d_ix_pos, (void *)g->d_ix_bucket_start, (void *)g->d_ix_chunk_tab,
+                    (void *)g->d_ix_vert, (void *)g->d_ix_sites})
         if (p) (void)hipFree(p);
     delete g;
     return VSC_OK;
@@ -404,9 +407,18 @@ int scan_groups(const vsc_ctx *ctx, uint32_t n_tiles)
     return (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
 }
 
+// VSC_SEED_KERNEL=pairs selects the per-pair comparison kernel (chunks of 512 sites, no bit-sliced
+// copy of the sites) for experiments; the default is the bit-sliced kernel.
+bool use_sliced_kernel()
+{
+    const char *o = std::getenv("VSC_SEED_KERNEL");
+    return !(o && std::strcmp(o, "pairs") == 0);
+}
+
 bool index_matches(const vsc_genome *g, const vsc_search_params *p)
 {
     if (!g->has_index) return false;
+    if (use_sliced_kernel() != (g->d_ix_vert != nullptr)) return false;
     const bool want = p && p->has_extra_pam && base_code(p->extra_pam[0]) < 4 && base_code(p->extra_pam[1]) < 4;
     if (want != (g->index_has_extra_pam != 0)) return false;
     return !want || (base_code(p->extra_pam[0]) == base_code(g->index_extra_pam[0]) &&
@@ -416,7 +428,7 @@ bool index_matches(const vsc_genome *g, const vsc_search_params *p)
 void free_index(vsc_genome *g)
 {
     for (void **p : {(void **)&g->d_ix_planes, (void **)&g->d_ix_pos, (void **)&g->d_ix_bucket_start,
-                     (void **)&g->d_ix_chunk_tab}) {
+                     (void **)&g->d_ix_chunk_tab, (void **)&g->d_ix_vert, (void **)&g->d_ix_sites}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -493,26 +505,45 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         free_index(g);
         return e;
     }
-    // chunks: at most kBatch sites of one bucket each
-    std::vector<uint32_t> ctab;  // {first site, site count, bucket, 0} per chunk
-    ctab.reserve(4 * (3 * S / kBatch + kBuckets));
+    // chunks: at most kSlicedChunk sites of one bucket each (kBatch for the pair kernel); the sites of a
+    // chunk also exist bit-sliced, in blocks of 32, from block `vfirst` on
+    const bool sliced = use_sliced_kernel();
+    const uint64_t chunk_sites = sliced ? kSlicedChunk : kBatch;
+    std::vector<uint32_t> ctab;  // {first site, site count, bucket, first vertical block} per chunk
+    ctab.reserve(4 * (3 * S / chunk_sites + kBuckets));
+    uint64_t n_blocks = 0;
     for (uint32_t b = 0; b < (uint32_t)kBuckets; ++b)
-        for (uint64_t p = bs[b]; p < bs[b + 1]; p += kBatch) {
+        for (uint64_t p = bs[b]; p < bs[b + 1]; p += chunk_sites) {
+            const uint64_t count = std::min<uint64_t>(chunk_sites, bs[b + 1] - p);
             ctab.push_back((uint32_t)p);
-            ctab.push_back((uint32_t)std::min<uint64_t>(kBatch, bs[b + 1] - p));
+            ctab.push_back((uint32_t)count);
             ctab.push_back(b);
-            ctab.push_back(0);
+            ctab.push_back((uint32_t)n_blocks);
+            n_blocks += (count + kSlicedSites - 1) / kSlicedSites;
         }
     g->ix_chunks = (uint32_t)(ctab.size() / 4);
     const size_t cb = std::max<size_t>(ctab.size(), 4) * sizeof(uint32_t);
+    const size_t vb = sliced ? std::max<uint64_t>(n_blocks, 1) * 2 * kRestBases * sizeof(uint32_t) : 0;
     step(hipMalloc((void **)&g->d_ix_chunk_tab, cb));
     if (e == hipSuccess && !ctab.empty())
         step(hipMemcpyAsync(g->d_ix_chunk_tab, ctab.data(), ctab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (sliced) {
+        step(hipMalloc((void **)&g->d_ix_vert, vb));
+        step(hipMalloc((void **)&g->d_ix_sites, std::max<uint64_t>(3 * S, 1) * sizeof(uint4)));
+        if (e == hipSuccess) step(launch_seed_transpose(g->d_ix_planes, g->d_ix_chunk_tab, g->ix_chunks, g->d_ix_vert, st));
+        if (e == hipSuccess) step(launch_seed_sites16(g->d_ix_planes, g->d_ix_pos, 3 * S, g->d_ix_sites, st));
+    }
     step(hipEventRecord(ctx->ev[6], st));
     step(hipStreamSynchronize(st));
     if (e != hipSuccess) {
         free_index(g);
         return e;
+    }
+    if (sliced) {  // the 16-byte records replace the separate plane / position tables
+        (void)hipFree(g->d_ix_planes);
+        (void)hipFree(g->d_ix_pos);
+        g->d_ix_planes = nullptr;
+        g->d_ix_pos = nullptr;
     }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]);
@@ -525,7 +556,7 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         g->index_extra_pam[0] = params->extra_pam[0];
         g->index_extra_pam[1] = params->extra_pam[1];
     }
-    g->index_bytes = 3 * S * (sizeof(uint2) + sizeof(uint32_t)) + (kBuckets + 1) * sizeof(uint32_t) + cb;
+    g->index_bytes = 3 * S * (sliced ? sizeof(uint4) : sizeof(uint2) + sizeof(uint32_t)) + (kBuckets + 1) * sizeof(uint32_t) + cb + vb;
     return hipSuccess;
 }
 
@@ -638,8 +669,10 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         const uint32_t k_seg = params->max_mismatches / kSegments;
         const uint32_t n_nbr = k_seg == 0 ? 1u : (k_seg == 1 ? 22u : 211u);
         const uint64_t n_pairs = (uint64_t)n_guides * kSegments * n_nbr;
-        if (n_pairs >= (1ull << 32) - (1u << 20)) return cleanup(fail(ctx, VSC_ERR_RANGE, "vsc_search: too many reads for one seeded pass"));
         const uint64_t list_cap = n_pairs + (uint64_t)kBuckets * (kGuideUnroll - 1) + 2 * kGuideUnroll;
+        // hit tokens carry the read index in kTokLaneShift bits (sliced kernel), list entries in kListDistShift bits
+        if (list_cap >= (1ull << 32) - (1u << 20) || n_guides >= (genome->d_ix_vert ? (1u << kTokLaneShift) : (1u << kListDistShift)))
+            return cleanup(fail(ctx, VSC_ERR_RANGE, "vsc_search: too many reads for one seeded pass (split the read set)"));
         size_t temp_bytes = 0;
         VSC_HIP_H(sort32_temp_bytes(n_pairs, 16, &temp_bytes));
         VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
@@ -648,14 +681,16 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         VSC_HIP_H(ctx->seed_poff.ensure((kBuckets + 1) * sizeof(uint32_t)));
         VSC_HIP_H(ctx->seed_lplanes.ensure(list_cap * sizeof(uint2)));
         VSC_HIP_H(ctx->seed_lgid.ensure(list_cap * sizeof(uint32_t)));
+        VSC_HIP_H(ctx->seed_lrest.ensure(list_cap * sizeof(uint4)));
         VSC_HIP_H(hipMemsetAsync(ctx->seed_lplanes.p, 0xFF, list_cap * sizeof(uint2), ctx->stream));  // padding never matches
+        VSC_HIP_H(hipMemsetAsync(ctx->seed_lrest.p, 0xFF, list_cap * sizeof(uint4), ctx->stream));    // y = ~0: skipped
         VSC_HIP_H(launch_seed_enum((const uint2 *)ctx->guides.p, n_guides, n_nbr, (uint32_t *)ctx->seed_k1.p,
                                    (uint32_t *)ctx->seed_v1.p, ctx->stream));
         VSC_HIP_H(launch_sort32(ctx->sort_temp.p, temp_bytes, (const uint32_t *)ctx->seed_k1.p, (uint32_t *)ctx->seed_k2.p,
                                 (const uint32_t *)ctx->seed_v1.p, (uint32_t *)ctx->seed_v2.p, n_pairs, 16, ctx->stream));
         VSC_HIP_H(launch_seed_lists((const uint32_t *)ctx->seed_k2.p, (const uint32_t *)ctx->seed_v2.p, n_pairs,
                                     (uint32_t *)ctx->seed_off.p, (uint32_t *)ctx->seed_poff.p, (const uint2 *)ctx->guides.p,
-                                    (uint2 *)ctx->seed_lplanes.p, (uint32_t *)ctx->seed_lgid.p, ctx->stream));
+                                    (uint2 *)ctx->seed_lplanes.p, (uint32_t *)ctx->seed_lgid.p, (uint4 *)ctx->seed_lrest.p, ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
         sa.planes = genome->d_ix_planes;
         sa.pos = genome->d_ix_pos;
@@ -664,6 +699,10 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         sa.n_chunks = genome->ix_chunks;
         sa.list_planes = (const uint4 *)ctx->seed_lplanes.p;
         sa.list_gid = (const uint32_t *)ctx->seed_lgid.p;
+        sa.vert = genome->d_ix_vert;
+        sa.list_rest = (const uint4 *)ctx->seed_lrest.p;
+        sa.sites = genome->d_ix_sites;
+        sa.guides = (const uint2 *)ctx->guides.p;
         sa.poff = (const uint32_t *)ctx->seed_poff.p;
         sa.max_mm = params->max_mismatches;
         sa.k_half = params->max_mismatches / 2;
@@ -674,7 +713,8 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         uint32_t groups_per_cu = 5;
         if (const char *o = std::getenv("VSC_SEED_GROUPS_PER_CU")) groups_per_cu = (uint32_t)std::max(1, std::atoi(o));
         const uint32_t n_waves_max = (uint32_t)ctx->n_cus * groups_per_cu * kWavesPerGroup;
-        const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, (sa.n_chunks + kSeedGrab - 1) / kSeedGrab));
+        const uint32_t grab = genome->d_ix_vert ? kSlicedGrab : kSeedGrab;
+        const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, (sa.n_chunks + grab - 1) / grab));
         n_groups = (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
         // block of records a wave reserves per atomic: large when many hits are expected, small otherwise
         // (the unused tail of every wave's last block is sorted along as sentinels)
@@ -703,7 +743,10 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
             // re-derivation of hits); VSC_SEED_DENSE=0 selects the min-tree variant for experiments
             bool dense = true;
             if (const char *o = std::getenv("VSC_SEED_DENSE")) dense = o[0] == '1';
-            VSC_HIP_H(launch_seed_compare(sa, n_groups, dense, ctx->stream));
+            if (sa.vert)
+                VSC_HIP_H(launch_seed_sliced(sa, n_groups, ctx->stream));
+            else
+                VSC_HIP_H(launch_seed_compare(sa, n_groups, dense, ctx->stream));
         }
         VSC_HIP_H(hipEventRecord(ctx->ev[2], ctx->stream));
         VSC_HIP_H(hipMemcpyAsync(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));

@@ -32,6 +32,13 @@ constexpr int kBucketsPerSeg = 1 << (2 * kSegBases);  // 16384 seven-mers
 constexpr int kBuckets = kSegments * kBucketsPerSeg;
 constexpr int kSeedTokCap = 512;                // per-wave LDS buffer of pending hit tokens
 constexpr int kSeedHitCap = 256;                // per-wave LDS buffer of resolved hits
+constexpr int kSlicedSites = 32;                // sites per lane of the bit-sliced comparison (one bit each)
+constexpr int kSlicedChunk = kWave * kSlicedSites;  // 2048 sites per wave and chunk
+constexpr int kRestBases = VSC_READ_LEN - kSegBases;  // 16 read positions outside the seed segment
+constexpr int kListDistShift = 30;              // list entry y: read index | seed distance << 30
+constexpr int kTokLaneShift = 26;               // sliced hit token, high word: read index | lane << 26
+constexpr int kSlicedTokCap = 320;              // sliced kernel: per-wave LDS ring of 16-byte hit tokens
+constexpr int kSlicedGrab = 4;                  // chunks of 2048 sites per grab of the work counter (sliced kernel)
 constexpr int kSeedGrab = 16;                   // chunks (<= 512 sites of one bucket) per grab of the work counter
 
 // counters[] slots of one scan launch
@@ -91,7 +98,11 @@ struct SeedArgs {
     const uint2 *planes;           // [3 S] sites (x = hi plane | strand | edge, y = lo plane), bucket-sorted per segment
     const uint32_t *pos;           // [3 S] global window starts, same order
     const uint32_t *bucket_start;  // [kBuckets + 1] first site of every bucket
-    const uint4 *chunk_tab;        // [n_chunks] {first site, site count, bucket, 0}
+    const uint4 *chunk_tab;        // [n_chunks] {first site, site count, bucket, first vertical block}
+    const uint32_t *vert;          // bit-sliced copies of the sites: 32 words per block of 32 sites (see seed_transpose_kernel)
+    const uint4 *list_rest;        // sliced kernel: per list entry {rest(hi) | rest(lo) << 16, read | distance << 30, hi, lo}
+    const uint4 *sites;            // sliced kernel: {hi plane | strand | edge, lo plane, position, 0} per site (replaces planes, pos)
+    const uint2 *guides;           // (hi plane, lo plane) per read
     uint32_t n_chunks;
     const uint4 *list_planes;      // padded per-bucket read lists: two reads per uint4 (hi0, lo0, hi1, lo1)
     const uint32_t *list_gid;      // read index of every list entry
@@ -144,7 +155,11 @@ hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_n
                             hipStream_t stream);
 hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted_gids, uint64_t n_pairs, uint32_t *off,
                              uint32_t *poff, const uint2 *guides, uint2 *list_planes, uint32_t *list_gid,
-                             hipStream_t stream);
+                             uint4 *list_rest, hipStream_t stream);
+hipError_t launch_seed_sites16(const uint2 *planes, const uint32_t *pos, uint64_t n, uint4 *out, hipStream_t stream);
+hipError_t launch_seed_transpose(const uint2 *planes, const uint4 *chunk_tab, uint32_t n_chunks, uint32_t *vert,
+                                 hipStream_t stream);
+hipError_t launch_seed_sliced(const SeedArgs &args, int n_groups, hipStream_t stream);
 hipError_t launch_seed_compare(const SeedArgs &args, int n_groups, bool dense, hipStream_t stream);
 hipError_t launch_merge(const vsc_hit *in, const uint64_t *shard_off_dev, uint32_t n_shards, uint32_t K, uint64_t *bound,
                         uint64_t *key_off, vsc_hit *out, hipStream_t stream);

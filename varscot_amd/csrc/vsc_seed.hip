@@ -124,7 +124,10 @@ __global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uin
         substitute(h, l, e / 3, e % 3 + 1);
     }
     keys[i] = s * kBucketsPerSeg + ((h << kSegBases) | l);
-    gids[i] = g;
+    // substitutions always change the base, so the read's own segment differs from this neighbour in
+    // exactly d = 0 / 1 / 2 positions: the seed distance of every site filed under the neighbour's bucket
+    const uint32_t d = n >= 22 ? 2u : (n >= 1 ? 1u : 0u);
+    gids[i] = g | (d << kListDistShift);
 }
 
 // poff[b] = sum over b' < b of roundup4(off[b'+1] - off[b']); one workgroup, kBuckets + 1 outputs
@@ -156,16 +159,32 @@ __global__ __launch_bounds__(1024) void seed_pad_scan_kernel(const uint32_t *off
 }
 
 // Scatters the sorted (bucket, read) pairs into the padded per-bucket lists.
+// The 16 read positions outside segment `seg`, packed in ascending order ("rest" of a 23-bit plane).
+__device__ __forceinline__ uint32_t rest_of(uint32_t v, uint32_t seg)
+{
+    v &= kMask23;
+    if (seg == 0) return v >> kSegBases;
+    if (seg == 1) return (v & 0x7Fu) | ((v >> (2 * kSegBases)) << kSegBases);
+    return (v & 0x3FFFu) | ((v >> (3 * kSegBases)) << (2 * kSegBases));
+}
+
+// list_planes / list_gid: full planes + read index (pair kernel).  list_rest (sliced kernel): x = rest(hi) |
+// rest(lo) << 16, y = read index | seed distance << 30, z / w = the full hi / lo planes (for the hit path).
 __global__ __launch_bounds__(256) void seed_list_kernel(const uint32_t *sorted_keys, const uint32_t *sorted_gids,
                                                         uint64_t n_pairs, const uint32_t *off, const uint32_t *poff,
-                                                        const uint2 *guides, uint2 *list_planes, uint32_t *list_gid)
+                                                        const uint2 *guides, uint2 *list_planes, uint32_t *list_gid,
+                                                        uint4 *list_rest)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pairs) return;
-    const uint32_t b = sorted_keys[i], g = sorted_gids[i];
+    const uint32_t b = sorted_keys[i], v = sorted_gids[i];
+    const uint32_t g = v & ((1u << kListDistShift) - 1u);
     const uint32_t dst = poff[b] + ((uint32_t)i - off[b]);
-    list_planes[dst] = guides[g];
+    const uint2 gp = guides[g];
+    list_planes[dst] = gp;
     list_gid[dst] = g;
+    const uint32_t seg = b / (uint32_t)kBucketsPerSeg;
+    list_rest[dst] = make_uint4(rest_of(gp.x, seg) | (rest_of(gp.y, seg) << 16), v, gp.x, gp.y);
 }
 
 hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *keys, uint32_t *gids,
@@ -180,7 +199,7 @@ hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_n
 
 hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted_gids, uint64_t n_pairs, uint32_t *off,
                              uint32_t *poff, const uint2 *guides, uint2 *list_planes, uint32_t *list_gid,
-                             hipStream_t stream)
+                             uint4 *list_rest, hipStream_t stream)
 {
     hipError_t e = launch_lower_bound(sorted_keys, n_pairs, kBuckets, 0, 0, off, stream);
     if (e != hipSuccess) return e;
@@ -188,7 +207,7 @@ hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted
     e = hipGetLastError();
     if (e != hipSuccess || n_pairs == 0) return e;
     hipLaunchKernelGGL(seed_list_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, sorted_keys,
-                       sorted_gids, n_pairs, (const uint32_t *)off, (const uint32_t *)poff, guides, list_planes, list_gid);
+                       sorted_gids, n_pairs, (const uint32_t *)off, (const uint32_t *)poff, guides, list_planes, list_gid, list_rest);
     return hipGetLastError();
 }
 
@@ -196,6 +215,7 @@ hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted
 // compare kernel
 // ------------------------------------------------------------------------------------------------
 struct SeedWave {
+    uint4 *tok4;     // sliced kernel: pending hit tokens (see sliced_fetch)
     uint64_t *tok;   // pending hits of the current chunk: t | slot << 23 | lane << 26  |  list index << 32
     uint64_t *hkey;  // resolved hits waiting for the global append
     uint32_t *hval;
@@ -457,6 +477,341 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(con
         atomicAdd(&a.counters[kCntSites], pairs);
         atomicAdd(&a.counters[kCntVisited], visited);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bit-sliced comparison
+// ------------------------------------------------------------------------------------------------
+// The pair kernel above spends 4 VALU instructions per (site, read) pair and lane.  Here a lane holds 32
+// sites "vertically": one word per read position and plane, bit i = site i.  One VALU instruction then
+// works on 32 pairs:  16 positions x 2 (mismatch vector) + a carry-save adder tree (11 full + 4 half
+// adders, 2 instructions each) + a 5-instruction bit-sliced "count <= budget" = ~67 instructions per 32
+// pairs, no popcount, no per-pair branch.  Only the 16 positions OUTSIDE the bucket's seed segment are
+// compared: all sites of a bucket share the segment, whose distance d to the read is a property of
+// the list entry (0, 1 or 2 substitutions), so the budget for the rest is m - d.
+//
+// Vertical block of 32 sites (128 bytes): words 0..15 = hi-plane bit of rest position q = 0..15,
+// words 16..31 = lo-plane bit.  Block b of a chunk holds the chunk's sites [32 b, 32 b + 32).
+__device__ __forceinline__ uint32_t rest_position(uint32_t q, uint32_t seg)
+{
+    if (seg == 0) return q + kSegBases;
+    if (seg == 1) return q < (uint32_t)kSegBases ? q : q + kSegBases;
+    return q < 2u * kSegBases ? q : q + kSegBases;
+}
+
+// One wave per chunk: 64 sites per step, two blocks; word j of a block is the ballot of one plane bit.
+__global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_transpose_kernel(const uint2 *planes, const uint4 *chunk_tab,
+                                                                              uint32_t n_chunks, uint32_t *vert)
+{
+    const uint32_t c = blockIdx.x * kWavesPerGroup + threadIdx.x / kWave;
+    if (c >= n_chunks) return;
+    const uint32_t lane = threadIdx.x % kWave;
+    const uint4 ct = chunk_tab[c];
+    const uint32_t seg = ct.z / (uint32_t)kBucketsPerSeg;
+    for (uint32_t k = 0; k * kWave < ct.y; ++k) {
+        const uint32_t i = k * kWave + lane;
+        uint2 v = make_uint2(0u, 0u);
+        if (i < ct.y) v = planes[ct.x + i];
+        uint32_t mine = 0;
+        for (uint32_t q = 0; q < (uint32_t)kRestBases; ++q) {
+            const uint32_t p = rest_position(q, seg);
+            const uint64_t bh = __ballot((v.x >> p) & 1u), bl = __ballot((v.y >> p) & 1u);
+            // lanes 0..31 assemble block 2k (low halves), lanes 32..63 block 2k + 1 (high halves)
+            const uint32_t wh = lane < 32 ? (uint32_t)bh : (uint32_t)(bh >> 32);
+            const uint32_t wl = lane < 32 ? (uint32_t)bl : (uint32_t)(bl >> 32);
+            if ((lane & 31u) == q) mine = wh;
+            if ((lane & 31u) == q + kRestBases) mine = wl;
+        }
+        const uint32_t block = 2 * k + (lane >> 5);
+        if (block * kSlicedSites < ct.y) vert[((size_t)ct.w + block) * 32 + (lane & 31u)] = mine;
+    }
+}
+
+hipError_t launch_seed_transpose(const uint2 *planes, const uint4 *chunk_tab, uint32_t n_chunks, uint32_t *vert,
+                                 hipStream_t stream)
+{
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(seed_transpose_kernel, dim3((n_chunks + kWavesPerGroup - 1) / kWavesPerGroup),
+                       dim3(kWave * kWavesPerGroup), 0, stream, planes, chunk_tab, n_chunks, vert);
+    return hipGetLastError();
+}
+
+// v_bitop3_b32 with an explicit truth table: bit (a << 2 | b << 1 | c) of `kTable` is the result for the
+// input bits (a, b, c), i.e. kTable = f(0xF0, 0xCC, 0xAA).  Written out because the compiler, given the
+// boolean expressions, shares sub-terms between sum and carry and ends up with three instructions per
+// full adder instead of two.
+template <int kTable> __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, kTable);
+}
+
+// The hit path reads one 16-byte record per hit: {hi plane | strand | edge, lo plane, position, 0}.  (Two
+// separate gathers - planes, position - cost the L1 one cache-line transaction per lane each.)
+__global__ __launch_bounds__(256) void seed_sites16_kernel(const uint2 *planes, const uint32_t *pos, uint64_t n, uint4 *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 v = planes[i];
+    out[i] = make_uint4(v.x, v.y, pos[i], 0u);
+}
+
+hipError_t launch_seed_sites16(const uint2 *planes, const uint32_t *pos, uint64_t n, uint4 *out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(seed_sites16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, planes, pos, n, out);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ void full_add(uint32_t a, uint32_t b, uint32_t c, uint32_t &sum, uint32_t &carry)
+{
+    sum = bitop3<0x96>(a, b, c);    // a ^ b ^ c
+    carry = bitop3<0xE8>(a, b, c);  // majority
+}
+
+__device__ __forceinline__ void half_add(uint32_t a, uint32_t b, uint32_t &sum, uint32_t &carry)
+{
+    sum = a ^ b;
+    carry = a & b;
+}
+
+// all-ones if bit `bit` of the (wave-uniform) word is set
+__device__ __forceinline__ uint32_t spread(uint32_t word, int bit)
+{
+    return (uint32_t)((int32_t)(word << (31 - bit)) >> 31);
+}
+
+// Bit i of the result: site i of this lane's block is valid and within `budget` mismatches of the read on
+// the 16 rest positions.  rx = rest(hi) | rest(lo) << 16 of the read (wave-uniform), budget <= 15.
+__device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[2 * kRestBases], uint32_t rx, uint32_t budget,
+                                                  uint32_t valid)
+{
+    uint32_t mm[kRestBases];
+#pragma unroll
+    for (int q = 0; q < kRestBases; ++q)  // (hi ^ read hi) | (lo ^ read lo)
+        mm[q] = bitop3<0xF6>(v[q] ^ spread(rx, q), v[kRestBases + q], spread(rx, kRestBases + q));
+    // 16 one-bit inputs -> 5-bit count (c4 .. c0), carry-save: 11 full and 4 half adders
+    uint32_t s0, s1, s2, s3, s4, s5, s6, k0, k1, k2, k3, k4, k5, k6, k7;
+    full_add(mm[0], mm[1], mm[2], s0, k0);
+    full_add(mm[3], mm[4], mm[5], s1, k1);
+    full_add(mm[6], mm[7], mm[8], s2, k2);
+    full_add(mm[9], mm[10], mm[11], s3, k3);
+    full_add(mm[12], mm[13], mm[14], s4, k4);
+    full_add(s0, s1, s2, s5, k5);
+    full_add(s3, s4, mm[15], s6, k6);
+    uint32_t c0, c1, c2, c3, c4;
+    half_add(s5, s6, c0, k7);
+    uint32_t t0, t1, t2, l0, l1, l2, l3;
+    full_add(k0, k1, k2, t0, l0);
+    full_add(k3, k4, k5, t1, l1);
+    full_add(t0, t1, k6, t2, l2);
+    half_add(t2, k7, c1, l3);
+    uint32_t u0, n0, n1;
+    full_add(l0, l1, l2, u0, n0);
+    half_add(u0, l3, c2, n1);
+    half_add(n0, n1, c3, c4);
+    // count <= budget, from the least significant bit up: le_i = (~c_i & b_i) | (~(c_i ^ b_i) & le_{i-1})
+    uint32_t le = ~c0 | spread(budget, 0);
+    le = bitop3<0x8E>(c1, spread(budget, 1), le);
+    le = bitop3<0x8E>(c2, spread(budget, 2), le);
+    le = bitop3<0x8E>(c3, spread(budget, 3), le);
+    return bitop3<0x20>(le, c4, valid);  // le & ~c4 & valid
+}
+
+// Second half of the hit path.  A token = {hit word of one lane's block, read | owner lane << 26, read hi
+// plane, read lo plane}; a lane takes one token and resolves its LOWEST set bit: one 16-byte gather of the
+// site record gives the full 23-position mask, the strand and the position.  A token with more bits goes
+// back into the ring with that bit cleared, so every pass over 64 tokens is dense.  The gather of the next
+// 64 tokens is issued before the current 64 are consumed.
+struct SlicedFetch {
+    uint32_t word, hi, site0;
+    uint2 gp;   // read planes
+    uint4 rec;  // site record of the lowest set bit
+};
+
+__device__ __forceinline__ SlicedFetch sliced_fetch(const SeedArgs &a, const SeedWave &w, uint32_t head, uint32_t n,
+                                                    uint32_t chunk_first)
+{
+    SlicedFetch f;
+    f.word = 0;
+    f.hi = 0;
+    f.site0 = 0;
+    f.gp = make_uint2(0u, 0u);
+    f.rec = make_uint4(0u, 0u, 0u, 0u);
+    if (w.lane < n) {
+        const uint4 tk = w.tok4[(head + w.lane) % kSlicedTokCap];
+        f.word = tk.x;
+        f.hi = tk.y;
+        f.gp = make_uint2(tk.z, tk.w);
+        f.site0 = chunk_first + (tk.y >> kTokLaneShift) * kSlicedSites;
+        f.rec = a.sites[f.site0 + (uint32_t)__builtin_ctz(tk.x)];
+    }
+    return f;
+}
+
+__device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, const SlicedFetch &f, uint32_t &tail, uint32_t seg)
+{
+    bool hit = f.word != 0;
+    // more hits of the same (block, read): back into the ring
+    const uint32_t rest = f.word & (f.word - 1);
+    const uint64_t again = __ballot(rest != 0);
+    if (again != 0) {
+        if (rest != 0) w.tok4[lanes_below(again, tail) % kSlicedTokCap] = make_uint4(rest, f.hi, f.gp.x, f.gp.y);
+        tail += (uint32_t)__popcll(again);
+    }
+    uint64_t key = 0;
+    uint32_t val = 0;
+    if (hit) {
+        const uint32_t t = ((f.rec.x ^ f.gp.x) | (f.rec.y ^ f.gp.y)) & kMask23;
+        const uint32_t strand = (f.rec.x >> kSiteStrandBit) & 1u;
+        const uint32_t pos = f.rec.z;
+        // a pair that also qualifies in an earlier segment was reported there
+        static_assert(kSegments == 3, "the duplicate test spells out segments 0 and 1");
+        if ((uint32_t)__popc(t & 0x7Fu) <= a.k_seg && seg >= 1) hit = false;
+        if ((uint32_t)__popc(t & 0x3F80u) <= a.k_seg && seg >= 2) hit = false;
+        const uint32_t mask = strand ? reverse23(t) : t;
+        // right-edge rule, bidir_mapping.cpp:51-52 (see emit_hits in vsc_kernels.hip)
+        if (hit && ((f.rec.x >> kSiteEdgeBit) & 1u)) {
+            if ((uint32_t)__popc(mask >> (VSC_READ_LEN / 2)) > a.k_half &&
+                is_contig_end(a.contig_end, a.n_contigs, pos + VSC_READ_LEN))
+                hit = false;
+        }
+        const uint32_t gid = f.hi & ((1u << kTokLaneShift) - 1u);
+        key = ((uint64_t)gid << 33) | ((uint64_t)strand << 32) | pos;
+        val = ((uint32_t)__popc(t) << 23) | mask;
+    }
+    const uint64_t b = __ballot(hit);
+    if (hit) {
+        const uint32_t at = lanes_below(b, w.hn);
+        w.hkey[at] = key;
+        w.hval[at] = val;
+    }
+    wave_sync();
+    w.hn += (uint32_t)__popcll(b);
+    if (w.hn > kSeedHitCap - kWave) seed_flush_hits(a, w);
+}
+
+// Drains the token ring [0, w.ntok) of the current chunk.
+__device__ __forceinline__ void sliced_resolve(const SeedArgs &a, SeedWave &w, uint32_t chunk_first, uint32_t seg)
+{
+    wave_sync();
+    uint32_t head = 0, tail = w.ntok;
+    bool have = false;
+    SlicedFetch f = sliced_fetch(a, w, 0, 0, chunk_first);
+    for (;;) {
+        const uint32_t n = min(tail - head, (uint32_t)kWave);
+        if (n == 0 && !have) break;
+        const SlicedFetch nf = sliced_fetch(a, w, head, n, chunk_first);  // n == 0: empty
+        head += n;
+        if (have) sliced_consume(a, w, f, tail, seg);  // may append to the ring
+        wave_sync();
+        f = nf;
+        have = n != 0;
+    }
+    w.ntok = 0;
+}
+
+typedef const __attribute__((address_space(4))) uint2 *const_u2_ptr;
+
+__global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_sliced_kernel(const SeedArgs a)
+{
+    __shared__ uint4 s_tok[kWavesPerGroup][kSlicedTokCap];
+    __shared__ uint64_t s_hkey[kWavesPerGroup][kSeedHitCap];
+    __shared__ uint32_t s_hval[kWavesPerGroup][kSeedHitCap];
+
+    const uint32_t wave = threadIdx.x / kWave;
+    SeedWave w;
+    w.lane = threadIdx.x % kWave;
+    w.tok = nullptr;
+    w.tok4 = s_tok[wave];
+    w.hkey = s_hkey[wave];
+    w.hval = s_hval[wave];
+    w.ntok = 0;
+    w.hn = 0;
+    w.res_base = 0;
+    w.res_left = 0;
+
+    const const_v4u_ptr lp = (const_v4u_ptr)(uintptr_t)a.list_rest;
+    const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
+    const const_u32_ptr poff = (const_u32_ptr)(uintptr_t)a.poff;
+    const uint32_t m = a.max_mm;
+    const uint32_t lane_tag = w.lane << kTokLaneShift;
+    unsigned long long pairs = 0, visited = 0;
+
+    for (;;) {
+        uint32_t first = 0;
+        if (w.lane == 0) first = (uint32_t)atomicAdd(&a.counters[kCntChunk], (unsigned long long)kSlicedGrab);
+        first = uniform(first);
+        if (first >= a.n_chunks) break;
+        const uint32_t last = min(first + (uint32_t)kSlicedGrab, a.n_chunks);
+        // chunk table entry and list bounds are fetched one chunk ahead (dependent scalar loads)
+        v4u t0 = ctab[first];
+        uint32_t p0a = poff[t0.z], p0b = poff[t0.z + 1];
+        for (uint32_t c = first; c < last; ++c) {
+            const v4u cur = t0;
+            const uint32_t g0 = p0a, g1 = p0b;
+            t0 = ctab[min(c + 1, last - 1)];
+            uint32_t v[2 * kRestBases];
+            const bool mine = w.lane * kSlicedSites < cur.y;
+            if (g0 != g1) {
+                const uint4 *vp = (const uint4 *)(a.vert + ((size_t)cur.w + w.lane) * (2 * kRestBases));
+#pragma unroll
+                for (int j = 0; j < 2 * kRestBases / 4; ++j) {
+                    uint4 x = make_uint4(0u, 0u, 0u, 0u);
+                    if (mine) x = vp[j];
+                    v[4 * j] = x.x;
+                    v[4 * j + 1] = x.y;
+                    v[4 * j + 2] = x.z;
+                    v[4 * j + 3] = x.w;
+                }
+            }
+            p0a = poff[t0.z];
+            p0b = poff[t0.z + 1];
+            if (g0 == g1) continue;  // no read has this bucket in its neighbourhood
+            const uint32_t seg = cur.z / (uint32_t)kBucketsPerSeg;
+            // sites of this lane's block that exist
+            const int32_t left = (int32_t)cur.y - (int32_t)(w.lane * kSlicedSites);
+            const uint32_t valid = left >= kSlicedSites ? 0xFFFFFFFFu : (left > 0 ? (1u << left) - 1u : 0u);
+            pairs += (unsigned long long)cur.y * (g1 - g0);
+            visited += cur.y;
+            v4u nr[kGuideUnroll];
+#pragma unroll
+            for (int u = 0; u < kGuideUnroll; ++u) nr[u] = lp[g0 + u];
+            asm volatile("; first read group ready" ::"s"(nr[0]), "s"(nr[1]), "s"(nr[2]), "s"(nr[3]));  // see seed_compare_kernel
+            for (uint32_t g = g0; g < g1; g += kGuideUnroll) {
+                v4u rd[kGuideUnroll];
+#pragma unroll
+                for (int u = 0; u < kGuideUnroll; ++u) {
+                    rd[u] = nr[u];
+                    nr[u] = lp[g + kGuideUnroll + u];  // the list is allocated with one spare group
+                }
+#pragma unroll
+                for (int u = 0; u < kGuideUnroll; ++u) {
+                    if (rd[u].y == 0xFFFFFFFFu) continue;  // list padding
+                    const uint32_t budget = m - (rd[u].y >> kListDistShift);
+                    const uint32_t word = sliced_within(v, rd[u].x, budget, valid);
+                    const uint64_t b = __ballot(word != 0);
+                    if (b == 0) continue;
+                    const uint32_t gid = rd[u].y & ((1u << kListDistShift) - 1u);
+                    if (word != 0) w.tok4[lanes_below(b, w.ntok)] = make_uint4(word, gid | lane_tag, rd[u].z, rd[u].w);
+                    w.ntok += (uint32_t)__popcll(b);
+                }
+                // a group of four reads adds at most 4 x 64 tokens
+                if (w.ntok > kSlicedTokCap - kGuideUnroll * kWave) sliced_resolve(a, w, cur.x, seg);
+            }
+            if (w.ntok) sliced_resolve(a, w, cur.x, seg);
+        }
+    }
+    seed_finish_hits(a, w);
+    if (w.lane == 0 && pairs) {
+        atomicAdd(&a.counters[kCntSites], pairs);
+        atomicAdd(&a.counters[kCntVisited], visited);
+    }
+}
+
+hipError_t launch_seed_sliced(const SeedArgs &args, int n_groups, hipStream_t stream)
+{
+    hipLaunchKernelGGL(seed_sliced_kernel, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
+    return hipGetLastError();
 }
 
 hipError_t launch_seed_compare(const SeedArgs &args, int n_groups, bool dense, hipStream_t stream)
