@@ -447,7 +447,7 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
     fill_pam(a, params);
     fill_genome(a, ctx, g);
     const int n_groups = scan_groups(ctx, a.n_tiles);
-    VSC_TRY(ctx->counters.ensure(kCntSlots * sizeof(unsigned long long)));
+    VSC_TRY(ctx->counters.ensure(kCounterWords * sizeof(unsigned long long)));
     a.counters = (unsigned long long *)ctx->counters.p;
     unsigned long long cnt[kCntSlots];
     VSC_TRY(hipEventRecord(ctx->ev[5], st));
@@ -643,7 +643,7 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     std::vector<uint32_t> gp((size_t)(n_pad + kGuideUnroll) * 2, 0xFFFFFFFFu);  // + one prefetch group
     for (uint32_t i = 0; i < n_guides; ++i) guide_planes(guides[i], &gp[2 * (size_t)i], &gp[2 * (size_t)i + 1]);
     VSC_HIP_H(ctx->guides.ensure(gp.size() * sizeof(uint32_t)));
-    VSC_HIP_H(ctx->counters.ensure(kCntSlots * sizeof(unsigned long long)));
+    VSC_HIP_H(ctx->counters.ensure(kCounterWords * sizeof(unsigned long long)));
     VSC_HIP_H(hipEventRecord(ctx->ev[0], ctx->stream));
     VSC_HIP_H(hipMemcpyAsync(ctx->guides.p, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 
@@ -710,7 +710,7 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         sa.contig_end = genome->d_contig_end;
         sa.n_contigs = genome->n_contigs;
         sa.counters = (unsigned long long *)ctx->counters.p;
-        uint32_t groups_per_cu = 5;
+        uint32_t groups_per_cu = genome->d_ix_vert ? 4 : 5;  // resident groups per CU (registers / LDS of the kernel)
         if (const char *o = std::getenv("VSC_SEED_GROUPS_PER_CU")) groups_per_cu = (uint32_t)std::max(1, std::atoi(o));
         const uint32_t n_waves_max = (uint32_t)ctx->n_cus * groups_per_cu * kWavesPerGroup;
         const uint32_t grab = genome->d_ix_vert ? kSlicedGrab : kSeedGrab;
@@ -728,7 +728,7 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     for (;;) {
         VSC_HIP_H(ctx->keys_a.ensure(cap * sizeof(uint64_t)));
         VSC_HIP_H(ctx->vals_a.ensure(cap * sizeof(uint32_t)));
-        VSC_HIP_H(hipMemsetAsync(ctx->counters.p, 0, kCntSlots * sizeof(unsigned long long), ctx->stream));
+        VSC_HIP_H(hipMemsetAsync(ctx->counters.p, 0, kCounterWords * sizeof(unsigned long long), ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[1], ctx->stream));
         if (algo == VSC_ALGO_SCAN) {
             a.hit_keys = (uint64_t *)ctx->keys_a.p;

@@ -220,6 +220,7 @@ struct SeedWave {
     uint64_t *hkey;  // resolved hits waiting for the global append
     uint32_t *hval;
     uint32_t ntok, hn, lane;
+    uint32_t thead;  // sliced kernel: ring slot of the oldest pending token
     unsigned long long res_base;  // this wave's reserved range of the global hit arrays
     uint32_t res_left;
 };
@@ -490,8 +491,9 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(con
 // compared: all sites of a bucket share the segment, whose distance d to the read is a property of
 // the list entry (0, 1 or 2 substitutions), so the budget for the rest is m - d.
 //
-// Vertical block of 32 sites (128 bytes): words 0..15 = hi-plane bit of rest position q = 0..15,
-// words 16..31 = lo-plane bit.  Block b of a chunk holds the chunk's sites [32 b, 32 b + 32).
+// Vertical block of 32 sites (32 words): words 0..15 = hi-plane bit of rest position q = 0..15, words 16..31 =
+// lo-plane bit.  Block b of a chunk holds the chunk's sites [32 b, 32 b + 32); the blocks of a chunk are
+// stored interleaved by word quad (see seed_transpose_kernel) so that a wave's loads are contiguous.
 __device__ __forceinline__ uint32_t rest_position(uint32_t q, uint32_t seg)
 {
     if (seg == 0) return q + kSegBases;
@@ -522,8 +524,10 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_transpose_kernel(c
             if ((lane & 31u) == q) mine = wh;
             if ((lane & 31u) == q + kRestBases) mine = wl;
         }
-        const uint32_t block = 2 * k + (lane >> 5);
-        if (block * kSlicedSites < ct.y) vert[((size_t)ct.w + block) * 32 + (lane & 31u)] = mine;
+        const uint32_t block = 2 * k + (lane >> 5), j = lane & 31u;
+        const uint32_t nb = (ct.y + kSlicedSites - 1) / kSlicedSites;  // blocks of this chunk
+        // chunk layout [word quad j / 4][block][j % 4]: the 16-byte loads of a wave (lane = block) coalesce
+        if (block < nb) vert[(size_t)ct.w * 32 + ((size_t)(j >> 2) * nb + block) * 4 + (j & 3u)] = mine;
     }
 }
 
@@ -628,6 +632,13 @@ struct SlicedFetch {
     uint4 rec;  // site record of the lowest set bit
 };
 
+// ring slot of running position p (p < 2 * kSlicedTokCap is all the callers need)
+__device__ __forceinline__ uint32_t ring_slot(uint32_t p)
+{
+    return p >= (uint32_t)kSlicedTokCap ? p - kSlicedTokCap : p;
+}
+
+// ring slots head .. head + n - 1 -> one token per lane (lanes >= n stay empty), gather issued
 __device__ __forceinline__ SlicedFetch sliced_fetch(const SeedArgs &a, const SeedWave &w, uint32_t head, uint32_t n,
                                                     uint32_t chunk_first)
 {
@@ -638,7 +649,7 @@ __device__ __forceinline__ SlicedFetch sliced_fetch(const SeedArgs &a, const See
     f.gp = make_uint2(0u, 0u);
     f.rec = make_uint4(0u, 0u, 0u, 0u);
     if (w.lane < n) {
-        const uint4 tk = w.tok4[(head + w.lane) % kSlicedTokCap];
+        const uint4 tk = w.tok4[ring_slot(head + w.lane)];
         f.word = tk.x;
         f.hi = tk.y;
         f.gp = make_uint2(tk.z, tk.w);
@@ -648,15 +659,18 @@ __device__ __forceinline__ SlicedFetch sliced_fetch(const SeedArgs &a, const See
     return f;
 }
 
-__device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, const SlicedFetch &f, uint32_t &tail, uint32_t seg)
+// w.ntok tokens wait in the ring from slot w.thead on; `tail` = first free slot
+__device__ __forceinline__ uint32_t ring_tail(const SeedWave &w) { return ring_slot(w.thead + w.ntok); }
+
+__device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, const SlicedFetch &f, uint32_t seg)
 {
     bool hit = f.word != 0;
     // more hits of the same (block, read): back into the ring
     const uint32_t rest = f.word & (f.word - 1);
     const uint64_t again = __ballot(rest != 0);
     if (again != 0) {
-        if (rest != 0) w.tok4[lanes_below(again, tail) % kSlicedTokCap] = make_uint4(rest, f.hi, f.gp.x, f.gp.y);
-        tail += (uint32_t)__popcll(again);
+        if (rest != 0) w.tok4[ring_slot(lanes_below(again, ring_tail(w)))] = make_uint4(rest, f.hi, f.gp.x, f.gp.y);
+        w.ntok += (uint32_t)__popcll(again);
     }
     uint64_t key = 0;
     uint32_t val = 0;
@@ -690,33 +704,60 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
     if (w.hn > kSeedHitCap - kWave) seed_flush_hits(a, w);
 }
 
-// Drains the token ring [0, w.ntok) of the current chunk.
-__device__ __forceinline__ void sliced_resolve(const SeedArgs &a, SeedWave &w, uint32_t chunk_first, uint32_t seg)
+// Resolves tokens in passes of 64.  drain = false: full passes only - what is left (< 64 tokens) waits
+// for more, so that every pass is dense; drain = true (end of the chunk): everything.
+__device__ __forceinline__ void sliced_resolve(const SeedArgs &a, SeedWave &w, uint32_t chunk_first, uint32_t seg, bool drain)
 {
     wave_sync();
-    uint32_t head = 0, tail = w.ntok;
     bool have = false;
     SlicedFetch f = sliced_fetch(a, w, 0, 0, chunk_first);
     for (;;) {
-        const uint32_t n = min(tail - head, (uint32_t)kWave);
+        uint32_t n = min(w.ntok, (uint32_t)kWave);
+        if (!drain && n < (uint32_t)kWave) n = 0;
         if (n == 0 && !have) break;
-        const SlicedFetch nf = sliced_fetch(a, w, head, n, chunk_first);  // n == 0: empty
-        head += n;
-        if (have) sliced_consume(a, w, f, tail, seg);  // may append to the ring
+        const SlicedFetch nf = sliced_fetch(a, w, w.thead, n, chunk_first);  // n == 0: empty
+        w.thead = ring_slot(w.thead + n);
+        w.ntok -= n;
+        if (have) sliced_consume(a, w, f, seg);  // may append to the ring
         wave_sync();
         f = nf;
         have = n != 0;
     }
-    w.ntok = 0;
 }
 
-typedef const __attribute__((address_space(4))) uint2 *const_u2_ptr;
+// entry g0 + lane of a read list [g0, g1) (past the end: padding, y = ~0)
+__device__ __forceinline__ uint4 sliced_load_list(const SeedArgs &a, uint32_t g0, uint32_t g1, uint32_t lane)
+{
+    uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (g0 + lane < g1) e = a.list_rest[g0 + lane];
+    return e;
+}
+
+// this lane's block of the chunk's bit-sliced sites (lanes past the chunk's last block: zeros)
+__device__ __forceinline__ void sliced_load_sites(const SeedArgs &a, const v4u &ct, bool wanted, uint32_t lane,
+                                                  uint32_t (&v)[2 * kRestBases])
+{
+    const uint32_t nb = (ct.y + kSlicedSites - 1) / kSlicedSites;
+    const bool mine = wanted && lane < nb;
+    const uint4 *vp = (const uint4 *)(a.vert + (size_t)ct.w * (2 * kRestBases)) + lane;
+#pragma unroll
+    for (int j = 0; j < 2 * kRestBases / 4; ++j) {
+        uint4 x = make_uint4(0u, 0u, 0u, 0u);
+        if (mine) x = vp[(size_t)j * nb];
+        v[4 * j] = x.x;
+        v[4 * j + 1] = x.y;
+        v[4 * j + 2] = x.z;
+        v[4 * j + 3] = x.w;
+    }
+}
+
 
 __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_sliced_kernel(const SeedArgs a)
 {
     __shared__ uint4 s_tok[kWavesPerGroup][kSlicedTokCap];
     __shared__ uint64_t s_hkey[kWavesPerGroup][kSeedHitCap];
     __shared__ uint32_t s_hval[kWavesPerGroup][kSeedHitCap];
+    __shared__ uint4 s_list[kWavesPerGroup][kWave];  // the current tile of 64 read-list entries
 
     const uint32_t wave = threadIdx.x / kWave;
     SeedWave w;
@@ -726,46 +767,64 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_sliced_kernel(cons
     w.hkey = s_hkey[wave];
     w.hval = s_hval[wave];
     w.ntok = 0;
+    w.thead = 0;
     w.hn = 0;
     w.res_base = 0;
     w.res_left = 0;
 
-    const const_v4u_ptr lp = (const_v4u_ptr)(uintptr_t)a.list_rest;
+    uint4 *const lt = s_list[wave];
     const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
     const const_u32_ptr poff = (const_u32_ptr)(uintptr_t)a.poff;
     const uint32_t m = a.max_mm;
     const uint32_t lane_tag = w.lane << kTokLaneShift;
     unsigned long long pairs = 0, visited = 0;
 
+    // work distribution: the chunk range is cut into kCursors slices with a cursor each; a wave starts in
+    // "its" slice and moves on to the next one when a slice is used up (see kCursors)
+    const uint32_t slice_len = (a.n_chunks + kCursors - 1) / kCursors;
+    uint32_t slice = (blockIdx.x * kWavesPerGroup + wave) % kCursors, exhausted = 0;
     for (;;) {
-        uint32_t first = 0;
-        if (w.lane == 0) first = (uint32_t)atomicAdd(&a.counters[kCntChunk], (unsigned long long)kSlicedGrab);
-        first = uniform(first);
-        if (first >= a.n_chunks) break;
-        const uint32_t last = min(first + (uint32_t)kSlicedGrab, a.n_chunks);
-        // chunk table entry and list bounds are fetched one chunk ahead (dependent scalar loads)
-        v4u t0 = ctab[first];
-        uint32_t p0a = poff[t0.z], p0b = poff[t0.z + 1];
+        uint32_t off = 0;
+        if (w.lane == 0)
+            off = (uint32_t)atomicAdd(&a.counters[kCursorBase + slice * kCursorStride], (unsigned long long)kSlicedGrab);
+        off = uniform(off);
+        const uint32_t slice_begin = slice * slice_len, slice_end = min(slice_begin + slice_len, a.n_chunks);
+        if (slice_begin + off >= slice_end) {
+            if (++exhausted == (uint32_t)kCursors) break;
+            slice = (slice + 1) % kCursors;
+            continue;
+        }
+        const uint32_t first = slice_begin + off;
+        const uint32_t last = min(first + (uint32_t)kSlicedGrab, slice_end);
+        // Three-stage software pipeline over the chunks of this grab, all stages one chunk apart:
+        //   A  chunk table entry (scalar load)   B  its read-list bounds poff[bucket..] (scalar load)
+        //   C  this lane's block of bit-sliced sites (8 x 16-byte vector loads)        then the comparison.
+        // With ~13 reads per bucket (1 000 reads) a chunk is compared in less time than one HBM round trip.
+        v4u t0 = ctab[first];                             // chunk c     : A done
+        v4u t1 = ctab[min(first + 1, last - 1)];          // chunk c + 1 : A in flight
+        uint32_t p0a = poff[t0.z], p0b = poff[t0.z + 1];  // chunk c     : B done
+        uint32_t nv[2 * kRestBases];
+        sliced_load_sites(a, t0, p0a != p0b, w.lane, nv);  // chunk c     : C in flight
+        uint4 nl = sliced_load_list(a, p0a, p0b, w.lane);   //               and the first 64 entries of its read list
+        uint32_t p1a = poff[t1.z], p1b = poff[t1.z + 1];  // chunk c + 1 : B in flight
+        v4u t2 = ctab[min(first + 2, last - 1)];          // chunk c + 2 : A in flight
         for (uint32_t c = first; c < last; ++c) {
             const v4u cur = t0;
             const uint32_t g0 = p0a, g1 = p0b;
-            t0 = ctab[min(c + 1, last - 1)];
             uint32_t v[2 * kRestBases];
-            const bool mine = w.lane * kSlicedSites < cur.y;
-            if (g0 != g1) {
-                const uint4 *vp = (const uint4 *)(a.vert + ((size_t)cur.w + w.lane) * (2 * kRestBases));
 #pragma unroll
-                for (int j = 0; j < 2 * kRestBases / 4; ++j) {
-                    uint4 x = make_uint4(0u, 0u, 0u, 0u);
-                    if (mine) x = vp[j];
-                    v[4 * j] = x.x;
-                    v[4 * j + 1] = x.y;
-                    v[4 * j + 2] = x.z;
-                    v[4 * j + 3] = x.w;
-                }
-            }
-            p0a = poff[t0.z];
-            p0b = poff[t0.z + 1];
+            for (int j = 0; j < 2 * kRestBases; ++j) v[j] = nv[j];
+            // advance the pipeline before the comparison so that its loads overlap it
+            t0 = t1;
+            p0a = p1a;
+            p0b = p1b;
+            uint4 tile = nl;
+            sliced_load_sites(a, t0, c + 1 < last && p0a != p0b, w.lane, nv);
+            nl = sliced_load_list(a, p0a, c + 1 < last ? p0b : p0a, w.lane);
+            t1 = t2;
+            p1a = poff[t1.z];
+            p1b = poff[t1.z + 1];
+            t2 = ctab[min(c + 3, last - 1)];
             if (g0 == g1) continue;  // no read has this bucket in its neighbourhood
             const uint32_t seg = cur.z / (uint32_t)kBucketsPerSeg;
             // sites of this lane's block that exist
@@ -773,32 +832,39 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_sliced_kernel(cons
             const uint32_t valid = left >= kSlicedSites ? 0xFFFFFFFFu : (left > 0 ? (1u << left) - 1u : 0u);
             pairs += (unsigned long long)cur.y * (g1 - g0);
             visited += cur.y;
-            v4u nr[kGuideUnroll];
+            // The read list goes through LDS in tiles of 64 entries: one coalesced vector load per tile,
+            // issued a whole tile (or chunk) ahead, then one broadcast LDS read per entry.  Scalar loads of
+            // the entries, a group at a time, left ~1 us of scalar-cache miss latency per group exposed
+            // whenever a bucket has only a handful of reads.
+            for (uint32_t tg = g0; tg < g1; tg += kWave) {
+                wave_sync();
+                lt[w.lane] = tile;
+                wave_sync();
+                if (tg + kWave < g1) tile = sliced_load_list(a, tg + kWave, g1, w.lane);
+                const uint32_t in_tile = min(g1 - tg, (uint32_t)kWave);
+                for (uint32_t gi = 0; gi < in_tile; gi += kGuideUnroll) {
+                    uint4 rd[kGuideUnroll];
 #pragma unroll
-            for (int u = 0; u < kGuideUnroll; ++u) nr[u] = lp[g0 + u];
-            asm volatile("; first read group ready" ::"s"(nr[0]), "s"(nr[1]), "s"(nr[2]), "s"(nr[3]));  // see seed_compare_kernel
-            for (uint32_t g = g0; g < g1; g += kGuideUnroll) {
-                v4u rd[kGuideUnroll];
+                    for (int u = 0; u < kGuideUnroll; ++u) rd[u] = lt[gi + u];  // same address in every lane
 #pragma unroll
-                for (int u = 0; u < kGuideUnroll; ++u) {
-                    rd[u] = nr[u];
-                    nr[u] = lp[g + kGuideUnroll + u];  // the list is allocated with one spare group
+                    for (int u = 0; u < kGuideUnroll; ++u) {
+                        const uint32_t ry = uniform(rd[u].y);
+                        if (ry == 0xFFFFFFFFu) continue;  // list padding
+                        const uint32_t rx = uniform(rd[u].x);
+                        const uint32_t budget = m - (ry >> kListDistShift);
+                        const uint32_t word = sliced_within(v, rx, budget, valid);
+                        const uint64_t b = __ballot(word != 0);
+                        if (b == 0) continue;
+                        const uint32_t gid = ry & ((1u << kListDistShift) - 1u);
+                        if (word != 0)
+                            w.tok4[ring_slot(lanes_below(b, ring_tail(w)))] = make_uint4(word, gid | lane_tag, rd[u].z, rd[u].w);
+                        w.ntok += (uint32_t)__popcll(b);
+                    }
+                    // a group of four reads adds at most 4 x 64 tokens, a resolve leaves fewer than 64
+                    if (w.ntok >= (uint32_t)kWave) sliced_resolve(a, w, cur.x, seg, false);
                 }
-#pragma unroll
-                for (int u = 0; u < kGuideUnroll; ++u) {
-                    if (rd[u].y == 0xFFFFFFFFu) continue;  // list padding
-                    const uint32_t budget = m - (rd[u].y >> kListDistShift);
-                    const uint32_t word = sliced_within(v, rd[u].x, budget, valid);
-                    const uint64_t b = __ballot(word != 0);
-                    if (b == 0) continue;
-                    const uint32_t gid = rd[u].y & ((1u << kListDistShift) - 1u);
-                    if (word != 0) w.tok4[lanes_below(b, w.ntok)] = make_uint4(word, gid | lane_tag, rd[u].z, rd[u].w);
-                    w.ntok += (uint32_t)__popcll(b);
-                }
-                // a group of four reads adds at most 4 x 64 tokens
-                if (w.ntok > kSlicedTokCap - kGuideUnroll * kWave) sliced_resolve(a, w, cur.x, seg);
             }
-            if (w.ntok) sliced_resolve(a, w, cur.x, seg);
+            if (w.ntok) sliced_resolve(a, w, cur.x, seg, true);
         }
     }
     seed_finish_hits(a, w);
