@@ -93,7 +93,7 @@ def sort_roofline(n_reads, n_hits, sort_ms):
     while (1 << gb) < n_reads:
         gb += 1
     end_bit = 33 + gb + (1 if n_reads == (1 << gb) else 0)
-    passes = -(-end_bit // 8) - 1  # vsc_search: begin_bit = end_bit - 8 * (passes_full - 1)
+    passes = -(-(end_bit - 16) // 8)  # vsc_search leaves up to 16 low position bits to finalize_kernel
     return {"bound": "hbm", "kernel": "rocprim onesweep radix sort (u64 key, u32 value)",
             "achieved": 24.0 * n_hits * passes / (max(sort_ms, 1e-9) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "launch_ms": sort_ms, "passes": passes, "key_bits_sorted": 8 * passes, "key_bits_left_to_finalize": end_bit - 8 * passes}
@@ -322,7 +322,7 @@ def main():
                                   "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK, "frac": lane_ops / VALU_LANE_OPS_PEAK}},
             # the library sort (rocPRIM onesweep) moves every 12-byte (key, value) pair once in and once
             # out per 8-bit digit; at m = 8 it is as long as the search kernel, so it gets its own line.
-            # vsc_search sorts key bits [begin, end): end = 33 + guide bits, the odd low digit is left to finalize
+            # vsc_search sorts key bits [begin, end): end = 33 + guide bits, up to 16 low bits are left to finalize
             "roofline_sort": sort_roofline(args.batch if streamed else n_guides, hits_local, float(np.mean(sort_ms))),
             "kernels_ms": {"search": scan_avg_ms, "prep": float(np.mean(prep_ms)), "sort": float(np.mean(sort_ms)),
                            "finalize": float(np.mean(fin_ms)), "score": float(np.mean(score_ms)) if score_ms else None},

@@ -779,30 +779,50 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         while (guide_bits < 31 && (1ull << guide_bits) < n_guides) ++guide_bits;
         // sentinels (all ones) must sort behind every real key: one more bit when the all-ones guide id is in use
         const unsigned end_bit = 33 + guide_bits + ((n_sort != n && n_guides == (1ull << guide_bits)) ? 1 : 0);
-        // the sort costs one pass over all pairs per 8 key bits: leave out the low position bits that
-        // make up the odd digit (<= 8 bits, a whole pass) and let finalize_kernel order those groups
-        unsigned begin_bit = end_bit > 16 ? end_bit - 8 * ((end_bit + 7) / 8 - 1) : 0;
-        if (const char *o = std::getenv("VSC_SORT_LOW_BITS")) begin_bit = std::min(8u, (unsigned)std::atoi(o));
-        size_t temp_bytes = 0;
-        VSC_HIP_H(sort_temp_bytes(n_sort, begin_bit, end_bit, &temp_bytes));
-        VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
+        // The sort costs one pass over all pairs per 8 key bits.  Up to 16 low position bits are left out
+        // (two passes for a 47-bit key) and finalize_kernel orders the records that agree in the rest; if
+        // it meets a group too large for that (> 257 hits of one read and strand within 2^low_bits bases),
+        // the sort is repeated with at most 8 bits left out, which always works.
+        auto low_bits_for = [&](unsigned max_low) {
+            const unsigned passes = (end_bit - std::min(end_bit, max_low) + 7) / 8;
+            return end_bit > 8 * passes ? end_bit - 8 * passes : 0u;
+        };
+        unsigned begin_bit = low_bits_for(16);
+        bool forced = false;
+        if (const char *o = std::getenv("VSC_SORT_LOW_BITS")) {
+            begin_bit = std::min(16u, (unsigned)std::atoi(o));
+            forced = true;
+        }
         VSC_HIP_H(ctx->keys_b.ensure(n_sort * sizeof(uint64_t)));
         VSC_HIP_H(ctx->vals_b.ensure(n_sort * sizeof(uint32_t)));
         ht.lap("sort buffers ensure");
         VSC_HIP_H(take_records(ctx, hits, n));
         ht.lap("record storage");
-        VSC_HIP_H(launch_sort(ctx->sort_temp.p, temp_bytes, (const uint64_t *)ctx->keys_a.p, (uint64_t *)ctx->keys_b.p,
-                              (const uint32_t *)ctx->vals_a.p, (uint32_t *)ctx->vals_b.p, n_sort, begin_bit, end_bit, ctx->stream));
-        VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
-        FinalizeArgs f{};
-        f.keys = (const uint64_t *)ctx->keys_b.p;
-        f.vals = (const uint32_t *)ctx->vals_b.p;
-        f.n = n;
-        f.low_bits = begin_bit;
-        f.contig_off = genome->d_contig_off;
-        f.n_contigs = genome->n_contigs;
-        f.out = hits->d_records;
-        VSC_HIP_H(launch_finalize(f, ctx->stream));
+        for (;;) {
+            size_t temp_bytes = 0;
+            VSC_HIP_H(sort_temp_bytes(n_sort, begin_bit, end_bit, &temp_bytes));
+            VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
+            VSC_HIP_H(launch_sort(ctx->sort_temp.p, temp_bytes, (const uint64_t *)ctx->keys_a.p, (uint64_t *)ctx->keys_b.p,
+                                  (const uint32_t *)ctx->vals_a.p, (uint32_t *)ctx->vals_b.p, n_sort, begin_bit, end_bit, ctx->stream));
+            VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
+            FinalizeArgs f{};
+            f.keys = (const uint64_t *)ctx->keys_b.p;
+            f.vals = (const uint32_t *)ctx->vals_b.p;
+            f.n = n;
+            f.low_bits = begin_bit;
+            f.overflow = (unsigned long long *)ctx->counters.p + kCntGroups;
+            f.contig_off = genome->d_contig_off;
+            f.n_contigs = genome->n_contigs;
+            f.out = hits->d_records;
+            VSC_HIP_H(launch_finalize(f, ctx->stream));
+            if (begin_bit <= 8) break;  // groups of at most 256 records: always rankable
+            unsigned long long too_large = 0;
+            VSC_HIP_H(hipMemcpyAsync(&too_large, f.overflow, sizeof too_large, hipMemcpyDeviceToHost, ctx->stream));
+            VSC_HIP_H(hipStreamSynchronize(ctx->stream));
+            if (!too_large) break;
+            if (forced) return cleanup(fail(ctx, VSC_ERR_DEVICE, "vsc_search: VSC_SORT_LOW_BITS leaves groups too large to order"));
+            begin_bit = low_bits_for(8);
+        }
     } else {
         VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
     }

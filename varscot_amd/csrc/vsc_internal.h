@@ -42,7 +42,7 @@ constexpr int kSlicedGrab = 4;                  // chunks of 2048 sites per grab
 constexpr int kSeedGrab = 16;                   // chunks (<= 512 sites of one bucket) per grab of the work counter
 
 // counters[] slots of one scan launch
-enum { kCntHits = 0, kCntChunk = 1, kCntSites = 2, kCntOverflow = 3, kCntVisited = 4, kCntPad = 5, kCntLost = 6, kCntSlots = 7 };
+enum { kCntHits = 0, kCntChunk = 1, kCntSites = 2, kCntOverflow = 3, kCntVisited = 4, kCntPad = 5, kCntLost = 6, kCntGroups = 7, kCntSlots = 8 };
 // The sliced kernel hands out chunks through kCursors work cursors, one per slice of the chunk range, 128
 // bytes apart behind the counters: one device-wide cursor sustains only ~90 atomics/us
 // (MI355X_MICROARCH.md), which for 270 000 grabs is 3 ms - as long as a whole 1 000-read search.
@@ -82,7 +82,8 @@ struct FinalizeArgs {
     const uint64_t *keys;
     const uint32_t *vals;
     uint64_t n;
-    uint32_t low_bits;           // key bits [0, low_bits) were left out of the sort (<= 8)
+    uint32_t low_bits;           // key bits [0, low_bits) were left out of the sort (<= 16)
+    unsigned long long *overflow;  // set to 1 when a group is too large to be ranked (only possible for low_bits > 8)
     const uint32_t *contig_off;  // ascending global start positions of all contigs
     uint32_t n_contigs;
     vsc_hit *out;

@@ -334,10 +334,12 @@ __device__ __forceinline__ uint32_t contig_of(const uint32_t *contig_off, uint32
     return lo;
 }
 
-// The sort left records that agree in key bits [low_bits, 64) adjacent but in arbitrary order.  Such
-// a group holds at most 2^low_bits <= 256 records (keys are unique), so a block stages its 256 keys
-// plus 256 on either side in LDS and every thread ranks its key inside its group: destination =
-// group start + number of smaller keys.  With low_bits = 0 every group is one record.
+// The sort left records that agree in key bits [low_bits, 64) adjacent but in arbitrary order.  A block
+// stages its keys plus 256 on either side in LDS and every thread ranks its key inside its group:
+// destination = group start + number of smaller keys (keys are unique).  That works for groups of up
+// to 257 records: always when low_bits <= 8, and for practically every search when up to 16 position
+// bits are left out (a group is then one read's hits on one strand inside a 64 kb window); a larger
+// group raises *overflow and the host repeats the sort with low_bits <= 8.  low_bits = 0: no groups.
 constexpr int kFinalizeBlock = 256;
 constexpr int kFinalizeItems = 8;    // records per thread
 constexpr int kFinalizeHalo = 256;   // >= the largest group
@@ -368,13 +370,18 @@ __global__ __launch_bounds__(kFinalizeBlock) void finalize_kernel(const Finalize
         uint64_t dst = i;
         if (a.low_bits) {
             const uint64_t group = key >> a.low_bits;
-            uint32_t before = 0, smaller = 0;
-            for (int t = me - 1; t >= 0 && (s_key[t] >> a.low_bits) == group; --t) {
+            uint32_t before = 0, smaller = 0, after = 0;
+            for (int t = me - 1; t >= me - kFinalizeHalo && (s_key[t] >> a.low_bits) == group; --t) {
                 ++before;
                 smaller += s_key[t] < key;
             }
-            for (int t = me + 1; t < kFinalizeTile + 2 * kFinalizeHalo && (s_key[t] >> a.low_bits) == group; ++t)
+            for (int t = me + 1; t <= me + kFinalizeHalo && (s_key[t] >> a.low_bits) == group; ++t) {
+                ++after;
                 smaller += s_key[t] < key;
+            }
+            // a group that reaches past the staged neighbourhood cannot be ranked here: the host sorts again
+            // with fewer bits left out
+            if (before == (uint32_t)kFinalizeHalo || after == (uint32_t)kFinalizeHalo) atomicMax(a.overflow, 1ull);
             dst = i - before + smaller;
         }
         const uint32_t pos = (uint32_t)key;
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(kFinalizeBlock) void finalize_kernel(const Finalize
 hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream)
 {
     if (args.n == 0) return hipSuccess;
-    if ((1u << args.low_bits) > (unsigned)kFinalizeHalo) return hipErrorInvalidValue;  // a group must fit the halo
+    if (args.low_bits > 16 || (args.low_bits && !args.overflow)) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((args.n + kFinalizeTile - 1) / kFinalizeTile);
     hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(kFinalizeBlock), 0, stream, args);
     return hipGetLastError();
