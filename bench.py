@@ -34,7 +34,9 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz (32-bit integer lane-ops / s)
-LANE_OPS_PER_COMPARE = 3.5  # v_xor + v_bitop3 + v_bcnt + 1/2 v_min3 per (site, read) pair
+LANE_OPS_PER_COMPARE = {"scan": 3.5,     # v_xor + v_bitop3 + v_bcnt + 1/2 v_min3 per (site, read) pair
+                        "pairs": 4.0,    # v_xor + v_bitop3 + v_bcnt + v_cmp
+                        "sliced": 2.25}  # 72 instructions per read and 32 sites: 16 x 2 mismatch vectors + adder tree + test
 
 
 def parse():
@@ -286,15 +288,21 @@ def main():
             # 0.375 B/base of planes + 16 B per hit + 16 B per read
             alg_bytes = 0.375 * own_bases + 16.0 * hits_local + 16.0 * n_guides
         else:
-            kernel = "seed_compare_kernel"
-            # site records of the visited buckets (8 B each, read once) + the per-bucket read lists
-            # (12 B per entry) + 12 B per hit written
+            sliced = os.environ.get("VSC_SEED_KERNEL") != "pairs"
+            kernel = "seed_sliced_kernel" if sliced else "seed_compare_kernel"
             k_seg = max_mm // 3
             list_entries = n_guides * 3 * (1, 22, 211)[k_seg]  # summed over the batches of a streamed run
-            alg_bytes = float(stream_bytes) + 12.0 * list_entries + 12.0 * hits_local
+            if sliced:
+                # bit-sliced sites of the visited buckets (4 B each, read once) + the per-bucket read lists
+                # (16 B per entry) + per hit one 16 B site record read and 12 B written
+                alg_bytes = float(stream_bytes) + 16.0 * list_entries + 28.0 * hits_local
+            else:
+                # site records of the visited buckets (8 B each) + read lists (12 B per entry) + 12 B per hit written
+                alg_bytes = float(stream_bytes) + 12.0 * list_entries + 12.0 * hits_local
         achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
         compares = float(pairs_local)
-        lane_ops = compares * LANE_OPS_PER_COMPARE / (scan_avg_ms * 1e-3)
+        ops_per_compare = LANE_OPS_PER_COMPARE["scan" if algorithm == "scan" else ("sliced" if sliced else "pairs")]
+        lane_ops = compares * ops_per_compare / (scan_avg_ms * 1e-3)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tpath):
@@ -316,9 +324,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel, "launch_ms": scan_avg_ms, "algorithmic_bytes": alg_bytes,
                          "note": "integer/bitwise compare kernel; VALU issue is the binding resource next to HBM "
-                                 "(DESIGN.md section 4) - both are reported",
+                                 "(DESIGN.md section 4) - both are reported; valu counts the comparison only, not the hit path",
                          "valu": {"pair_compares_per_s": compares / (scan_avg_ms * 1e-3),
-                                  "lane_ops_per_compare": LANE_OPS_PER_COMPARE, "achieved_lane_ops_per_s": lane_ops,
+                                  "lane_ops_per_compare": ops_per_compare, "achieved_lane_ops_per_s": lane_ops,
                                   "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK, "frac": lane_ops / VALU_LANE_OPS_PEAK}},
             # the library sort (rocPRIM onesweep) moves every 12-byte (key, value) pair once in and once
             # out per 8-bit digit; at m = 8 it is as long as the search kernel, so it gets its own line.

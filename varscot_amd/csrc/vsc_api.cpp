@@ -770,7 +770,8 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     } else {
         t.sites = genome->index_sites;
         t.pairs = cnt[kCntSites];
-        t.genome_bytes = cnt[kCntVisited] * sizeof(uint2);
+        // sites visited: 4 bytes each bit-sliced (16 compared positions x 2 planes / 32 sites per word), 8 as records
+        t.genome_bytes = cnt[kCntVisited] * (genome->d_ix_vert ? sizeof(uint32_t) : sizeof(uint2));
     }
     t.hits = n;
 
