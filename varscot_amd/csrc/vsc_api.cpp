@@ -95,7 +95,7 @@ struct vsc_genome {
     uint32_t *d_ix_pos = nullptr, *d_ix_bucket_start = nullptr;
     uint4 *d_ix_chunk_tab = nullptr;
     uint32_t *d_ix_vert = nullptr;  // bit-sliced blocks of 32 sites (null: index built for the pair kernel)
-    uint4 *d_ix_sites = nullptr;    // sliced kernel: 16-byte site records (then d_ix_planes / d_ix_pos are released)
+    uint4 *d_ix_sites = nullptr;    // sliced kernel: 16-byte site records (instead of d_ix_planes / d_ix_pos)
     uint32_t ix_chunks = 0;
     uint64_t index_bytes = 0;
     double index_ms = 0;
@@ -474,8 +474,13 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
     size_t temp_bytes = 0;
     step(sort32_temp_bytes(S, 2 * kSegBases, &temp_bytes));
     step(tmp.ensure(std::max<size_t>(temp_bytes, 16)));
-    step(hipMalloc((void **)&g->d_ix_planes, std::max<uint64_t>(3 * S, 1) * sizeof(uint2)));
-    step(hipMalloc((void **)&g->d_ix_pos, std::max<uint64_t>(3 * S, 1) * sizeof(uint32_t)));
+    const bool sliced = use_sliced_kernel();
+    if (sliced) {
+        step(hipMalloc((void **)&g->d_ix_sites, std::max<uint64_t>(3 * S, 1) * sizeof(uint4)));
+    } else {
+        step(hipMalloc((void **)&g->d_ix_planes, std::max<uint64_t>(3 * S, 1) * sizeof(uint2)));
+        step(hipMalloc((void **)&g->d_ix_pos, std::max<uint64_t>(3 * S, 1) * sizeof(uint32_t)));
+    }
     step(hipMalloc((void **)&g->d_ix_bucket_start, (kBuckets + 1) * sizeof(uint32_t)));
     if (e == hipSuccess && S > 0) {
         // pass 2: emit
@@ -490,8 +495,12 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         step(launch_seed_keys((const uint32_t *)sx.p, (const uint32_t *)sl.p, S, s, (uint32_t *)k1.p, (uint32_t *)i1.p, st));
         step(launch_sort32(tmp.p, temp_bytes, (const uint32_t *)k1.p, (uint32_t *)k2.p, (const uint32_t *)i1.p,
                            (uint32_t *)i2.p, S, 2 * kSegBases, st));
-        step(launch_seed_gather((const uint32_t *)sx.p, (const uint32_t *)sl.p, (const uint32_t *)sp.p,
-                                (const uint32_t *)i2.p, S, g->d_ix_planes + (size_t)s * S, g->d_ix_pos + (size_t)s * S, st));
+        if (sliced)
+            step(launch_seed_gather16((const uint32_t *)sx.p, (const uint32_t *)sl.p, (const uint32_t *)sp.p,
+                                      (const uint32_t *)i2.p, S, g->d_ix_sites + (size_t)s * S, st));
+        else
+            step(launch_seed_gather((const uint32_t *)sx.p, (const uint32_t *)sl.p, (const uint32_t *)sp.p,
+                                    (const uint32_t *)i2.p, S, g->d_ix_planes + (size_t)s * S, g->d_ix_pos + (size_t)s * S, st));
         step(launch_lower_bound((const uint32_t *)k2.p, S, kBucketsPerSeg, 0, (uint32_t)(s * S),
                                 g->d_ix_bucket_start + (size_t)s * kBucketsPerSeg, st));
     }
@@ -507,7 +516,6 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
     }
     // chunks: at most kSlicedChunk sites of one bucket each (kBatch for the pair kernel); the sites of a
     // chunk also exist bit-sliced, in blocks of 32, from block `vfirst` on
-    const bool sliced = use_sliced_kernel();
     const uint64_t chunk_sites = sliced ? kSlicedChunk : kBatch;
     std::vector<uint32_t> ctab;  // {first site, site count, bucket, first vertical block} per chunk
     ctab.reserve(4 * (3 * S / chunk_sites + kBuckets));
@@ -529,21 +537,13 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         step(hipMemcpyAsync(g->d_ix_chunk_tab, ctab.data(), ctab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     if (sliced) {
         step(hipMalloc((void **)&g->d_ix_vert, vb));
-        step(hipMalloc((void **)&g->d_ix_sites, std::max<uint64_t>(3 * S, 1) * sizeof(uint4)));
-        if (e == hipSuccess) step(launch_seed_transpose(g->d_ix_planes, g->d_ix_chunk_tab, g->ix_chunks, g->d_ix_vert, st));
-        if (e == hipSuccess) step(launch_seed_sites16(g->d_ix_planes, g->d_ix_pos, 3 * S, g->d_ix_sites, st));
+        if (e == hipSuccess) step(launch_seed_transpose(g->d_ix_sites, g->d_ix_chunk_tab, g->ix_chunks, g->d_ix_vert, st));
     }
     step(hipEventRecord(ctx->ev[6], st));
     step(hipStreamSynchronize(st));
     if (e != hipSuccess) {
         free_index(g);
         return e;
-    }
-    if (sliced) {  // the 16-byte records replace the separate plane / position tables
-        (void)hipFree(g->d_ix_planes);
-        (void)hipFree(g->d_ix_pos);
-        g->d_ix_planes = nullptr;
-        g->d_ix_pos = nullptr;
     }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]);

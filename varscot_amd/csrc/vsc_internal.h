@@ -164,8 +164,9 @@ hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_n
 hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted_gids, uint64_t n_pairs, uint32_t *off,
                              uint32_t *poff, const uint2 *guides, uint2 *list_planes, uint32_t *list_gid,
                              uint4 *list_rest, hipStream_t stream);
-hipError_t launch_seed_sites16(const uint2 *planes, const uint32_t *pos, uint64_t n, uint4 *out, hipStream_t stream);
-hipError_t launch_seed_transpose(const uint2 *planes, const uint4 *chunk_tab, uint32_t n_chunks, uint32_t *vert,
+hipError_t launch_seed_gather16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, const uint32_t *idx, uint64_t n,
+                                uint4 *out, hipStream_t stream);
+hipError_t launch_seed_transpose(const uint4 *sites, const uint4 *chunk_tab, uint32_t n_chunks, uint32_t *vert,
                                  hipStream_t stream);
 hipError_t launch_seed_sliced(const SeedArgs &args, int n_groups, hipStream_t stream);
 hipError_t launch_seed_compare(const SeedArgs &args, int n_groups, bool dense, hipStream_t stream);

@@ -46,6 +46,17 @@ __global__ __launch_bounds__(256) void seed_gather_kernel(const uint32_t *x, con
     pos_out[i] = pos[j];
 }
 
+// same, as 16-byte records {hi plane | strand | edge, lo plane, position, 0} (what the sliced kernel's hit path reads:
+// one gather per hit; two separate gathers - planes, position - cost the L1 a cache-line transaction per lane each)
+__global__ __launch_bounds__(256) void seed_gather16_kernel(const uint32_t *x, const uint32_t *l, const uint32_t *pos,
+                                                            const uint32_t *idx, uint64_t n, uint4 *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = idx[i];
+    out[i] = make_uint4(x[j], l[j], pos[j], 0u);
+}
+
 // out[b] = base + (first index i with sorted_keys[i] >= b), b = 0 .. n_buckets (inclusive)
 __global__ __launch_bounds__(256) void lower_bound_kernel(const uint32_t *sorted_keys, uint64_t n, uint32_t n_buckets,
                                                           uint32_t key_offset, uint32_t base, uint32_t *out)
@@ -75,6 +86,14 @@ hipError_t launch_seed_gather(const uint32_t *x, const uint32_t *l, const uint32
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(seed_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, l, pos, idx, n,
                        planes_out, pos_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_seed_gather16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, const uint32_t *idx, uint64_t n,
+                                uint4 *out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(seed_gather16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, l, pos, idx, n, out);
     return hipGetLastError();
 }
 
@@ -502,7 +521,7 @@ __device__ __forceinline__ uint32_t rest_position(uint32_t q, uint32_t seg)
 }
 
 // One wave per chunk: 64 sites per step, two blocks; word j of a block is the ballot of one plane bit.
-__global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_transpose_kernel(const uint2 *planes, const uint4 *chunk_tab,
+__global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_transpose_kernel(const uint4 *sites, const uint4 *chunk_tab,
                                                                               uint32_t n_chunks, uint32_t *vert)
 {
     const uint32_t c = blockIdx.x * kWavesPerGroup + threadIdx.x / kWave;
@@ -512,8 +531,8 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_transpose_kernel(c
     const uint32_t seg = ct.z / (uint32_t)kBucketsPerSeg;
     for (uint32_t k = 0; k * kWave < ct.y; ++k) {
         const uint32_t i = k * kWave + lane;
-        uint2 v = make_uint2(0u, 0u);
-        if (i < ct.y) v = planes[ct.x + i];
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i < ct.y) v = sites[ct.x + i];
         uint32_t mine = 0;
         for (uint32_t q = 0; q < (uint32_t)kRestBases; ++q) {
             const uint32_t p = rest_position(q, seg);
@@ -531,12 +550,12 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_transpose_kernel(c
     }
 }
 
-hipError_t launch_seed_transpose(const uint2 *planes, const uint4 *chunk_tab, uint32_t n_chunks, uint32_t *vert,
+hipError_t launch_seed_transpose(const uint4 *sites, const uint4 *chunk_tab, uint32_t n_chunks, uint32_t *vert,
                                  hipStream_t stream)
 {
     if (n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(seed_transpose_kernel, dim3((n_chunks + kWavesPerGroup - 1) / kWavesPerGroup),
-                       dim3(kWave * kWavesPerGroup), 0, stream, planes, chunk_tab, n_chunks, vert);
+                       dim3(kWave * kWavesPerGroup), 0, stream, sites, chunk_tab, n_chunks, vert);
     return hipGetLastError();
 }
 
@@ -547,23 +566,6 @@ hipError_t launch_seed_transpose(const uint2 *planes, const uint4 *chunk_tab, ui
 template <int kTable> __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
 {
     return __builtin_amdgcn_bitop3_b32(a, b, c, kTable);
-}
-
-// The hit path reads one 16-byte record per hit: {hi plane | strand | edge, lo plane, position, 0}.  (Two
-// separate gathers - planes, position - cost the L1 one cache-line transaction per lane each.)
-__global__ __launch_bounds__(256) void seed_sites16_kernel(const uint2 *planes, const uint32_t *pos, uint64_t n, uint4 *out)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint2 v = planes[i];
-    out[i] = make_uint4(v.x, v.y, pos[i], 0u);
-}
-
-hipError_t launch_seed_sites16(const uint2 *planes, const uint32_t *pos, uint64_t n, uint4 *out, hipStream_t stream)
-{
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(seed_sites16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, planes, pos, n, out);
-    return hipGetLastError();
 }
 
 __device__ __forceinline__ void full_add(uint32_t a, uint32_t b, uint32_t c, uint32_t &sum, uint32_t &carry)
