@@ -4,9 +4,9 @@ set -e -o pipefail
 W=${1:-c3}; CTR=${2}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/probe2_$W; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTR -d "$OUT/a" -o run --output-format csv -- python3 $ROOT/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/a.err"
+rocprofv3 --pmc $CTR -d "$OUT/a" -o run --output-format csv -- python3 $ROOT/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/a.err"
 python3 - "$OUT" <<'PY'
-import csv, glob, sys
+import csv, glob, sys, json
 acc = {}
 for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     per = {}
@@ -18,4 +18,6 @@ for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=Tru
         acc.setdefault(n, []).append(v)
 for n, v in sorted(acc.items()):
     print("%-36s %.4g" % (n, sum(v) / len(v)))
+d = json.loads(open(sys.argv[1] + "/bench.json").read().strip().splitlines()[-1])
+print("search ms", d["kernels_ms"]["search"])
 PY
