@@ -53,7 +53,10 @@ def parse():
     ap.add_argument("--snps", type=int, default=5_000_000, help="records of the synthetic VCF (workload c4)")
     ap.add_argument("--batch", type=int, default=5_000, help="reads per search call for the streamed workload c5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="run the RCCL gather/merge path even with one rank")
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange/merge path even with one rank")
+    ap.add_argument("--exchange", default="reads", choices=["reads", "root"],
+                    help="multi-rank exchange of the hit records: 'reads' = every rank gathers and merges its read "
+                         "range (all-to-all, result stays distributed), 'root' = everything to rank 0")
     ap.add_argument("--cpu-sample-bases", type=int, default=192_000_000)
     ap.add_argument("--cpu-sample-guides", type=int, default=64)
     return ap.parse_args()
@@ -195,7 +198,8 @@ def main():
     def search_batch(batch_codes):
         if not use_dist:
             return genome.search(batch_codes, max_mm, algorithm=algorithm), None
-        merged, local = vdist.sharded_search(ctx, genome, batch_codes, max_mm, device=device, algorithm=algorithm)
+        merged, local = vdist.sharded_search(ctx, genome, batch_codes, max_mm, device=device, algorithm=algorithm,
+                                             exchange=args.exchange)
         return local, merged
 
     def step_c4():
@@ -270,10 +274,11 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        agg = torch.tensor([float(sites_local), float(np.mean(scan_ms))], dtype=torch.float64, device=device)
-        sites_all = agg.clone()
-        dist.all_reduce(sites_all, op=dist.ReduceOp.SUM)
-        total_sites = float(sites_all[0].item())
+        # every rank holds a part of the result (exchange = reads) or rank 0 holds it all (root): sum of the shard hits
+        agg = torch.tensor([float(sites_local), float(hits_local)], dtype=torch.float64, device=device)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        total_sites = float(agg[0].item())
+        total_hits = int(agg[1].item())
     else:
         total_sites = float(sites_local)
 
@@ -317,6 +322,7 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, desc), "guides": n_guides, "genome_bases": total_bases,
                        "max_mismatches": max_mm, "parallelism": "genome-shard x%d" % world, "algorithm": algorithm,
+                       "exchange": (args.exchange if use_dist else None),
                        "hits_per_step": int(total_hits), "candidate_sites_per_s": total_hits * args.steps / dt,
                        "pam_valid_sites": int(total_sites), "scan_passes": passes,
                        "batch": args.batch if streamed else n_guides, "variant_genome": snp_info},

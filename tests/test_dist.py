@@ -35,7 +35,7 @@ def _shard_hits(contigs, guides, max_mm, packed, rank, world):
     return h[keep]
 
 
-def _worker(rank, world, port, seed, q):
+def _worker(rank, world, port, seed, q, mode="root"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,13 +50,17 @@ def _worker(rank, world, port, seed, q):
         assert vdist.shard_words(packed.n_words, rank, world) == packed.shard_words(rank, world)
         mine = _shard_hits(contigs, guides, 6, packed, rank, world)
         local = torch.from_numpy(mine.view(np.uint8).copy())
-        gathered, counts = vdist.gather_records(local)
-        if rank == 0:
-            got = gathered.numpy().view(va.HIT_DTYPE)
-            q.put((got.tobytes(), counts))
+        if mode == "reads":
+            received, counts = vdist.exchange_by_reads(local, len(guides))
+            q.put((rank, received.numpy().tobytes(), counts))
         else:
-            assert gathered is None
-            q.put(None)
+            gathered, counts = vdist.gather_records(local)
+            if rank == 0:
+                got = gathered.numpy().view(va.HIT_DTYPE)
+                q.put((got.tobytes(), counts))
+            else:
+                assert gathered is None
+                q.put(None)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -94,3 +98,40 @@ def test_gather_records_over_gloo(world, oracle):
     merged = got[np.argsort(key, kind="stable")]
     whole = oracle.search_fast(contigs, guides, 6)
     assert merged.tobytes() == whole.tobytes()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_by_reads_over_gloo(world, oracle):
+    """exchange="reads": every rank ends up with the records of its read range from all genome shards, in
+    shard order; merging each rank's part and concatenating the ranks gives the global result."""
+    from helpers import make_genome, random_guides
+    import varscot_amd as va
+    from varscot_amd import dist as vdist
+    seed = 950 + world
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, q, "reads")) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(seed)
+    guides = random_guides(rng, 12)
+    contigs = make_genome(seed, [40000, 15000, 9000, 50], guides, 6, n_plant=300, n_runs=4)
+    packed = va.PackedGenome.from_sequences(contigs)
+    shards = [_shard_hits(contigs, guides, 6, packed, r, world) for r in range(world)]
+    parts = []
+    for rank, blob, counts in results:
+        got = np.frombuffer(blob, dtype=va.HIT_DTYPE)
+        b, e = vdist.read_range(len(guides), rank, world)
+        want = [s[(s["guide"] >= b) & (s["guide"] < e)] for s in shards]
+        assert counts == [len(x) for x in want]
+        assert got.tobytes() == np.concatenate(want).tobytes()
+        key = (got["guide"].astype(np.int64) << 1) | (got["info"] >> 31)
+        parts.append(got[np.argsort(key, kind="stable")])  # what vsc_hits_merge does on the GPU
+    whole = oracle.search_fast(contigs, guides, 6)
+    assert len(whole) > 50
+    assert np.concatenate(parts).tobytes() == whole.tobytes()

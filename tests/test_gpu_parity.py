@@ -232,7 +232,7 @@ def test_features_match_reference_golden_on_gpu(ctx, golden_dir):
 
 
 # ------------------------------------------------------------------------------------ multi-rank
-def _rank_worker(rank, world, port, q):
+def _rank_worker(rank, world, port, q, exchange="root"):
     import traceback
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -246,8 +246,11 @@ def _rank_worker(rank, world, port, q):
         packed = va.PackedGenome.from_sequences(contigs)
         c = va.Context(0)  # both ranks share the one GPU of the test box; the data path is per rank
         shard = c.load_genome(packed, rank, world)
-        merged, local = vdist.sharded_search(c, shard, va.pack_guides(guides), 7)
-        if rank == 0:
+        merged, local = vdist.sharded_search(c, shard, va.pack_guides(guides), 7, exchange=exchange)
+        if exchange == "reads":
+            q.put((rank, merged.to_numpy().tobytes()))
+            merged.close()
+        elif rank == 0:
             q.put(merged.to_numpy().tobytes())
             merged.close()
         local.close()
@@ -286,6 +289,32 @@ def test_sharded_search_over_gloo(oracle):
     want = oracle.search_fast(contigs, guides, 7)
     assert len(want) > 300
     assert got.tobytes() == want.tobytes()
+
+
+def test_sharded_search_exchange_by_reads_over_gloo(oracle):
+    """Two ranks, genome shards searched on the GPU, every rank collects and merges its read range."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_rank_worker, args=(r, 2, port, q, "reads")) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    assert all(isinstance(g, tuple) for g in got), got
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    blob = b"".join(b for _, b in sorted(got))
+    rng = np.random.default_rng(4242)
+    guides = random_guides(rng, 16)
+    contigs = make_genome(4242, [300000, 120000, 70000, 23], guides, 7, n_plant=400, n_runs=6)
+    want = oracle.search_fast(contigs, guides, 7)
+    assert blob == want.tobytes()
 
 
 def test_auto_uses_an_existing_index_and_rebuilds_for_another_pam(ctx, oracle):

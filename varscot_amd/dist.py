@@ -1,6 +1,12 @@
 """Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm), the
 genome sharded by tile-aligned plane ranges, every rank searching all reads on its shard, and ONE
-exchange per search: the gather of the hit records to rank 0 over xGMI.
+exchange of hit records per search over xGMI:
+
+  exchange="root"   the gather of all records to rank 0 (one consumer; rank 0's links carry everything:
+                    (N-1)/N of the result over N-1 links)
+  exchange="reads"  every rank gathers the hits of ITS read range from all genome shards (N gathers at
+                    once = an all-to-all; each link carries 1/N^2 of the result) and merges them; the
+                    result stays distributed, sorted, in read-range order
 
 torch is used for the process group and the device buffers that RCCL moves - nothing else.
 """
@@ -50,17 +56,79 @@ def gather_records(local, group=None, dst=0):
     return out, counts
 
 
-def sharded_search(ctx, genome_shard, codes, max_mismatches, extra_pam=None, group=None, device=None,
-                   algorithm="auto"):
-    """Search all reads on this rank's shard, gather to rank 0, merge there.
+def read_range(n_reads, rank, world):
+    """Reads [begin, end) whose hits `rank` collects under exchange="reads"."""
+    return n_reads * rank // world, n_reads * (rank + 1) // world
 
-    Returns (merged hits on rank 0 | None, local Hits)."""
-    hits = genome_shard.search(codes, max_mismatches, extra_pam, algorithm=algorithm)
+
+def exchange_by_reads(local, n_reads, group=None):
+    """local: 1-D uint8 tensor with this rank's records, sorted by (read, strand, contig, pos).
+
+    Every rank receives, from every rank, the records of its own read range (read_range); returns the
+    received records concatenated in source-rank order (= genome-shard order, what vsc_hits_merge
+    expects) and the per-source counts.  One all_gather of the world x world count matrix + one
+    grouped send/recv of the payloads straight into their final place."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    rec = local.view(torch.int32).view(-1, 4)
+    bounds = torch.tensor([read_range(n_reads, d, world)[0] for d in range(world)] + [n_reads], dtype=torch.int32,
+                          device=local.device)
+    cut = torch.searchsorted(rec[:, 0].contiguous(), bounds)  # first record of every destination's read range
+    send = (cut[1:] - cut[:-1]).to(torch.int64)
+    rows = [torch.zeros_like(send) for _ in range(world)]
+    dist.all_gather(rows, send, group=group)
+    matrix = torch.stack(rows).cpu().numpy()  # matrix[s][d] = records s sends to d
+    cut = cut.cpu().numpy().astype(np.int64) * RECORD_BYTES
+    counts = [int(matrix[s][rank]) for s in range(world)]
+    out = torch.empty(sum(counts) * RECORD_BYTES, dtype=torch.uint8, device=local.device)
+    offs = np.concatenate([[0], np.cumsum(counts)]) * RECORD_BYTES
+    out[offs[rank]:offs[rank + 1]] = local[cut[rank]:cut[rank + 1]]
+    ops = []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        if matrix[rank][peer] > 0:
+            ops.append(dist.P2POp(dist.isend, local[cut[peer]:cut[peer + 1]], peer, group))
+        if counts[peer] > 0:
+            ops.append(dist.P2POp(dist.irecv, out[offs[peer]:offs[peer + 1]], peer, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out, counts
+
+
+class _DeviceAlias:
+    """Zero-copy view of library-owned device memory for torch (the records of a vsc_hits)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _records_tensor(hits, device):
+    """The records of `hits` as a uint8 tensor on `device` (a CPU copy for gloo, an alias for nccl)."""
     n = len(hits)
+    if device is not None and torch.device(device).type == "cuda" and n:
+        return torch.as_tensor(_DeviceAlias(hits.device_ptr, n * RECORD_BYTES), device=device)
     local = torch.empty(n * RECORD_BYTES, dtype=torch.uint8, device=device)
     if n:
         hits.copy_to(local.data_ptr(), local.is_cuda)
-    gathered, counts = gather_records(local, group)
+    return local
+
+
+def sharded_search(ctx, genome_shard, codes, max_mismatches, extra_pam=None, group=None, device=None,
+                   algorithm="auto", exchange="root"):
+    """Search all reads on this rank's shard, exchange the hit records once, merge.
+
+    exchange="root":  returns (merged hits of all reads on rank 0 | None elsewhere, local Hits)
+    exchange="reads": returns (merged hits of this rank's read range, local Hits)"""
+    hits = genome_shard.search(codes, max_mismatches, extra_pam, algorithm=algorithm)
+    local = _records_tensor(hits, device)
+    if exchange == "reads":
+        gathered, counts = exchange_by_reads(local, len(codes), group)
+    elif exchange == "root":
+        gathered, counts = gather_records(local, group)
+    else:
+        raise ValueError("exchange must be 'root' or 'reads'")
     merged = None
     if gathered is not None:
         if gathered.is_cuda:
