@@ -454,3 +454,35 @@ def test_low_position_bits_left_to_finalize(ctx, oracle, algo, low_bits, monkeyp
     got = gpu_search(ctx, contigs, guides, 3, None, algo=algo)
     assert len(want) > 5000
     assert hits_as_tuples(got) == hits_as_tuples(want)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_baseline_config_c1(ctx, oracle, algo):
+    """BASELINE.json configs[0]: 10 guides, 1 Mbp synthetic FASTA, <= 4 mismatches - the bench's own
+    synthetic generator, checked against the oracle's bit-parallel port."""
+    from varscot_amd import synth
+    packed = synth.synthetic_genome(1_000_000)
+    ids, guides = synth.synthetic_guides(10)
+    planted = synth.plant_sites(packed, guides, 60, 4)
+    contigs = [packed.contig_sequence(c) for c in range(len(packed.contigs))]
+    assert len(planted) > 20
+    want = oracle.search_fast(contigs, guides, 4)
+    got = gpu_search(ctx, contigs, guides, 4, algo=algo)
+    assert hits_as_tuples(got) == hits_as_tuples(want)
+
+
+def test_pair_kernel_still_matches(oracle, monkeypatch):
+    """VSC_SEED_KERNEL=pairs: the per-pair comparison kernel (8-byte site records, chunks of 512) stays a
+    selectable variant of the seed search and must give the same records."""
+    monkeypatch.setenv("VSC_SEED_KERNEL", "pairs")
+    c = va.Context(0)
+    try:
+        rng = np.random.default_rng(31)
+        guides = random_guides(rng, 24)
+        contigs = make_genome(31, [400000, 150000, 23, 5000], guides, 8, n_plant=300, n_runs=8)
+        for m in (8, 4, 1):
+            want = oracle.search_fast(contigs, guides, m)
+            got = gpu_search(c, contigs, guides, m, algo="seed")
+            assert hits_as_tuples(got) == hits_as_tuples(want)
+    finally:
+        c.close()
