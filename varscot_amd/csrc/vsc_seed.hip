@@ -784,7 +784,9 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_sliced_kernel(cons
     // work distribution: the chunk range is cut into kCursors slices with a cursor each; a wave starts in
     // "its" slice and moves on to the next one when a slice is used up (see kCursors)
     const uint32_t slice_len = (a.n_chunks + kCursors - 1) / kCursors;
-    uint32_t slice = (blockIdx.x * kWavesPerGroup + wave) % kCursors, exhausted = 0;
+    // (uniform(): `wave` derives from threadIdx, and a slice the compiler takes for divergent drags the whole
+    // chunk bookkeeping - table entries, list bounds, loop counters - from scalar into vector registers)
+    uint32_t slice = uniform((blockIdx.x * kWavesPerGroup + wave) % kCursors), exhausted = 0;
     for (;;) {
         uint32_t off = 0;
         if (w.lane == 0)
