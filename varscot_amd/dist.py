@@ -108,7 +108,10 @@ def _records_tensor(hits, device):
     """The records of `hits` as a uint8 tensor on `device` (a CPU copy for gloo, an alias for nccl)."""
     n = len(hits)
     if device is not None and torch.device(device).type == "cuda" and n:
-        return torch.as_tensor(_DeviceAlias(hits.device_ptr, n * RECORD_BYTES), device=device)
+        try:
+            return torch.as_tensor(_DeviceAlias(hits.device_ptr, n * RECORD_BYTES), device=device)
+        except (TypeError, RuntimeError, ValueError):
+            pass  # a torch build without __cuda_array_interface__ import: stage a copy instead
     local = torch.empty(n * RECORD_BYTES, dtype=torch.uint8, device=device)
     if n:
         hits.copy_to(local.data_ptr(), local.is_cuda)
