@@ -103,8 +103,8 @@ struct ScoreArgs {
 };
 
 struct SeedArgs {
-    const uint2 *planes;           // [3 S] sites (x = hi plane | strand | edge, y = lo plane), bucket-sorted per segment
-    const uint32_t *pos;           // [3 S] global window starts, same order
+    const uint2 *planes;           // pair kernel: [3 S] sites (x = hi plane | strand | edge, y = lo plane), bucket-sorted per segment
+    const uint32_t *pos;           // pair kernel: [3 S] global window starts, same order
     const uint32_t *bucket_start;  // [kBuckets + 1] first site of every bucket
     const uint4 *chunk_tab;        // [n_chunks] {first site, site count, bucket, first vertical block}
     const uint32_t *vert;          // bit-sliced copies of the sites: 32 words per block of 32 sites (see seed_transpose_kernel)
@@ -112,8 +112,8 @@ struct SeedArgs {
     const uint4 *sites;            // sliced kernel: {hi plane | strand | edge, lo plane, position, 0} per site (replaces planes, pos)
     const uint2 *guides;           // (hi plane, lo plane) per read
     uint32_t n_chunks;
-    const uint4 *list_planes;      // padded per-bucket read lists: two reads per uint4 (hi0, lo0, hi1, lo1)
-    const uint32_t *list_gid;      // read index of every list entry
+    const uint4 *list_planes;      // pair kernel: padded per-bucket read lists: two reads per uint4 (hi0, lo0, hi1, lo1)
+    const uint32_t *list_gid;      // pair kernel: read index of every list entry
     const uint32_t *poff;          // [kBuckets + 1] first list entry of every bucket (multiples of kGuideUnroll)
     uint32_t max_mm, k_half, k_seg;
     const uint32_t *contig_end;

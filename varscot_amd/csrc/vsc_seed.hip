@@ -10,9 +10,16 @@
 // 14-bit code of its 7 segment bases ("bucket").  A search enumerates, per read and segment, the
 // 1 / 22 / 211 seven-mers within k substitutions of the read's segment, which turns into one list of
 // reads per bucket; a wave then compares a chunk of one bucket's sites only with that bucket's reads:
-// 3 * 211 / 16384 = 3.9 % of all (site, read) pairs at m = 6..8.  The comparison itself is the full
-// 23-position one of the streaming scan, so the accepted set is identical; a pair that qualifies in
-// several segments is reported by the first one only.
+// 3 * 211 / 16384 = 3.9 % of all (site, read) pairs at m = 6..8.  A pair is accepted on exactly the
+// streaming scan's criterion - at most m mismatches over all 23 positions, the right-edge rule - so the
+// accepted set is identical; a pair that qualifies in several segments is reported by the first only.
+//
+// Two comparison kernels share the index build and the read lists:
+//   seed_sliced_kernel   (default) bit-sliced: 32 sites per lane and instruction, only the 16 positions
+//                        outside the bucket's segment are counted, the segment adds the list entry's
+//                        known distance; hits are resolved from 16-byte site records
+//   seed_compare_kernel  (VSC_SEED_KERNEL=pairs) one (site, read) pair per lane and iteration over all
+//                        23 positions, 8-byte site records
 #include "vsc_internal.h"
 #include "vsc_device.h"
 
