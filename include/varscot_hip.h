@@ -95,7 +95,7 @@ typedef struct {
 
 /* Per-search device timings measured with HIP events on the context's stream (milliseconds). */
 typedef struct {
-    double scan_ms;          /* the dominant search kernel: scan_kernel or seed_compare_kernel (last pass) */
+    double scan_ms;          /* the dominant search kernel: scan_kernel or seed_sliced_kernel (last pass) */
     double prep_ms;          /* read upload (+ per-bucket read lists for VSC_ALGO_SEED) */
     double sort_ms;          /* radix sort of the hit keys */
     double finalize_ms;      /* contig resolution + record assembly */
@@ -158,7 +158,8 @@ int vsc_genome_load(vsc_ctx *ctx, const uint32_t *hi, const uint32_t *lo, const 
 int vsc_genome_free(vsc_genome *genome);
 /* Builds (or keeps, if it matches) the seed index of a resident genome for the PAM set of `params`
  * (NULL = GG, GA only): the PAM-valid, N-free windows of both strands, filed once per 7-base
- * segment in bucket order, 36 bytes per window.  Plays the part of `bidir_index`
+ * segment in bucket order (a 16-byte record + 4 bytes of bit-sliced planes per window and segment:
+ * 60 bytes per window).  Plays the part of `bidir_index`
  * (read_mapping/bidir_index.cpp:45-47); vsc_search builds it on demand. */
 int vsc_genome_build_index(vsc_ctx *ctx, vsc_genome *genome, const vsc_search_params *params);
 /* Bytes of HBM the resident genome (planes + seed index) occupies. */
