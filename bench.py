@@ -52,6 +52,9 @@ def parse():
                     help="scan = stream the packed planes; seed = resident pigeonhole site tables; auto = seed")
     ap.add_argument("--snps", type=int, default=5_000_000, help="records of the synthetic VCF (workload c4)")
     ap.add_argument("--batch", type=int, default=5_000, help="reads per search call for the streamed workload c5")
+    ap.add_argument("--sub-batches", type=int, default=None,
+                    help="multi-rank runs with --exchange reads: cut the reads into this many pieces and overlap the "
+                         "exchange of one piece with the search of the next (default: 4 at 2 ranks, 2 at 3-4, 1 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange/merge path even with one rank")
     ap.add_argument("--exchange", default="reads", choices=["reads", "root"],
@@ -195,6 +198,33 @@ def main():
     streamed = args.workload == "c5"
     score_ms = []
 
+    # more pieces = more of the exchange hidden, but every piece visits all site chunks again (c3 on one GPU:
+    # 102 ms in one piece, 116 ms in four): 4 pieces at 2 ranks (13 GB over one link), 2 at 4, 1 at 8
+    sub_batches = args.sub_batches if args.sub_batches is not None else {2: 4, 3: 2, 4: 2}.get(world, 1)
+    pipelined = use_dist and args.exchange == "reads" and sub_batches > 1 and args.workload == "c3"
+
+    class Pieces:
+        """Result of a pipelined multi-rank search: this rank's merged share of every piece of the read set."""
+
+        def __init__(self, parts):
+            self.parts = parts
+
+        def __len__(self):
+            return sum(len(m) for _, m in self.parts)
+
+        def close(self):
+            for _, m in self.parts:
+                m.close()
+
+    def step_pipelined():
+        timings = []
+        parts = vdist.sharded_search_pipelined(ctx, genome, codes, max_mm, device=device, algorithm=algorithm,
+                                               sub_batches=sub_batches, timings=timings)
+        acc = {k: sum(t[k] for t in timings) for k in ("scan_ms", "sort_ms", "finalize_ms", "prep_ms", "hits", "pairs", "genome_bytes")}
+        acc["score_ms"] = 0.0
+        step.acc, step.total = acc, len(Pieces(parts))
+        return Pieces(parts), None
+
     def search_batch(batch_codes):
         if not use_dist:
             return genome.search(batch_codes, max_mm, algorithm=algorithm), None
@@ -219,6 +249,8 @@ def main():
         their packed feature rows + MIT scores on the GPU that owns the shard, before any gather."""
         if args.workload == "c4":
             return step_c4()
+        if pipelined:
+            return step_pipelined()
         if not streamed:
             return search_batch(codes)
         total, last = 0, None
@@ -255,7 +287,7 @@ def main():
     for i in range(args.steps):
         h, m = step()
         t = dict(ctx.timing())
-        if streamed or args.workload == "c4":
+        if streamed or pipelined or args.workload == "c4":
             t.update(step.acc)
             score_ms.append(step.acc["score_ms"])
         scan_ms.append(t["scan_ms"])
@@ -264,7 +296,7 @@ def main():
         prep_ms.append(t["prep_ms"])
         hits_local, sites_local, passes = t["hits"], t["sites"], max(passes, t["passes"])
         pairs_local, stream_bytes = t["pairs"], t["genome_bytes"]
-        total_hits = step.total if (streamed or args.workload == "c4") else (len(m) if m is not None else len(h))
+        total_hits = step.total if (streamed or pipelined or args.workload == "c4") else (len(m) if m is not None else len(h))
         h.close()
         if m is not None:
             m.close()
@@ -322,7 +354,7 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, desc), "guides": n_guides, "genome_bases": total_bases,
                        "max_mismatches": max_mm, "parallelism": "genome-shard x%d" % world, "algorithm": algorithm,
-                       "exchange": (args.exchange if use_dist else None),
+                       "exchange": (args.exchange if use_dist else None), "sub_batches": (sub_batches if pipelined else 1),
                        "hits_per_step": int(total_hits), "candidate_sites_per_s": total_hits * args.steps / dt,
                        "pam_valid_sites": int(total_sites), "scan_passes": passes,
                        "batch": args.batch if streamed else n_guides, "variant_genome": snp_info},

@@ -53,6 +53,17 @@ def _worker(rank, world, port, seed, q, mode="root"):
         if mode == "reads":
             received, counts = vdist.exchange_by_reads(local, len(guides))
             q.put((rank, received.numpy().tobytes(), counts))
+        elif mode == "async":
+            # two exchanges in flight one after the other without waiting in between (what the pipelined
+            # search does): the second is issued while the first may still be travelling
+            r1, c1, q1 = vdist.start_exchange_by_reads(local, len(guides))
+            for req in q1:
+                req.wait()
+            r2, c2, q2 = vdist.start_exchange_by_reads(local, len(guides))
+            for req in q2:
+                req.wait()
+            assert c1 == c2 and r1.numpy().tobytes() == r2.numpy().tobytes()
+            q.put((rank, r2.numpy().tobytes(), c2))
         else:
             gathered, counts = vdist.gather_records(local)
             if rank == 0:
@@ -100,8 +111,9 @@ def test_gather_records_over_gloo(world, oracle):
     assert merged.tobytes() == whole.tobytes()
 
 
+@pytest.mark.parametrize("mode", ["reads", "async"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_exchange_by_reads_over_gloo(world, oracle):
+def test_exchange_by_reads_over_gloo(world, oracle, mode):
     """exchange="reads": every rank ends up with the records of its read range from all genome shards, in
     shard order; merging each rank's part and concatenating the ranks gives the global result."""
     from helpers import make_genome, random_guides
@@ -111,7 +123,7 @@ def test_exchange_by_reads_over_gloo(world, oracle):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, q, "reads")) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=120) for _ in range(world))

@@ -246,6 +246,19 @@ def _rank_worker(rank, world, port, q, exchange="root"):
         packed = va.PackedGenome.from_sequences(contigs)
         c = va.Context(0)  # both ranks share the one GPU of the test box; the data path is per rank
         shard = c.load_genome(packed, rank, world)
+        if exchange == "pipelined":
+            parts = vdist.sharded_search_pipelined(c, shard, va.pack_guides(guides), 7, sub_batches=3)
+            blobs = []
+            for first, m in parts:
+                rec = m.to_numpy().copy()
+                rec["guide"] += first  # records count reads from the first read of their piece
+                blobs.append((first, rank, rec.tobytes()))
+                m.close()
+            q.put(blobs)
+            shard.close()
+            c.close()
+            dist.barrier()
+            return
         merged, local = vdist.sharded_search(c, shard, va.pack_guides(guides), 7, exchange=exchange)
         if exchange == "reads":
             q.put((rank, merged.to_numpy().tobytes()))
@@ -310,6 +323,33 @@ def test_sharded_search_exchange_by_reads_over_gloo(oracle):
         p.join(timeout=120)
         assert p.exitcode == 0
     blob = b"".join(b for _, b in sorted(got))
+    rng = np.random.default_rng(4242)
+    guides = random_guides(rng, 16)
+    contigs = make_genome(4242, [300000, 120000, 70000, 23], guides, 7, n_plant=400, n_runs=6)
+    want = oracle.search_fast(contigs, guides, 7)
+    assert blob == want.tobytes()
+
+
+def test_sharded_search_pipelined_over_gloo(oracle):
+    """Two ranks, the reads in three pieces: the exchange of one piece is in flight during the search of the
+    next; pieces in read order, within a piece the ranks' shares in rank order = the global result."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_rank_worker, args=(r, 2, port, q, "pipelined")) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    assert all(isinstance(g, list) for g in got), got
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    blob = b"".join(b for _, _, b in sorted(got[0] + got[1]))
     rng = np.random.default_rng(4242)
     guides = random_guides(rng, 16)
     contigs = make_genome(4242, [300000, 120000, 70000, 23], guides, 7, n_plant=400, n_runs=6)

@@ -61,13 +61,9 @@ def read_range(n_reads, rank, world):
     return n_reads * rank // world, n_reads * (rank + 1) // world
 
 
-def exchange_by_reads(local, n_reads, group=None):
-    """local: 1-D uint8 tensor with this rank's records, sorted by (read, strand, contig, pos).
-
-    Every rank receives, from every rank, the records of its own read range (read_range); returns the
-    received records concatenated in source-rank order (= genome-shard order, what vsc_hits_merge
-    expects) and the per-source counts.  One all_gather of the world x world count matrix + one
-    grouped send/recv of the payloads straight into their final place."""
+def start_exchange_by_reads(local, n_reads, group=None):
+    """Issues the exchange of exchange_by_reads and returns without waiting for the payloads:
+    (receive buffer, per-source counts, outstanding requests)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     rec = local.view(torch.int32).view(-1, 4)
@@ -91,9 +87,20 @@ def exchange_by_reads(local, n_reads, group=None):
             ops.append(dist.P2POp(dist.isend, local[cut[peer]:cut[peer + 1]], peer, group))
         if counts[peer] > 0:
             ops.append(dist.P2POp(dist.irecv, out[offs[peer]:offs[peer + 1]], peer, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    return out, counts, reqs
+
+
+def exchange_by_reads(local, n_reads, group=None):
+    """local: 1-D uint8 tensor with this rank's records, sorted by (read, strand, contig, pos).
+
+    Every rank receives, from every rank, the records of its own read range (read_range); returns the
+    received records concatenated in source-rank order (= genome-shard order, what vsc_hits_merge
+    expects) and the per-source counts.  One all_gather of the world x world count matrix + one
+    grouped send/recv of the payloads straight into their final place."""
+    out, counts, reqs = start_exchange_by_reads(local, n_reads, group)
+    for req in reqs:
+        req.wait()
     return out, counts
 
 
@@ -138,3 +145,41 @@ def sharded_search(ctx, genome_shard, codes, max_mismatches, extra_pam=None, gro
             torch.cuda.current_stream(gathered.device).synchronize()
         merged = merge_shard_records(ctx, gathered.data_ptr(), gathered.is_cuda, counts, len(codes))
     return merged, hits
+
+
+def sharded_search_pipelined(ctx, genome_shard, codes, max_mismatches, extra_pam=None, group=None, device=None,
+                             algorithm="auto", sub_batches=4, timings=None):
+    """exchange="reads" with the read set cut into `sub_batches` consecutive pieces: the exchange of piece i
+    travels over xGMI while piece i + 1 is searched ("chunked by guide batch so that
+    gather overlaps the next batch's scan").
+
+    Returns [(first read of the piece, merged hits of this rank's share of the piece)], in read order; the
+    records' `guide` fields count from the first read of their piece.  `timings`, if a list, receives the
+    library's timing of every piece's search."""
+    n = len(codes)
+    cuts = [n * i // sub_batches for i in range(sub_batches + 1)]
+    pieces = [(cuts[i], codes[cuts[i]:cuts[i + 1]]) for i in range(sub_batches) if cuts[i + 1] > cuts[i]]
+    out = []
+    pending = None
+
+    def finish(p):
+        first, n_reads, hits, local, recv, counts, reqs = p
+        for req in reqs:
+            req.wait()
+        if recv.is_cuda:
+            torch.cuda.current_stream(recv.device).synchronize()
+        out.append((first, merge_shard_records(ctx, recv.data_ptr(), recv.is_cuda, counts, n_reads)))
+        hits.close()  # the send buffers alias its records: only now
+
+    for first, part in pieces:
+        hits = genome_shard.search(part, max_mismatches, extra_pam, algorithm=algorithm)  # overlaps the pending exchange
+        if timings is not None:
+            timings.append(dict(ctx.timing()))
+        if pending is not None:
+            finish(pending)
+        local = _records_tensor(hits, device)
+        recv, counts, reqs = start_exchange_by_reads(local, len(part), group)
+        pending = (first, len(part), hits, local, recv, counts, reqs)
+    if pending is not None:
+        finish(pending)
+    return out
