@@ -66,31 +66,39 @@ def test_c2_scan_and_seed_agree_and_find_planted_sites(big):
         assert (gi, c, pos, strand) in found
 
 
+def _digest(hits, chunk=1 << 27):
+    """(count, strictly ascending?, max NM, three checksums) of a result, computed in HBM chunk by chunk."""
+    rec = _device_records(hits)
+    n = rec.shape[0]
+    ascending, max_nm, sums, last = True, 0, [0, 0, 0], None
+    for b in range(0, n, chunk):
+        r = rec[b:b + chunk]
+        k = _keys(r)
+        ascending = ascending and bool((k[1:] > k[:-1]).all()) and (last is None or int(k[0]) > last)
+        last = int(k[-1])
+        mask = (r[:, 3] & 0x7FFFFF).to(torch.int64)
+        nm = ((r[:, 3] >> 23) & 31).to(torch.int64)
+        max_nm = max(max_nm, int(nm.max()))
+        sums[0] += int(k.sum())
+        sums[1] += int((k ^ (mask << 7)).sum())
+        sums[2] += int(nm.sum())
+        del k, mask, nm
+    return n, ascending, max_nm, sums
+
+
 def test_c3_scan_and_seed_agree_on_the_device(big):
     """1.6e9 records per result: compared where they are (HBM), through torch views of the record buffers."""
     ctx, packed, genome, guides, planted = big
     h_seed = genome.search(guides, 8, algorithm="seed")
-    n = len(h_seed)
-    assert n > 1_000_000_000
-    rec = _device_records(h_seed)
-    k = _keys(rec)
-    assert bool((k[1:] > k[:-1]).all())  # strictly ascending
-    mask = rec[:, 3] & 0x7FFFFF
-    nm = (rec[:, 3] >> 23) & 31
-    assert int(nm.max()) <= 8
-    checksum = (int(k.sum()), int((k ^ (mask.to(torch.int64) << 7)).sum()), int(nm.to(torch.int64).sum()))
-    del rec, k, mask, nm
+    n, ascending, max_nm, sums = _digest(h_seed)
+    assert n > 1_000_000_000 and ascending and max_nm <= 8
+    mid = n // 2
+    seed_mid = _device_records(h_seed)[mid:mid + 1_000_000].clone()
+    h_seed.close()
     torch.cuda.empty_cache()
     h_scan = genome.search(guides, 8, algorithm="scan")
-    assert len(h_scan) == n
-    rec = _device_records(h_scan)
-    k = _keys(rec)
-    mask = rec[:, 3] & 0x7FFFFF
-    nm = (rec[:, 3] >> 23) & 31
-    assert checksum == (int(k.sum()), int((k ^ (mask.to(torch.int64) << 7)).sum()), int(nm.to(torch.int64).sum()))
-    # and record by record on a slice from the middle of each
-    mid = n // 2
-    seed_mid = _device_records(h_seed)[mid:mid + 1_000_000]
-    assert bool((seed_mid == rec[mid:mid + 1_000_000]).all())
-    h_seed.close()
+    assert _digest(h_scan) == (n, True, max_nm, sums)
+    # and record by record on a slice from the middle
+    assert bool((seed_mid == _device_records(h_scan)[mid:mid + 1_000_000]).all())
     h_scan.close()
+    torch.cuda.empty_cache()

@@ -97,6 +97,16 @@ def lib():
             raise ImportError(
                 "libvarscot_hip.so is not built (%s). Build it with `make -C varscot_amd/csrc` or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own copy of the HIP runtime.  Two runtimes in one process do not share
+        # the device: whichever initialises it second reports "no GPU".  With torch imported first the
+        # dynamic loader resolves this library's libamdhip64 dependency to the copy torch already
+        # loaded, so there is ONE runtime whatever the later order of initialisation.  (varscot_amd.dist
+        # and bench.py need torch anyway; the C++ tools never load it.)
+        if os.environ.get("VSC_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(L, name)  # AttributeError = header and library out of sync
