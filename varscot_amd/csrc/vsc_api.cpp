@@ -128,7 +128,7 @@ int fail(vsc_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
 #define VSC_HIP(ctx, call)                                                 \
     do {                                                                   \
         hipError_t e_ = (call);                                            \
-        if (e_ != hipSuccess) return fail((ctx), VSC_ERR_DEVICE, #call, e_); \
+        if (e_ != hipSuccess) return fail((ctx), e_ == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, #call, e_); \
     } while (0)
 
 // Scoring reads the genome at random hit positions: give it the interleaved copy of the planes.
