@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--sub-batches", type=int, default=None,
                     help="multi-rank runs with --exchange reads: cut the reads into this many pieces and overlap the "
                          "exchange of one piece with the search of the next (default: 4 at 2 ranks, 2 at 3-4, 1 otherwise)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="rehearsal of the multi-rank control flow on a box with ONE GPU: all ranks use cuda:0, the "
+                         "process group is gloo and the records travel through host memory (use a small workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange/merge path even with one rank")
     ap.add_argument("--exchange", default="reads", choices=["reads", "root"],
@@ -133,13 +136,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+    xdev = None if args.rehearse else device  # where the exchanged records live (None: host memory)
 
     # ---- inputs: this rank's shard of the synthetic genome, resident in HBM ------------------------
     table, names = synth.contig_table(total_bases)
@@ -201,7 +210,7 @@ def main():
     # more pieces = more of the exchange hidden, but every piece visits all site chunks again (c3 on one GPU:
     # 102 ms in one piece, 116 ms in four): 4 pieces at 2 ranks (13 GB over one link), 2 at 4, 1 at 8
     sub_batches = args.sub_batches if args.sub_batches is not None else {2: 4, 3: 2, 4: 2}.get(world, 1)
-    pipelined = use_dist and args.exchange == "reads" and sub_batches > 1 and args.workload == "c3"
+    pipelined = use_dist and args.exchange == "reads" and sub_batches > 1 and args.workload in ("c2", "c3")
 
     class Pieces:
         """Result of a pipelined multi-rank search: this rank's merged share of every piece of the read set."""
@@ -218,7 +227,7 @@ def main():
 
     def step_pipelined():
         timings = []
-        parts = vdist.sharded_search_pipelined(ctx, genome, codes, max_mm, device=device, algorithm=algorithm,
+        parts = vdist.sharded_search_pipelined(ctx, genome, codes, max_mm, device=xdev, algorithm=algorithm,
                                                sub_batches=sub_batches, timings=timings)
         acc = {k: sum(t[k] for t in timings) for k in ("scan_ms", "sort_ms", "finalize_ms", "prep_ms", "hits", "pairs", "genome_bytes")}
         acc["score_ms"] = 0.0
@@ -228,7 +237,7 @@ def main():
     def search_batch(batch_codes):
         if not use_dist:
             return genome.search(batch_codes, max_mm, algorithm=algorithm), None
-        merged, local = vdist.sharded_search(ctx, genome, batch_codes, max_mm, device=device, algorithm=algorithm,
+        merged, local = vdist.sharded_search(ctx, genome, batch_codes, max_mm, device=xdev, algorithm=algorithm,
                                              exchange=args.exchange)
         return local, merged
 
@@ -303,11 +312,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # every rank holds a part of the result (exchange = reads) or rank 0 holds it all (root): sum of the shard hits
-        agg = torch.tensor([float(sites_local), float(hits_local)], dtype=torch.float64, device=device)
+        agg = torch.tensor([float(sites_local), float(hits_local)], dtype=torch.float64, device=xdev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         total_sites = float(agg[0].item())
         total_hits = int(agg[1].item())
