@@ -370,6 +370,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel, "launch_ms": scan_avg_ms, "algorithmic_bytes": alg_bytes,
+                         # SURVEY.md 8(d)'s figure for ANY search of this shape (planes once + 16 B per hit and read),
+                         # whatever data structure the kernel actually reads
+                         "survey_bytes": 0.375 * own_bases + 16.0 * hits_local + 16.0 * n_guides,
+                         "survey_frac": (0.375 * own_bases + 16.0 * hits_local + 16.0 * n_guides) / (scan_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "integer/bitwise compare kernel; VALU issue is the binding resource next to HBM "
                                  "(DESIGN.md section 4) - both are reported; valu counts the comparison only, not the hit path",
                          "valu": {"pair_compares_per_s": compares / (scan_avg_ms * 1e-3),
