@@ -593,41 +593,62 @@ __device__ __forceinline__ uint32_t spread(uint32_t word, int bit)
     return (uint32_t)((int32_t)(word << (31 - bit)) >> 31);
 }
 
-// Bit i of the result: site i of this lane's block is valid and within `budget` mismatches of the read on
-// the 16 rest positions.  rx = rest(hi) | rest(lo) << 16 of the read (wave-uniform), budget <= 15.
+// 7 one-bit inputs -> 3-bit count (4 full adders)
+__device__ __forceinline__ void count7(const uint32_t *m, uint32_t &b0, uint32_t &b1, uint32_t &b2)
+{
+    uint32_t s1, c1, s2, c2, c3;
+    full_add(m[0], m[1], m[2], s1, c1);
+    full_add(m[3], m[4], m[5], s2, c2);
+    full_add(s1, s2, m[6], b0, c3);
+    full_add(c1, c2, c3, b1, b2);
+}
+
+// 3-bit-sliced count <= k (k wave-uniform, 0..7)
+__device__ __forceinline__ uint32_t count_le(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t k)
+{
+    uint32_t le = ~b0 | spread(k, 0);
+    le = bitop3<0x8E>(b1, spread(k, 1), le);
+    return bitop3<0x8E>(b2, spread(k, 2), le);
+}
+
+// Bit i of the result: site i of this lane's block is valid, within `budget` mismatches of the read on the
+// 16 rest positions, and NOT already reported by an earlier segment.  rx = rest(hi) | rest(lo) << 16 of the
+// read (wave-uniform), budget <= 15.
+// Whatever the bucket's segment, the 16 rest positions are [7 positions of another segment][7 of the third]
+// [read positions 21, 22], so the adder tree first counts the two groups of seven (3 bits each) and then
+// adds them and the last two inputs: the same 30 instructions as a flat tree, and the group counts give
+// the duplicate test for free - a pair with <= k mismatches in an EARLIER segment (group A for segments 1
+// and 2, also group B for segment 2) was reported from that segment's bucket.  Without this 40 % of the
+// candidates at m = 8 (1.67 qualifying segments per hit on average) went through the hit path only to be
+// dropped there.
 __device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[2 * kRestBases], uint32_t rx, uint32_t budget,
-                                                  uint32_t valid)
+                                                  uint32_t valid, uint32_t seg, uint32_t k_seg)
 {
     uint32_t mm[kRestBases];
 #pragma unroll
     for (int q = 0; q < kRestBases; ++q)  // (hi ^ read hi) | (lo ^ read lo)
         mm[q] = bitop3<0xF6>(v[q] ^ spread(rx, q), v[kRestBases + q], spread(rx, kRestBases + q));
-    // 16 one-bit inputs -> 5-bit count (c4 .. c0), carry-save: 11 full and 4 half adders
-    uint32_t s0, s1, s2, s3, s4, s5, s6, k0, k1, k2, k3, k4, k5, k6, k7;
-    full_add(mm[0], mm[1], mm[2], s0, k0);
-    full_add(mm[3], mm[4], mm[5], s1, k1);
-    full_add(mm[6], mm[7], mm[8], s2, k2);
-    full_add(mm[9], mm[10], mm[11], s3, k3);
-    full_add(mm[12], mm[13], mm[14], s4, k4);
-    full_add(s0, s1, s2, s5, k5);
-    full_add(s3, s4, mm[15], s6, k6);
-    uint32_t c0, c1, c2, c3, c4;
-    half_add(s5, s6, c0, k7);
-    uint32_t t0, t1, t2, l0, l1, l2, l3;
-    full_add(k0, k1, k2, t0, l0);
-    full_add(k3, k4, k5, t1, l1);
-    full_add(t0, t1, k6, t2, l2);
-    half_add(t2, k7, c1, l3);
-    uint32_t u0, n0, n1;
-    full_add(l0, l1, l2, u0, n0);
-    half_add(u0, l3, c2, n1);
-    half_add(n0, n1, c3, c4);
+    uint32_t a0, a1, a2, b0, b1, b2;
+    count7(mm, a0, a1, a2);
+    count7(mm + kSegBases, b0, b1, b2);
+    // A + B + mm[14] + mm[15] -> c4 .. c0
+    uint32_t t0, t1, t2, k0, k1, k2, j0, j1, j2, c0, c1, c2, c3, c4;
+    full_add(a0, b0, mm[14], t0, k0);
+    half_add(t0, mm[15], c0, j0);
+    full_add(a1, b1, k0, t1, k1);
+    half_add(t1, j0, c1, j1);
+    full_add(a2, b2, k1, t2, k2);
+    half_add(t2, j1, c2, j2);
+    half_add(k2, j2, c3, c4);
     // count <= budget, from the least significant bit up: le_i = (~c_i & b_i) | (~(c_i ^ b_i) & le_{i-1})
     uint32_t le = ~c0 | spread(budget, 0);
     le = bitop3<0x8E>(c1, spread(budget, 1), le);
     le = bitop3<0x8E>(c2, spread(budget, 2), le);
     le = bitop3<0x8E>(c3, spread(budget, 3), le);
-    return bitop3<0x20>(le, c4, valid);  // le & ~c4 & valid
+    uint32_t ok = bitop3<0x20>(le, c4, valid);  // le & ~c4 & valid
+    if (seg >= 1) ok &= ~count_le(a0, a1, a2, k_seg);
+    if (seg >= 2) ok &= ~count_le(b0, b1, b2, k_seg);
+    return ok;
 }
 
 // Second half of the hit path.  A token = {hit word of one lane's block, read | owner lane << 26, read hi
@@ -761,7 +782,9 @@ __device__ __forceinline__ void sliced_load_sites(const SeedArgs &a, const v4u &
 }
 
 
-__global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_sliced_kernel(const SeedArgs a)
+// (amdgpu_waves_per_eu: 4 waves per SIMD = at most 128 VGPRs; without the hint the allocator settles at 129)
+__global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(4, 4))) void seed_sliced_kernel(
+    const SeedArgs a)
 {
     __shared__ uint4 s_tok[kWavesPerGroup][kSlicedTokCap];
     __shared__ uint64_t s_hkey[kWavesPerGroup][kSeedHitCap];
@@ -863,7 +886,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_sliced_kernel(cons
                         if (ry == 0xFFFFFFFFu) continue;  // list padding
                         const uint32_t rx = uniform(rd[u].x);
                         const uint32_t budget = m - (ry >> kListDistShift);
-                        const uint32_t word = sliced_within(v, rx, budget, valid);
+                        const uint32_t word = sliced_within(v, rx, budget, valid, seg, a.k_seg);
                         const uint64_t b = __ballot(word != 0);
                         if (b == 0) continue;
                         const uint32_t gid = ry & ((1u << kListDistShift) - 1u);
