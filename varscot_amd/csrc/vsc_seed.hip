@@ -708,10 +708,7 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
         const uint32_t t = ((f.rec.x ^ f.gp.x) | (f.rec.y ^ f.gp.y)) & kMask23;
         const uint32_t strand = (f.rec.x >> kSiteStrandBit) & 1u;
         const uint32_t pos = f.rec.z;
-        // a pair that also qualifies in an earlier segment was reported there
-        static_assert(kSegments == 3, "the duplicate test spells out segments 0 and 1");
-        if ((uint32_t)__popc(t & 0x7Fu) <= a.k_seg && seg >= 1) hit = false;
-        if ((uint32_t)__popc(t & 0x3F80u) <= a.k_seg && seg >= 2) hit = false;
+        // (pairs that an earlier segment reports never become tokens: sliced_within)
         const uint32_t mask = strand ? reverse23(t) : t;
         // right-edge rule, bidir_mapping.cpp:51-52 (see emit_hits in vsc_kernels.hip)
         if (hit && ((f.rec.x >> kSiteEdgeBit) & 1u)) {
