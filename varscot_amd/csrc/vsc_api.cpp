@@ -710,10 +710,7 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         sa.contig_end = genome->d_contig_end;
         sa.n_contigs = genome->n_contigs;
         sa.counters = (unsigned long long *)ctx->counters.p;
-        // resident groups per CU: 4 fit (registers / LDS of the sliced kernel); with long read lists and many
-        // hits (32+ reads per bucket) 3 are faster - the 32 KB of site records per resident chunk that the hit
-        // path gathers from then stay in L2 (measured: c3 31.9 ms with 3, 34.9 ms with 4; c2 2.66 vs 2.37 ms)
-        uint32_t groups_per_cu = genome->d_ix_vert ? (n_pairs >= 32ull * kBuckets ? 3 : 4) : 5;
+        uint32_t groups_per_cu = genome->d_ix_vert ? 4 : 5;  // resident groups per CU (registers / LDS of the kernel)
         if (const char *o = std::getenv("VSC_SEED_GROUPS_PER_CU")) groups_per_cu = (uint32_t)std::max(1, std::atoi(o));
         const uint32_t n_waves_max = (uint32_t)ctx->n_cus * groups_per_cu * kWavesPerGroup;
         const uint32_t grab = genome->d_ix_vert ? kSlicedGrab : kSeedGrab;
