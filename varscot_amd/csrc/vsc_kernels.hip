@@ -346,12 +346,14 @@ constexpr int kFinalizeHalo = 256;   // >= the largest group
 constexpr int kFinalizeTile = kFinalizeBlock * kFinalizeItems;
 constexpr int kFinalizeContigs = 1024;
 
+// kStaged: the contig table fits the LDS copy (a separate instantiation: merged into one loop the two table
+// pointers become a generic pointer and the binary search runs on flat loads)
+template <bool kStaged>
 __global__ __launch_bounds__(kFinalizeBlock) void finalize_kernel(const FinalizeArgs a)
 {
     __shared__ uint64_t s_key[kFinalizeTile + 2 * kFinalizeHalo];
     __shared__ uint32_t s_contig[kFinalizeContigs];  // contig starts: a genome has few, a variant genome millions
-    const bool contigs_staged = a.n_contigs <= (uint32_t)kFinalizeContigs;
-    if (contigs_staged)
+    if (kStaged)
         for (uint32_t t = threadIdx.x; t < a.n_contigs; t += kFinalizeBlock) s_contig[t] = a.contig_off[t];
     const uint64_t block_first = (uint64_t)blockIdx.x * kFinalizeTile;
     // tile = records [block_first - halo, block_first + tile + halo); slots outside [0, n) get a key no group shares
@@ -387,8 +389,13 @@ __global__ __launch_bounds__(kFinalizeBlock) void finalize_kernel(const Finalize
         const uint32_t pos = (uint32_t)key;
         const uint32_t strand = (uint32_t)(key >> 32) & 1u;
         uint32_t c, start;
-        if (contigs_staged) {
-            c = contig_of(s_contig, a.n_contigs, pos);
+        if (kStaged) {
+            uint32_t lo = 0, hi = a.n_contigs;  // contig_of on the LDS copy
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_contig[mid] <= pos) lo = mid; else hi = mid;
+            }
+            c = lo;
             start = s_contig[c];
         } else {
             c = contig_of(a.contig_off, a.n_contigs, pos);
@@ -408,7 +415,10 @@ hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream)
     if (args.n == 0) return hipSuccess;
     if (args.low_bits > 16 || (args.low_bits && !args.overflow)) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((args.n + kFinalizeTile - 1) / kFinalizeTile);
-    hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(kFinalizeBlock), 0, stream, args);
+    if (args.n_contigs <= (uint32_t)kFinalizeContigs)
+        hipLaunchKernelGGL(finalize_kernel<true>, dim3(blocks), dim3(kFinalizeBlock), 0, stream, args);
+    else
+        hipLaunchKernelGGL(finalize_kernel<false>, dim3(blocks), dim3(kFinalizeBlock), 0, stream, args);
     return hipGetLastError();
 }
 
