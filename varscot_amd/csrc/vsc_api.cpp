@@ -68,6 +68,9 @@ struct vsc_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // the output regions of a sliced search are sorted and finalized concurrently: region 0 on `stream`, the others here
+    hipStream_t aux[kParts - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t sorted_ev[kParts] = {nullptr, nullptr, nullptr, nullptr}, done_ev[kParts] = {nullptr, nullptr, nullptr, nullptr};
     std::string err;
     vsc_timing timing{};
     DeviceBuf counters, guides, keys_a, keys_b, vals_a, vals_b, sort_temp, score_mit, score_flags, score_feat;
@@ -244,6 +247,12 @@ int vsc_ctx_create(int device_id, vsc_ctx **out)
             vsc_ctx_destroy(ctx);
             return VSC_ERR_DEVICE;
         }
+    for (int i = 0; i < kParts; ++i)
+        if (hipEventCreate(&ctx->sorted_ev[i]) != hipSuccess || hipEventCreate(&ctx->done_ev[i]) != hipSuccess ||
+            (i + 1 < kParts && hipStreamCreate(&ctx->aux[i]) != hipSuccess)) {
+            vsc_ctx_destroy(ctx);
+            return VSC_ERR_DEVICE;
+        }
     *out = ctx;
     return VSC_OK;
 }
@@ -261,6 +270,14 @@ int vsc_ctx_destroy(vsc_ctx *ctx)
     for (auto &b : ctx->spare_records) b.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < kParts; ++i) {
+        if (ctx->sorted_ev[i]) (void)hipEventDestroy(ctx->sorted_ev[i]);
+        if (ctx->done_ev[i]) (void)hipEventDestroy(ctx->done_ev[i]);
+        if (i + 1 < kParts && ctx->aux[i]) {
+            (void)hipStreamSynchronize(ctx->aux[i]);
+            (void)hipStreamDestroy(ctx->aux[i]);
+        }
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VSC_OK;
@@ -649,10 +666,12 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
 
     const double sites_est = genome->sites ? (double)genome->sites : own_bases / 4;
     uint64_t cap = (uint64_t)(1.5 * sites_est * n_guides * hit_probability(params->max_mismatches)) + (1u << 20);
-    unsigned long long cnt[kCntSlots] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long cnt[kCntPart + 4 * kParts] = {};
 
     ScanArgs a{};
     SeedArgs sa{};
+    int n_parts = 0;             // > 0: sliced kernel, hits in n_parts output regions of part_cap records each
+    uint64_t part_cap = 0;
     int n_groups = 1;
     if (algo == VSC_ALGO_SCAN) {
         fill_pam(a, params);
@@ -721,7 +740,20 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         const uint64_t per_wave = cap / ((uint64_t)n_groups * kWavesPerGroup * 8);
         sa.reserve = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(kSeedHitCap, per_wave / kWave * kWave));
         if (const char *o = std::getenv("VSC_SEED_RESERVE")) sa.reserve = (uint32_t)std::atoi(o);
-        cap += (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
+        if (genome->d_ix_vert) {
+            // output regions by read range (quartiles): sorted and finalized concurrently below
+            // (worth it when there are many hits: long read lists; a small result sorts faster in one piece)
+            n_parts = (n_guides >= 64 && n_pairs >= 32ull * kBuckets) ? kParts : 1;
+            if (const char *o = std::getenv("VSC_SEED_PARTS")) n_parts = std::atoi(o) == 1 ? 1 : (n_guides >= 4 ? kParts : 1);
+            for (int i = 0; i + 1 < kParts; ++i)
+                sa.part_bound[i] = n_parts == 1 ? 0xFFFFFFFFu : (uint32_t)((uint64_t)n_guides * (i + 1) / kParts);
+            if (n_parts > 1) sa.reserve = std::min<uint32_t>(sa.reserve, 1024);  // every wave leaves one open block per region
+            // a region gets its share of the expected hits + 15 % (read ranges differ) + the open blocks
+            part_cap = cap / n_parts + cap / n_parts / 7 + 4096 + (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
+            cap = part_cap * n_parts;
+        } else {
+            cap += (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
+        }
     }
 
     ht.lap("prep enqueue");
@@ -739,6 +771,7 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
             sa.hit_keys = (uint64_t *)ctx->keys_a.p;
             sa.hit_vals = (uint32_t *)ctx->vals_a.p;
             sa.hit_cap = cap;
+            sa.part_cap = part_cap;
             // the per-pair test beats the min-tree variant at every m measured (fewer registers, no
             // re-derivation of hits); VSC_SEED_DENSE=0 selects the min-tree variant for experiments
             bool dense = true;
@@ -756,13 +789,30 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         if (!cnt[kCntOverflow]) break;
         if (t.passes >= 3) return cleanup(fail(ctx, VSC_ERR_DEVICE, "vsc_search: hit buffer overflowed repeatedly"));
         // the counters hold the true total (SEED: records placed + records lost, + one block per wave)
+        if (n_parts > 0) {
+            uint64_t need = 0;
+            for (int q = 0; q < n_parts; ++q) need = std::max<uint64_t>(need, cnt[kCntPart + 4 * q] + cnt[kCntPart + 4 * q + 2]);
+            part_cap = need + (need >> 6) + 4096 + (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
+            cap = part_cap * n_parts;
+            continue;
+        }
         cap = cnt[kCntHits] + cnt[kCntLost];
         cap += (cap >> 6) + 4096 + (algo == VSC_ALGO_SEED ? (uint64_t)n_groups * kWavesPerGroup * sa.reserve : 0);
     }
     // SEED: counters[kCntHits] counts reserved records, kCntPad of them are sentinels (key = all ones)
     // that the sort moves behind the n real hits
-    const uint64_t n_sort = cnt[kCntHits];
-    const uint64_t n = n_sort - cnt[kCntPad];
+    uint64_t n_sort = cnt[kCntHits];
+    uint64_t n = n_sort - cnt[kCntPad];
+    uint64_t part_sort[kParts] = {0, 0, 0, 0}, part_n[kParts] = {0, 0, 0, 0};
+    if (n_parts > 0) {
+        n_sort = n = 0;
+        for (int q = 0; q < n_parts; ++q) {
+            part_sort[q] = cnt[kCntPart + 4 * q];
+            part_n[q] = part_sort[q] - cnt[kCntPart + 4 * q + 1];
+            n_sort += part_sort[q];
+            n += part_n[q];
+        }
+    }
     if (algo == VSC_ALGO_SCAN) {
         const_cast<vsc_genome *>(genome)->sites = cnt[kCntSites];
         t.sites = cnt[kCntSites];
@@ -794,12 +844,56 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
             begin_bit = std::min(16u, (unsigned)std::atoi(o));
             forced = true;
         }
-        VSC_HIP_H(ctx->keys_b.ensure(n_sort * sizeof(uint64_t)));
-        VSC_HIP_H(ctx->vals_b.ensure(n_sort * sizeof(uint32_t)));
+        const uint64_t sorted_cap = n_parts > 0 ? cap : n_sort;
+        VSC_HIP_H(ctx->keys_b.ensure(sorted_cap * sizeof(uint64_t)));
+        VSC_HIP_H(ctx->vals_b.ensure(sorted_cap * sizeof(uint32_t)));
         ht.lap("sort buffers ensure");
         VSC_HIP_H(take_records(ctx, hits, n));
         ht.lap("record storage");
-        for (;;) {
+        for (; n_parts > 0;) {
+            // one sort + finalize per output region, each on a stream of its own: the passes of one sort
+            // leave the memory system idle between kernels and at their tails, and finalize_kernel is not
+            // bandwidth-bound - four of them interleaved finish in less time than one after the other
+            size_t temp_bytes = 0;
+            for (int q = 0; q < n_parts; ++q) {
+                size_t tb = 0;
+                VSC_HIP_H(sort_temp_bytes(std::max<uint64_t>(part_sort[q], 1), begin_bit, end_bit, &tb));
+                temp_bytes = std::max(temp_bytes, (tb + 255) / 256 * 256);
+            }
+            VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes * n_parts, 16)));
+            uint64_t out_off = 0;
+            for (int q = 0; q < n_parts; ++q) {
+                hipStream_t st = q == 0 ? ctx->stream : ctx->aux[q - 1];
+                const uint64_t off = (uint64_t)q * part_cap;
+                if (part_sort[q])
+                    VSC_HIP_H(launch_sort((char *)ctx->sort_temp.p + temp_bytes * q, temp_bytes, (const uint64_t *)ctx->keys_a.p + off,
+                                          (uint64_t *)ctx->keys_b.p + off, (const uint32_t *)ctx->vals_a.p + off,
+                                          (uint32_t *)ctx->vals_b.p + off, part_sort[q], begin_bit, end_bit, st));
+                VSC_HIP_H(hipEventRecord(ctx->sorted_ev[q], st));
+                FinalizeArgs f{};
+                f.keys = (const uint64_t *)ctx->keys_b.p + off;
+                f.vals = (const uint32_t *)ctx->vals_b.p + off;
+                f.n = part_n[q];
+                f.low_bits = begin_bit;
+                f.overflow = (unsigned long long *)ctx->counters.p + kCntGroups;
+                f.contig_off = genome->d_contig_off;
+                f.n_contigs = genome->n_contigs;
+                f.out = hits->d_records + out_off;
+                VSC_HIP_H(launch_finalize(f, st));
+                out_off += part_n[q];
+                VSC_HIP_H(hipEventRecord(ctx->done_ev[q], st));
+                if (q > 0) VSC_HIP_H(hipStreamWaitEvent(ctx->stream, ctx->done_ev[q], 0));
+            }
+            if (begin_bit <= 8) break;  // groups of at most 256 records: always rankable
+            unsigned long long too_large = 0;
+            VSC_HIP_H(hipMemcpyAsync(&too_large, (unsigned long long *)ctx->counters.p + kCntGroups, sizeof too_large,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+            VSC_HIP_H(hipStreamSynchronize(ctx->stream));
+            if (!too_large) break;
+            if (forced) return cleanup(fail(ctx, VSC_ERR_DEVICE, "vsc_search: VSC_SORT_LOW_BITS leaves groups too large to order"));
+            begin_bit = low_bits_for(8);
+        }
+        for (; n_parts == 0;) {
             size_t temp_bytes = 0;
             VSC_HIP_H(sort_temp_bytes(n_sort, begin_bit, end_bit, &temp_bytes));
             VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
@@ -835,10 +929,22 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     t.prep_ms = ms;
     VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
     t.scan_ms = ms;
-    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
-    t.sort_ms = ms;
-    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
-    t.finalize_ms = ms;
+    if (n_parts > 0 && n > 0) {
+        // regions overlap: "sort" = until the last region is sorted, "finalize" = what remains after that
+        float last_sorted = 0, total = 0;
+        for (int q = 0; q < n_parts; ++q) {
+            VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[2], ctx->sorted_ev[q]));
+            last_sorted = std::max(last_sorted, ms);
+        }
+        VSC_HIP_H(hipEventElapsedTime(&total, ctx->ev[2], ctx->ev[4]));
+        t.sort_ms = last_sorted;
+        t.finalize_ms = std::max(0.0f, total - last_sorted);
+    } else {
+        VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+        t.sort_ms = ms;
+        VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+        t.finalize_ms = ms;
+    }
     VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]));
     t.total_ms = ms;
     ctx->timing = t;

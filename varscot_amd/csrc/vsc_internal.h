@@ -46,9 +46,14 @@ enum { kCntHits = 0, kCntChunk = 1, kCntSites = 2, kCntOverflow = 3, kCntVisited
 // The sliced kernel hands out chunks through kCursors work cursors, one per slice of the chunk range, 128
 // bytes apart behind the counters: one device-wide cursor sustains only ~90 atomics/us
 // (MI355X_MICROARCH.md), which for 270 000 grabs is 3 ms - as long as a whole 1 000-read search.
+// The sliced kernel writes its hits into kParts regions by read range (quartiles of the read indices): the
+// regions are sorted and finalized independently, on streams of their own, and their concatenation is the
+// result.  Per region: counters[kCntPart + 4 p + {0, 1, 2}] = records reserved, sentinels among them, records lost.
+constexpr int kParts = 4;
+constexpr int kCntPart = 8;
 constexpr int kCursors = 32;
 constexpr int kCursorStride = 16;  // in 8-byte words
-constexpr int kCursorBase = 16;    // first cursor, in 8-byte words from the start of the counter buffer
+constexpr int kCursorBase = 32;    // first cursor, in 8-byte words from the start of the counter buffer
 constexpr int kCounterWords = kCursorBase + kCursors * kCursorStride;
 
 // Required plane bits of the two PAM letters, expanded to all-ones / all-zero words.
@@ -122,6 +127,8 @@ struct SeedArgs {
     uint32_t *hit_vals;
     unsigned long long hit_cap;
     uint32_t reserve;              // records a wave reserves per atomic on counters[kCntHits]
+    uint32_t part_bound[kParts - 1];  // sliced kernel: first read index of regions 1 .. kParts - 1 (~0: region unused)
+    unsigned long long part_cap;   // sliced kernel: records per region; region p = [p * part_cap, (p + 1) * part_cap)
     unsigned long long *counters;  // kCntHits (reserved records), kCntPad (sentinels among them), kCntChunk,
                                    // kCntSites (= pairs compared), kCntVisited, kCntOverflow
 };

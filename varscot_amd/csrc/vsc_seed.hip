@@ -249,6 +249,8 @@ struct SeedWave {
     uint32_t thead;  // sliced kernel: ring slot of the oldest pending token
     unsigned long long res_base;  // this wave's reserved range of the global hit arrays
     uint32_t res_left;
+    uint32_t cp;     // sliced kernel: the output region the staged hits and the reservation belong to
+    uint4 *parts;    // sliced kernel: {res_base lo, hi, res_left, 0} of the regions this wave is not writing to
 };
 
 // Moves the resolved hits of this wave to the global hit arrays.  A single device-wide cursor
@@ -662,6 +664,65 @@ struct SlicedFetch {
     uint4 rec;  // site record of the lowest set bit
 };
 
+// seed_flush_hits for the sliced kernel: the staged hits belong to output region w.cp
+__device__ __forceinline__ void sliced_flush_hits(const SeedArgs &a, SeedWave &w)
+{
+    unsigned long long *const cursor = &a.counters[kCntPart + 4 * w.cp];
+    uint32_t done = 0;
+    while (done < w.hn) {
+        if (w.res_left == 0) {
+            const uint32_t want = a.reserve ? a.reserve : w.hn - done;
+            unsigned long long rel = 0;
+            if (w.lane == 0) rel = atomicAdd(cursor, (unsigned long long)want);
+            rel = ((unsigned long long)uniform((uint32_t)(rel >> 32)) << 32) | uniform((uint32_t)rel);
+            if (rel + want > a.part_cap) {
+                // region too small: undo the reservation, count what is lost; the host re-runs with room for
+                // reserved + lost records (+ one block per wave) in every region
+                if (w.lane == 0) {
+                    atomicAdd(cursor, 0ull - (unsigned long long)want);
+                    atomicAdd(cursor + 2, (unsigned long long)(w.hn - done));
+                    atomicMax(&a.counters[kCntOverflow], 1ull);
+                }
+                break;
+            }
+            w.res_base = (unsigned long long)w.cp * a.part_cap + rel;
+            w.res_left = want;
+        }
+        const uint32_t take = min(w.hn - done, w.res_left);
+        for (uint32_t i = w.lane; i < take; i += kWave) {
+            a.hit_keys[w.res_base + i] = w.hkey[done + i];
+            a.hit_vals[w.res_base + i] = w.hval[done + i];
+        }
+        w.res_base += take;
+        w.res_left -= take;
+        done += take;
+    }
+    wave_sync();
+    w.hn = 0;
+}
+
+// the wave turns to output region p (wave-uniform): what is staged goes out, the reservations are swapped
+__device__ __forceinline__ void sliced_switch_region(const SeedArgs &a, SeedWave &w, uint32_t p)
+{
+    sliced_flush_hits(a, w);
+    if (w.lane == 0) w.parts[w.cp] = make_uint4((uint32_t)w.res_base, (uint32_t)(w.res_base >> 32), w.res_left, 0u);
+    wave_sync();
+    const uint4 st = w.parts[p];
+    w.res_base = ((unsigned long long)uniform(st.y) << 32) | uniform(st.x);
+    w.res_left = uniform(st.z);
+    w.cp = p;
+}
+
+__device__ __forceinline__ void sliced_finish_hits(const SeedArgs &a, SeedWave &w)
+{
+    for (uint32_t q = 0; q < (uint32_t)kParts; ++q) {
+        sliced_switch_region(a, w, q);  // flushes what is staged (first turn), then pads region q's open block
+        for (uint32_t i = w.lane; i < w.res_left; i += kWave) a.hit_keys[w.res_base + i] = ~0ull;
+        if (w.lane == 0 && w.res_left) atomicAdd(&a.counters[kCntPart + 4 * q + 1], (unsigned long long)w.res_left);
+        w.res_left = 0;
+    }
+}
+
 // ring slot of running position p (p < 2 * kSlicedTokCap is all the callers need)
 __device__ __forceinline__ uint32_t ring_slot(uint32_t p)
 {
@@ -702,6 +763,7 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
         if (rest != 0) w.tok4[ring_slot(lanes_below(again, ring_tail(w)))] = make_uint4(rest, f.hi, f.gp.x, f.gp.y);
         w.ntok += (uint32_t)__popcll(again);
     }
+    const uint32_t gid_of = f.hi & ((1u << kTokLaneShift) - 1u);
     uint64_t key = 0;
     uint32_t val = 0;
     if (hit) {
@@ -716,19 +778,27 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
                 is_contig_end(a.contig_end, a.n_contigs, pos + VSC_READ_LEN))
                 hit = false;
         }
-        const uint32_t gid = f.hi & ((1u << kTokLaneShift) - 1u);
-        key = ((uint64_t)gid << 33) | ((uint64_t)strand << 32) | pos;
+        key = ((uint64_t)gid_of << 33) | ((uint64_t)strand << 32) | pos;
         val = ((uint32_t)__popc(t) << 23) | mask;
     }
-    const uint64_t b = __ballot(hit);
-    if (hit) {
-        const uint32_t at = lanes_below(b, w.hn);
-        w.hkey[at] = key;
-        w.hval[at] = val;
+    // the hits of a pass belong to one output region, two at a boundary between read ranges
+    const uint32_t region = (gid_of >= a.part_bound[0]) + (gid_of >= a.part_bound[1]) + (gid_of >= a.part_bound[2]);
+    uint64_t todo = __ballot(hit);
+    while (todo != 0) {
+        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)region, (int)__builtin_ctzll(todo));
+        if (p != w.cp) sliced_switch_region(a, w, p);
+        const bool mine = hit && region == p;
+        const uint64_t b = __ballot(mine);
+        if (mine) {
+            const uint32_t at = lanes_below(b, w.hn);
+            w.hkey[at] = key;
+            w.hval[at] = val;
+        }
+        wave_sync();
+        w.hn += (uint32_t)__popcll(b);
+        if (w.hn > kSeedHitCap - kWave) sliced_flush_hits(a, w);
+        todo &= ~b;
     }
-    wave_sync();
-    w.hn += (uint32_t)__popcll(b);
-    if (w.hn > kSeedHitCap - kWave) seed_flush_hits(a, w);
 }
 
 // Resolves tokens in passes of 64.  drain = false: full passes only - what is left (< 64 tokens) waits
@@ -787,6 +857,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     __shared__ uint64_t s_hkey[kWavesPerGroup][kSeedHitCap];
     __shared__ uint32_t s_hval[kWavesPerGroup][kSeedHitCap];
     __shared__ uint4 s_list[kWavesPerGroup][kWave];  // the current tile of 64 read-list entries
+    __shared__ uint4 s_parts[kWavesPerGroup][kParts];
 
     const uint32_t wave = threadIdx.x / kWave;
     SeedWave w;
@@ -800,6 +871,9 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     w.hn = 0;
     w.res_base = 0;
     w.res_left = 0;
+    w.cp = 0;
+    w.parts = s_parts[wave];
+    if (w.lane < (uint32_t)kParts) w.parts[w.lane] = make_uint4(0u, 0u, 0u, 0u);
 
     uint4 *const lt = s_list[wave];
     const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
@@ -898,7 +972,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
             if (w.ntok) sliced_resolve(a, w, cur.x, seg, true);
         }
     }
-    seed_finish_hits(a, w);
+    sliced_finish_hits(a, w);
     if (w.lane == 0 && pairs) {
         atomicAdd(&a.counters[kCntSites], pairs);
         atomicAdd(&a.counters[kCntVisited], visited);
