@@ -69,8 +69,8 @@ struct vsc_ctx {
     bool own_stream = false;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // the output regions of a sliced search are sorted and finalized concurrently: region 0 on `stream`, the others here
-    hipStream_t aux[kParts - 1] = {nullptr, nullptr, nullptr};
-    hipEvent_t sorted_ev[kParts] = {nullptr, nullptr, nullptr, nullptr}, done_ev[kParts] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux[kParts - 1] = {};
+    hipEvent_t sorted_ev[kParts] = {}, done_ev[kParts] = {};
     std::string err;
     vsc_timing timing{};
     DeviceBuf counters, guides, keys_a, keys_b, vals_a, vals_b, sort_temp, score_mit, score_flags, score_feat;
@@ -803,7 +803,7 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     // that the sort moves behind the n real hits
     uint64_t n_sort = cnt[kCntHits];
     uint64_t n = n_sort - cnt[kCntPad];
-    uint64_t part_sort[kParts] = {0, 0, 0, 0}, part_n[kParts] = {0, 0, 0, 0};
+    uint64_t part_sort[kParts] = {}, part_n[kParts] = {};
     if (n_parts > 0) {
         n_sort = n = 0;
         for (int q = 0; q < n_parts; ++q) {

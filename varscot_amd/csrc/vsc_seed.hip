@@ -782,7 +782,9 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
         val = ((uint32_t)__popc(t) << 23) | mask;
     }
     // the hits of a pass belong to one output region, two at a boundary between read ranges
-    const uint32_t region = (gid_of >= a.part_bound[0]) + (gid_of >= a.part_bound[1]) + (gid_of >= a.part_bound[2]);
+    uint32_t region = 0;
+#pragma unroll
+    for (int i = 0; i + 1 < kParts; ++i) region += gid_of >= a.part_bound[i];
     uint64_t todo = __ballot(hit);
     while (todo != 0) {
         const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)region, (int)__builtin_ctzll(todo));
