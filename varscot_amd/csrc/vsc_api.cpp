@@ -739,7 +739,6 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         // (the unused tail of every wave's last block is sorted along as sentinels)
         const uint64_t per_wave = cap / ((uint64_t)n_groups * kWavesPerGroup * 8);
         sa.reserve = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(kSeedHitCap, per_wave / kWave * kWave));
-        if (const char *o = std::getenv("VSC_SEED_RESERVE")) sa.reserve = (uint32_t)std::atoi(o);
         if (genome->d_ix_vert) {
             // output regions by read range (quartiles): sorted and finalized concurrently below
             // (worth it when there are many hits: long read lists; a small result sorts faster in one piece)
@@ -748,10 +747,12 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
             for (int i = 0; i + 1 < kParts; ++i)
                 sa.part_bound[i] = n_parts == 1 ? 0xFFFFFFFFu : (uint32_t)((uint64_t)n_guides * (i + 1) / kParts);
             if (n_parts > 1) sa.reserve = std::min<uint32_t>(sa.reserve, 1024);  // every wave leaves one open block per region
+            if (const char *o = std::getenv("VSC_SEED_RESERVE")) sa.reserve = (uint32_t)std::atoi(o);
             // a region gets its share of the expected hits + 15 % (read ranges differ) + the open blocks
             part_cap = cap / n_parts + cap / n_parts / 7 + 4096 + (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
             cap = part_cap * n_parts;
         } else {
+            if (const char *o = std::getenv("VSC_SEED_RESERVE")) sa.reserve = (uint32_t)std::atoi(o);
             cap += (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
         }
     }
