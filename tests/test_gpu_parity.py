@@ -526,3 +526,24 @@ def test_pair_kernel_still_matches(oracle, monkeypatch):
             assert hits_as_tuples(got) == hits_as_tuples(want)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("parts", ["1", "4"])
+def test_output_regions_by_read_range(ctx, oracle, parts, monkeypatch):
+    """The sliced kernel writes its hits into regions by read range that are sorted and finalized
+    concurrently (on by default only for long read lists): forced on and off here, with a hit buffer that
+    has to grow, reads whose hits straddle the region boundaries, and a read count that is not a multiple
+    of four."""
+    monkeypatch.setenv("VSC_SEED_PARTS", parts)
+    rng = np.random.default_rng(909)
+    guides = random_guides(rng, 37)
+    pieces = []
+    for _ in range(6000):  # a contig of mutated read copies: thousands of hits for every read
+        g = guides[int(rng.integers(0, len(guides)))]
+        pieces.append(mutate(rng, g, int(rng.integers(0, 7)), 0, 20) + random_seq(rng, int(rng.integers(0, 3))))
+    contigs = make_genome(909, [50000, 20000], guides, 8, n_plant=200) + ["".join(pieces)]
+    want = oracle.search_fast(contigs, guides, 8)
+    assert len(want) > 5000
+    for _ in range(2):  # the second search reuses the grown buffers
+        got = gpu_search(ctx, contigs, guides, 8, algo="seed")
+        assert hits_as_tuples(got) == hits_as_tuples(want)
