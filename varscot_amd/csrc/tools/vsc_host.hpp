@@ -23,20 +23,50 @@ struct FastaRecord {
 // Multi-FASTA reader (line-wrapped sequences, CR/LF tolerant, blank lines ignored).
 inline std::vector<FastaRecord> read_fasta(const std::string &path)
 {
-    std::ifstream in(path, std::ios::binary);
-    if (!in) throw std::runtime_error("Could not open " + path);
+    // whole lines are appended at once (memchr / append): a 3 GB genome parses at disk speed, not at one
+    // push_back per base
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("Could not open " + path);
     std::vector<FastaRecord> out;
-    std::string line;
-    while (std::getline(in, line)) {
-        while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
-        if (line.empty()) continue;
-        if (line[0] == '>') {
-            out.push_back({line.substr(1), std::string()});
+    std::vector<char> buf(1 << 24);
+    std::string carry;  // an incomplete line at the end of the previous block
+    auto take_line = [&](const char *p, size_t n) {
+        while (n && (p[n - 1] == '\r' || p[n - 1] == '\n')) --n;
+        if (n == 0) return;
+        if (p[0] == '>') {
+            out.push_back({std::string(p + 1, n - 1), std::string()});
         } else if (!out.empty()) {
-            for (char c : line)
-                if (c != ' ' && c != '\t') out.back().seq.push_back(c);
+            std::string &seq = out.back().seq;
+            if (!std::memchr(p, ' ', n) && !std::memchr(p, '\t', n)) {
+                seq.append(p, n);
+            } else {
+                for (size_t i = 0; i < n; ++i)
+                    if (p[i] != ' ' && p[i] != '\t') seq.push_back(p[i]);
+            }
+        }
+    };
+    for (;;) {
+        const size_t got = std::fread(buf.data(), 1, buf.size(), f);
+        if (got == 0) break;
+        const char *p = buf.data(), *end = p + got;
+        while (p < end) {
+            const char *nl = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+            if (!nl) {
+                carry.append(p, (size_t)(end - p));
+                break;
+            }
+            if (!carry.empty()) {
+                carry.append(p, (size_t)(nl - p));
+                take_line(carry.data(), carry.size());
+                carry.clear();
+            } else {
+                take_line(p, (size_t)(nl - p));
+            }
+            p = nl + 1;
         }
     }
+    if (!carry.empty()) take_line(carry.data(), carry.size());
+    std::fclose(f);
     return out;
 }
 

@@ -47,11 +47,16 @@ void vsc_planes_init(uint32_t *hi, uint32_t *lo, uint32_t *nmask, uint64_t n_wor
 
 void vsc_pack_bases(const char *seq, uint64_t n, uint64_t dst_pos, uint32_t *hi, uint32_t *lo, uint32_t *nmask)
 {
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint64_t p = dst_pos + i;
+    static const struct Lut {
+        uint8_t c[256];
+        Lut()
+        {
+            for (int i = 0; i < 256; ++i) c[i] = (uint8_t)code_of((char)i);
+        }
+    } lut;
+    auto put = [&](uint64_t p, int c) {
         const uint64_t w = p >> 5;
         const uint32_t bit = 1u << (p & 31);
-        const int c = code_of(seq[i]);
         if (c == 4) {
             hi[w] &= ~bit;
             lo[w] &= ~bit;
@@ -61,7 +66,27 @@ void vsc_pack_bases(const char *seq, uint64_t n, uint64_t dst_pos, uint32_t *hi,
             lo[w] = (c & 1) ? (lo[w] | bit) : (lo[w] & ~bit);
             nmask[w] &= ~bit;
         }
+    };
+    uint64_t i = 0;
+    while (i < n && ((dst_pos + i) & 31)) {  // up to the first word boundary
+        put(dst_pos + i, lut.c[(uint8_t)seq[i]]);
+        ++i;
     }
+    for (; i + 32 <= n; i += 32) {  // whole words: 32 bases at a time
+        uint32_t h = 0, l = 0, m = 0;
+        const uint8_t *s = (const uint8_t *)seq + i;
+        for (int b = 0; b < 32; ++b) {
+            const uint32_t c = lut.c[s[b]];
+            h |= ((c >> 1) & 1u) << b;
+            l |= (c & 1u) << b;
+            m |= (c >> 2) << b;
+        }
+        const uint64_t w = (dst_pos + i) >> 5;
+        hi[w] = h & ~m;
+        lo[w] = l & ~m;
+        nmask[w] = m;
+    }
+    for (; i < n; ++i) put(dst_pos + i, lut.c[(uint8_t)seq[i]]);
 }
 
 void vsc_unpack_bases(const uint32_t *hi, const uint32_t *lo, const uint32_t *nmask, uint64_t src_pos, uint64_t n,
