@@ -839,10 +839,15 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
             const unsigned passes = (end_bit - std::min(end_bit, max_low) + 7) / 8;
             return end_bit > 8 * passes ? end_bit - 8 * passes : 0u;
         };
-        unsigned begin_bit = low_bits_for(16);
+        // how many bits can go: as many as keep the groups small - a group is one read's hits on one strand
+        // inside 2^low bases, n / (2 reads 2^(32 - low)) records on average; aim at <= 2 (16 bits for the
+        // 1.6e9 hits of 10 000 reads, up to 24 for small results: one pass less again)
+        unsigned max_low = 16;
+        while (max_low < 24 && (double)n / (2.0 * n_guides * (double)(1ull << (32 - (max_low + 1)))) <= 2.0) ++max_low;
+        unsigned begin_bit = low_bits_for(max_low);
         bool forced = false;
         if (const char *o = std::getenv("VSC_SORT_LOW_BITS")) {
-            begin_bit = std::min(16u, (unsigned)std::atoi(o));
+            begin_bit = std::min(24u, (unsigned)std::atoi(o));
             forced = true;
         }
         const uint64_t sorted_cap = n_parts > 0 ? cap : n_sort;

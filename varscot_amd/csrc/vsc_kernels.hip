@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kFinalizeBlock) void finalize_kernel(const Finalize
 hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream)
 {
     if (args.n == 0) return hipSuccess;
-    if (args.low_bits > 16 || (args.low_bits && !args.overflow)) return hipErrorInvalidValue;
+    if (args.low_bits > 24 || (args.low_bits && !args.overflow)) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((args.n + kFinalizeTile - 1) / kFinalizeTile);
     if (args.n_contigs <= (uint32_t)kFinalizeContigs)
         hipLaunchKernelGGL(finalize_kernel<true>, dim3(blocks), dim3(kFinalizeBlock), 0, stream, args);
