@@ -345,6 +345,7 @@ constexpr int kFinalizeItems = 8;    // records per thread
 constexpr int kFinalizeHalo = 256;   // >= the largest group
 constexpr int kFinalizeTile = kFinalizeBlock * kFinalizeItems;
 constexpr int kFinalizeContigs = 1024;
+constexpr int kFinalizeNear = 3;     // neighbours per side ranked without a loop
 
 // kStaged: the contig table fits the LDS copy (a separate instantiation: merged into one loop the two table
 // pointers become a generic pointer and the binary search runs on flat loads)
@@ -371,15 +372,32 @@ __global__ __launch_bounds__(kFinalizeBlock) void finalize_kernel(const Finalize
         const uint64_t key = s_key[me];
         uint64_t dst = i;
         if (a.low_bits) {
+            // The first kNear neighbours on either side are tested with straight-line predicated code: written as
+            // loops with data-dependent exits the compiler spends ~370 scalar instructions per record on
+            // execution-mask bookkeeping (the kernel was bound by the CU's one scalar unit).  Groups that
+            // reach further - rare at <= 2 records per group on average - continue in a wave-uniform loop.
             const uint64_t group = key >> a.low_bits;
             uint32_t before = 0, smaller = 0, after = 0;
-            for (int t = me - 1; t >= me - kFinalizeHalo && (s_key[t] >> a.low_bits) == group; --t) {
-                ++before;
-                smaller += s_key[t] < key;
+            bool up = true, down = true;
+#pragma unroll
+            for (int d = 1; d <= kFinalizeNear; ++d) {
+                const uint64_t ku = s_key[me - d], kd = s_key[me + d];
+                up = up && (ku >> a.low_bits) == group;
+                down = down && (kd >> a.low_bits) == group;
+                before += up;
+                after += down;
+                smaller += (up && ku < key) + (down && kd < key);
             }
-            for (int t = me + 1; t <= me + kFinalizeHalo && (s_key[t] >> a.low_bits) == group; ++t) {
-                ++after;
-                smaller += s_key[t] < key;
+            if (__ballot(up || down) != 0) {  // wave-uniform: the whole wave walks on, predicated, until no lane needs to
+                for (int d = kFinalizeNear + 1; d <= kFinalizeHalo; ++d) {
+                    const uint64_t ku = s_key[me - d], kd = s_key[me + d];
+                    up = up && (ku >> a.low_bits) == group;
+                    down = down && (kd >> a.low_bits) == group;
+                    before += up;
+                    after += down;
+                    smaller += (up && ku < key) + (down && kd < key);
+                    if (__ballot(up || down) == 0) break;
+                }
             }
             // a group that reaches past the staged neighbourhood cannot be ranked here: the host sorts again
             // with fewer bits left out
