@@ -69,8 +69,8 @@ struct vsc_ctx {
     bool own_stream = false;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // the output regions of a sliced search are sorted and finalized concurrently: region 0 on `stream`, the others here
-    hipStream_t aux[kParts - 1] = {};
-    hipEvent_t sorted_ev[kParts] = {}, done_ev[kParts] = {};
+    hipStream_t aux[kSortStreams - 1] = {};
+    hipEvent_t sorted_ev[kParts] = {}, done_ev[kSortStreams] = {};
     std::string err;
     vsc_timing timing{};
     DeviceBuf counters, guides, keys_a, keys_b, vals_a, vals_b, sort_temp, score_mit, score_flags, score_feat;
@@ -248,8 +248,12 @@ int vsc_ctx_create(int device_id, vsc_ctx **out)
             return VSC_ERR_DEVICE;
         }
     for (int i = 0; i < kParts; ++i)
-        if (hipEventCreate(&ctx->sorted_ev[i]) != hipSuccess || hipEventCreate(&ctx->done_ev[i]) != hipSuccess ||
-            (i + 1 < kParts && hipStreamCreate(&ctx->aux[i]) != hipSuccess)) {
+        if (hipEventCreate(&ctx->sorted_ev[i]) != hipSuccess) {
+            vsc_ctx_destroy(ctx);
+            return VSC_ERR_DEVICE;
+        }
+    for (int i = 0; i < kSortStreams; ++i)
+        if (hipEventCreate(&ctx->done_ev[i]) != hipSuccess || (i + 1 < kSortStreams && hipStreamCreate(&ctx->aux[i]) != hipSuccess)) {
             vsc_ctx_destroy(ctx);
             return VSC_ERR_DEVICE;
         }
@@ -270,10 +274,11 @@ int vsc_ctx_destroy(vsc_ctx *ctx)
     for (auto &b : ctx->spare_records) b.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
-    for (int i = 0; i < kParts; ++i) {
+    for (int i = 0; i < kParts; ++i)
         if (ctx->sorted_ev[i]) (void)hipEventDestroy(ctx->sorted_ev[i]);
+    for (int i = 0; i < kSortStreams; ++i) {
         if (ctx->done_ev[i]) (void)hipEventDestroy(ctx->done_ev[i]);
-        if (i + 1 < kParts && ctx->aux[i]) {
+        if (i + 1 < kSortStreams && ctx->aux[i]) {
             (void)hipStreamSynchronize(ctx->aux[i]);
             (void)hipStreamDestroy(ctx->aux[i]);
         }
@@ -671,6 +676,7 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     ScanArgs a{};
     SeedArgs sa{};
     int n_parts = 0;             // > 0: sliced kernel, hits in n_parts output regions of part_cap records each
+    unsigned part_shift = 31;    // region of a hit = read index >> part_shift
     uint64_t part_cap = 0;
     int n_groups = 1;
     if (algo == VSC_ALGO_SCAN) {
@@ -740,13 +746,25 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         const uint64_t per_wave = cap / ((uint64_t)n_groups * kWavesPerGroup * 8);
         sa.reserve = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(kSeedHitCap, per_wave / kWave * kWave));
         if (genome->d_ix_vert) {
-            // output regions by read range (quartiles): sorted and finalized concurrently below
-            // (worth it when there are many hits: long read lists; a small result sorts faster in one piece)
-            n_parts = (n_guides >= 64 && n_pairs >= 32ull * kBuckets) ? kParts : 1;
-            if (const char *o = std::getenv("VSC_SEED_PARTS")) n_parts = std::atoi(o) == 1 ? 1 : (n_guides >= 4 ? kParts : 1);
-            for (int i = 0; i + 1 < kParts; ++i)
-                sa.part_bound[i] = n_parts == 1 ? 0xFFFFFFFFu : (uint32_t)((uint64_t)n_guides * (i + 1) / kParts);
-            if (n_parts > 1) sa.reserve = std::min<uint32_t>(sa.reserve, 1024);  // every wave leaves one open block per region
+            // output regions by read range: sorted and finalized concurrently below.  Many hits (long read
+            // lists): regions of `region_reads` reads (default 512: a region's sort then covers 33 + 9 - 18 = 24 key
+            // bits, 3 passes, with 18 bits left to finalize); a small result sorts faster in one piece.
+            unsigned gb = 1;
+            while (gb < 31 && (1ull << gb) < n_guides) ++gb;
+            part_shift = 31;
+            n_parts = 1;
+            int want_parts = (n_guides >= 64 && n_pairs >= 32ull * kBuckets) ? kParts : 1;
+            if (const char *o = std::getenv("VSC_SEED_PARTS")) want_parts = std::max(1, std::min(kParts, std::atoi(o)));
+            unsigned region_bits = 9;
+            if (const char *o = std::getenv("VSC_SEED_REGION_BITS")) region_bits = (unsigned)std::max(0, std::atoi(o));
+            if (want_parts > 1 && n_guides >= 4) {
+                part_shift = gb > region_bits ? region_bits : 0;
+                while (((n_guides - 1) >> part_shift) + 1 > (unsigned)want_parts) ++part_shift;  // at most want_parts regions
+                n_parts = (int)(((n_guides - 1) >> part_shift) + 1);
+            }
+            sa.part_shift = part_shift;
+            sa.n_parts = (uint32_t)n_parts;
+            if (n_parts > 1) sa.reserve = std::min<uint32_t>(sa.reserve, n_parts > 8 ? 256 : 1024);  // one open block per wave and region
             if (const char *o = std::getenv("VSC_SEED_RESERVE")) sa.reserve = (uint32_t)std::atoi(o);
             // a region gets its share of the expected hits + 15 % (read ranges differ) + the open blocks
             part_cap = cap / n_parts + cap / n_parts / 7 + 4096 + (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
@@ -830,21 +848,35 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         unsigned guide_bits = 1;
         while (guide_bits < 31 && (1ull << guide_bits) < n_guides) ++guide_bits;
         // sentinels (all ones) must sort behind every real key: one more bit when the all-ones guide id is in use
-        const unsigned end_bit = 33 + guide_bits + ((n_sort != n && n_guides == (1ull << guide_bits)) ? 1 : 0);
-        // The sort costs one pass over all pairs per 8 key bits.  Up to 16 low position bits are left out
-        // (two passes for a 47-bit key) and finalize_kernel orders the records that agree in the rest; if
-        // it meets a group too large for that (> 257 hits of one read and strand within 2^low_bits bases),
-        // the sort is repeated with at most 8 bits left out, which always works.
+        unsigned end_bit = 33 + guide_bits + ((n_sort != n && n_guides == (1ull << guide_bits)) ? 1 : 0);
+        if (n_parts > 1) {
+            // inside a region only the low part_shift bits of the read index vary.  A real key equals a sentinel in
+            // all sorted bits only with every sorted position bit set, i.e. within 2^24 bases of the 4 Gbase
+            // limit: such a genome gets one more bit
+            const bool near_limit = ((uint64_t)genome->first_word + genome->own_words) * 32 + (1ull << 24) >= (1ull << 32);
+            end_bit = 33 + part_shift + (near_limit ? 1 : 0);
+        }
+        // The sort costs one pass over all pairs per 8 key bits.  Low position bits are left out and
+        // finalize_kernel orders the records that agree in the rest; if it meets a group too large for that
+        // (> 257 hits of one read and strand within 2^low_bits bases), the sort is repeated with at most 8 bits
+        // left out, which always works.
         auto low_bits_for = [&](unsigned max_low) {
             const unsigned passes = (end_bit - std::min(end_bit, max_low) + 7) / 8;
             return end_bit > 8 * passes ? end_bit - 8 * passes : 0u;
         };
         // how many bits can go: as many as keep the groups small - a group is one read's hits on one strand
-        // inside 2^low bases, n / (2 reads 2^(32 - low)) records on average; aim at <= 2 (16 bits for the
-        // 1.6e9 hits of 10 000 reads, up to 24 for small results: one pass less again)
+        // inside 2^low bases, n / (2 reads 2^(32 - low)) records on average.  Aim at <= 2 records, or at <= 8
+        // when that saves a pass (16 bits for 1.6e9 hits of 10 000 reads in one region, 18 in regions of 512
+        // reads; up to 24 for small results)
+        auto avg_group = [&](unsigned low) { return (double)n / (2.0 * n_guides * (double)(1ull << (32 - low))); };
         unsigned max_low = 16;
-        while (max_low < 24 && (double)n / (2.0 * n_guides * (double)(1ull << (32 - (max_low + 1)))) <= 2.0) ++max_low;
+        while (max_low < 24 && avg_group(max_low + 1) <= 2.0) ++max_low;
         unsigned begin_bit = low_bits_for(max_low);
+        for (unsigned more = max_low + 1; more <= 24 && avg_group(more) <= 8.0; ++more)
+            if ((end_bit - low_bits_for(more) + 7) / 8 < (end_bit - begin_bit + 7) / 8) {
+                begin_bit = low_bits_for(more);
+                break;
+            }
         bool forced = false;
         if (const char *o = std::getenv("VSC_SORT_LOW_BITS")) {
             begin_bit = std::min(24u, (unsigned)std::atoi(o));
@@ -856,48 +888,64 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         ht.lap("sort buffers ensure");
         VSC_HIP_H(take_records(ctx, hits, n));
         ht.lap("record storage");
-        for (; n_parts > 0;) {
-            // one sort + finalize per output region, each on a stream of its own: the passes of one sort
-            // leave the memory system idle between kernels and at their tails, and finalize_kernel is not
-            // bandwidth-bound - four of them interleaved finish in less time than one after the other
-            size_t temp_bytes = 0;
-            for (int q = 0; q < n_parts; ++q) {
-                size_t tb = 0;
-                VSC_HIP_H(sort_temp_bytes(std::max<uint64_t>(part_sort[q], 1), begin_bit, end_bit, &tb));
-                temp_bytes = std::max(temp_bytes, (tb + 255) / 256 * 256);
-            }
-            VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes * n_parts, 16)));
+        if (n_parts > 0) {
+            // one sort + finalize per output region, the regions taking turns on kSortStreams streams: the
+            // passes of one sort leave the memory system idle between kernels and at their tails, and
+            // finalize_kernel is not bandwidth-bound - interleaved they finish in less time than one after
+            // the other.  A region in which finalize meets a group too large to rank (flag per region:
+            // counters[kCntPart + 4 q + 3]) is sorted again, alone, with at most 8 bits left out.
+            uint64_t region_out[kParts];
             uint64_t out_off = 0;
             for (int q = 0; q < n_parts; ++q) {
-                hipStream_t st = q == 0 ? ctx->stream : ctx->aux[q - 1];
-                const uint64_t off = (uint64_t)q * part_cap;
-                if (part_sort[q])
-                    VSC_HIP_H(launch_sort((char *)ctx->sort_temp.p + temp_bytes * q, temp_bytes, (const uint64_t *)ctx->keys_a.p + off,
-                                          (uint64_t *)ctx->keys_b.p + off, (const uint32_t *)ctx->vals_a.p + off,
-                                          (uint32_t *)ctx->vals_b.p + off, part_sort[q], begin_bit, end_bit, st));
-                VSC_HIP_H(hipEventRecord(ctx->sorted_ev[q], st));
-                FinalizeArgs f{};
-                f.keys = (const uint64_t *)ctx->keys_b.p + off;
-                f.vals = (const uint32_t *)ctx->vals_b.p + off;
-                f.n = part_n[q];
-                f.low_bits = begin_bit;
-                f.overflow = (unsigned long long *)ctx->counters.p + kCntGroups;
-                f.contig_off = genome->d_contig_off;
-                f.n_contigs = genome->n_contigs;
-                f.out = hits->d_records + out_off;
-                VSC_HIP_H(launch_finalize(f, st));
+                region_out[q] = out_off;
                 out_off += part_n[q];
-                VSC_HIP_H(hipEventRecord(ctx->done_ev[q], st));
-                if (q > 0) VSC_HIP_H(hipStreamWaitEvent(ctx->stream, ctx->done_ev[q], 0));
             }
-            if (begin_bit <= 8) break;  // groups of at most 256 records: always rankable
-            unsigned long long too_large = 0;
-            VSC_HIP_H(hipMemcpyAsync(&too_large, (unsigned long long *)ctx->counters.p + kCntGroups, sizeof too_large,
-                                     hipMemcpyDeviceToHost, ctx->stream));
-            VSC_HIP_H(hipStreamSynchronize(ctx->stream));
-            if (!too_large) break;
-            if (forced) return cleanup(fail(ctx, VSC_ERR_DEVICE, "vsc_search: VSC_SORT_LOW_BITS leaves groups too large to order"));
-            begin_bit = low_bits_for(8);
+            bool redo[kParts];
+            for (int q = 0; q < n_parts; ++q) redo[q] = true;
+            for (unsigned low = begin_bit;;) {
+                size_t temp_bytes = 0;
+                for (int q = 0; q < n_parts; ++q) {
+                    size_t tb = 0;
+                    VSC_HIP_H(sort_temp_bytes(std::max<uint64_t>(part_sort[q], 1), low, end_bit, &tb));
+                    temp_bytes = std::max(temp_bytes, (tb + 255) / 256 * 256);
+                }
+                VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes * kSortStreams, 16)));
+                int turn = 0;
+                for (int q = 0; q < n_parts; ++q) {
+                    if (!redo[q]) continue;
+                    const int lane = turn++ % kSortStreams;  // a stream works through its regions in order
+                    hipStream_t st = lane == 0 ? ctx->stream : ctx->aux[lane - 1];
+                    const uint64_t off = (uint64_t)q * part_cap;
+                    if (part_sort[q])
+                        VSC_HIP_H(launch_sort((char *)ctx->sort_temp.p + temp_bytes * lane, temp_bytes,
+                                              (const uint64_t *)ctx->keys_a.p + off, (uint64_t *)ctx->keys_b.p + off,
+                                              (const uint32_t *)ctx->vals_a.p + off, (uint32_t *)ctx->vals_b.p + off, part_sort[q],
+                                              low, end_bit, st));
+                    if (low == begin_bit) VSC_HIP_H(hipEventRecord(ctx->sorted_ev[q], st));
+                    FinalizeArgs f{};
+                    f.keys = (const uint64_t *)ctx->keys_b.p + off;
+                    f.vals = (const uint32_t *)ctx->vals_b.p + off;
+                    f.n = part_n[q];
+                    f.low_bits = low;
+                    f.overflow = (unsigned long long *)ctx->counters.p + kCntPart + 4 * q + 3;
+                    f.contig_off = genome->d_contig_off;
+                    f.n_contigs = genome->n_contigs;
+                    f.out = hits->d_records + region_out[q];
+                    VSC_HIP_H(launch_finalize(f, st));
+                }
+                for (int lane = 1; lane < kSortStreams; ++lane) {
+                    VSC_HIP_H(hipEventRecord(ctx->done_ev[lane], ctx->aux[lane - 1]));
+                    VSC_HIP_H(hipStreamWaitEvent(ctx->stream, ctx->done_ev[lane], 0));
+                }
+                if (low <= 8) break;  // groups of at most 256 records: always rankable
+                VSC_HIP_H(hipMemcpyAsync(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+                VSC_HIP_H(hipStreamSynchronize(ctx->stream));
+                bool any = false;
+                for (int q = 0; q < n_parts; ++q) any |= (redo[q] = cnt[kCntPart + 4 * q + 3] != 0);
+                if (!any) break;
+                if (forced) return cleanup(fail(ctx, VSC_ERR_DEVICE, "vsc_search: VSC_SORT_LOW_BITS leaves groups too large to order"));
+                low = low_bits_for(8);
+            }
         }
         for (; n_parts == 0;) {
             size_t temp_bytes = 0;

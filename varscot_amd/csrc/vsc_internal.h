@@ -46,14 +46,17 @@ enum { kCntHits = 0, kCntChunk = 1, kCntSites = 2, kCntOverflow = 3, kCntVisited
 // The sliced kernel hands out chunks through kCursors work cursors, one per slice of the chunk range, 128
 // bytes apart behind the counters: one device-wide cursor sustains only ~90 atomics/us
 // (MI355X_MICROARCH.md), which for 270 000 grabs is 3 ms - as long as a whole 1 000-read search.
-// The sliced kernel writes its hits into kParts regions by read range (quartiles of the read indices): the
-// regions are sorted and finalized independently, on streams of their own, and their concatenation is the
-// result.  Per region: counters[kCntPart + 4 p + {0, 1, 2}] = records reserved, sentinels among them, records lost.
-constexpr int kParts = 4;
+// The sliced kernel writes its hits into up to kParts regions by read range (region = read index >>
+// part_shift): the regions are sorted and finalized independently, on kSortStreams streams, and their
+// concatenation is the result.  Inside a region the top read-index bits are constant, so its sort
+// covers fewer key bits: regions of 512 reads turn a 47-bit key into 24 sorted bits = 3 passes.
+// Per region: counters[kCntPart + 4 p + {0, 1, 2}] = records reserved, sentinels among them, records lost.
+constexpr int kParts = 32;
+constexpr int kSortStreams = 4;
 constexpr int kCntPart = 8;
 constexpr int kCursors = 32;
 constexpr int kCursorStride = 16;  // in 8-byte words
-constexpr int kCursorBase = 32;    // first cursor, in 8-byte words from the start of the counter buffer
+constexpr int kCursorBase = 144;    // first cursor, in 8-byte words from the start of the counter buffer
 constexpr int kCounterWords = kCursorBase + kCursors * kCursorStride;
 
 // Required plane bits of the two PAM letters, expanded to all-ones / all-zero words.
@@ -127,7 +130,8 @@ struct SeedArgs {
     uint32_t *hit_vals;
     unsigned long long hit_cap;
     uint32_t reserve;              // records a wave reserves per atomic on counters[kCntHits]
-    uint32_t part_bound[kParts - 1];  // sliced kernel: first read index of regions 1 .. kParts - 1 (~0: region unused)
+    uint32_t part_shift;           // sliced kernel: output region of a hit = read index >> part_shift (31: one region)
+    uint32_t n_parts;              // sliced kernel: regions in use
     unsigned long long part_cap;   // sliced kernel: records per region; region p = [p * part_cap, (p + 1) * part_cap)
     unsigned long long *counters;  // kCntHits (reserved records), kCntPad (sentinels among them), kCntChunk,
                                    // kCntSites (= pairs compared), kCntVisited, kCntOverflow

@@ -664,62 +664,71 @@ struct SlicedFetch {
     uint4 rec;  // site record of the lowest set bit
 };
 
-// seed_flush_hits for the sliced kernel: the staged hits belong to output region w.cp
-__device__ __forceinline__ void sliced_flush_hits(const SeedArgs &a, SeedWave &w)
+// Output of the sliced kernel.  A wave keeps, per output region, an open block of reserved records
+// (w.parts[p] = {next free record lo, hi, records left}).  The hits of a pass go straight from registers to
+// their region's block - no staging in LDS: the hits of consecutive passes belong to different regions
+// often enough (a wave walks through the read ranges once per chunk) that staged batches stayed small.
+//
+// Reserves a new block in region p (wave-uniform).  Returns false when the region is full: the host
+// re-runs with room for reserved + lost records in every region.
+__device__ __forceinline__ bool sliced_reserve(const SeedArgs &a, const SeedWave &w, uint32_t p, uint32_t losing,
+                                               unsigned long long &base)
 {
-    unsigned long long *const cursor = &a.counters[kCntPart + 4 * w.cp];
-    uint32_t done = 0;
-    while (done < w.hn) {
-        if (w.res_left == 0) {
-            const uint32_t want = a.reserve ? a.reserve : w.hn - done;
-            unsigned long long rel = 0;
-            if (w.lane == 0) rel = atomicAdd(cursor, (unsigned long long)want);
-            rel = ((unsigned long long)uniform((uint32_t)(rel >> 32)) << 32) | uniform((uint32_t)rel);
-            if (rel + want > a.part_cap) {
-                // region too small: undo the reservation, count what is lost; the host re-runs with room for
-                // reserved + lost records (+ one block per wave) in every region
-                if (w.lane == 0) {
-                    atomicAdd(cursor, 0ull - (unsigned long long)want);
-                    atomicAdd(cursor + 2, (unsigned long long)(w.hn - done));
-                    atomicMax(&a.counters[kCntOverflow], 1ull);
-                }
-                break;
-            }
-            w.res_base = (unsigned long long)w.cp * a.part_cap + rel;
-            w.res_left = want;
+    unsigned long long *const cursor = &a.counters[kCntPart + 4 * p];
+    unsigned long long rel = 0;
+    if (w.lane == 0) rel = atomicAdd(cursor, (unsigned long long)a.reserve);
+    rel = ((unsigned long long)uniform((uint32_t)(rel >> 32)) << 32) | uniform((uint32_t)rel);
+    if (rel + a.reserve > a.part_cap) {
+        if (w.lane == 0) {
+            atomicAdd(cursor, 0ull - (unsigned long long)a.reserve);
+            atomicAdd(cursor + 2, (unsigned long long)losing);
+            atomicMax(&a.counters[kCntOverflow], 1ull);
         }
-        const uint32_t take = min(w.hn - done, w.res_left);
-        for (uint32_t i = w.lane; i < take; i += kWave) {
-            a.hit_keys[w.res_base + i] = w.hkey[done + i];
-            a.hit_vals[w.res_base + i] = w.hval[done + i];
-        }
-        w.res_base += take;
-        w.res_left -= take;
-        done += take;
+        return false;
+    }
+    base = (unsigned long long)p * a.part_cap + rel;
+    return true;
+}
+
+// lanes in `mask` (all of region p, wave-uniform) store their record
+__device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, uint32_t p, uint64_t mask, bool mine,
+                                             uint64_t key, uint32_t val)
+{
+    const uint4 st = w.parts[p];
+    unsigned long long base = ((unsigned long long)uniform(st.y) << 32) | uniform(st.x);
+    uint32_t left = uniform(st.z);
+    const uint32_t n = (uint32_t)__popcll(mask);
+    const uint32_t rank = lanes_below(mask);
+    unsigned long long next = base;
+    bool ok = true;
+    if (left < n) ok = sliced_reserve(a, w, p, n - left, next);  // the open block takes `left`, a new one the rest
+    if (mine && (rank < left || ok)) {
+        const unsigned long long at = rank < left ? base + rank : next + (rank - left);
+        a.hit_keys[at] = key;
+        a.hit_vals[at] = val;
+    }
+    if (left < n) {
+        base = ok ? next + (n - left) : base + left;
+        left = ok ? a.reserve - (n - left) : 0;
+    } else {
+        base += n;
+        left -= n;
     }
     wave_sync();
-    w.hn = 0;
-}
-
-// the wave turns to output region p (wave-uniform): what is staged goes out, the reservations are swapped
-__device__ __forceinline__ void sliced_switch_region(const SeedArgs &a, SeedWave &w, uint32_t p)
-{
-    sliced_flush_hits(a, w);
-    if (w.lane == 0) w.parts[w.cp] = make_uint4((uint32_t)w.res_base, (uint32_t)(w.res_base >> 32), w.res_left, 0u);
+    if (w.lane == 0) w.parts[p] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), left, 0u);
     wave_sync();
-    const uint4 st = w.parts[p];
-    w.res_base = ((unsigned long long)uniform(st.y) << 32) | uniform(st.x);
-    w.res_left = uniform(st.z);
-    w.cp = p;
 }
 
+// end of the kernel: the open blocks are filled up with sentinel keys that sort behind every real hit
 __device__ __forceinline__ void sliced_finish_hits(const SeedArgs &a, SeedWave &w)
 {
-    for (uint32_t q = 0; q < (uint32_t)kParts; ++q) {
-        sliced_switch_region(a, w, q);  // flushes what is staged (first turn), then pads region q's open block
-        for (uint32_t i = w.lane; i < w.res_left; i += kWave) a.hit_keys[w.res_base + i] = ~0ull;
-        if (w.lane == 0 && w.res_left) atomicAdd(&a.counters[kCntPart + 4 * q + 1], (unsigned long long)w.res_left);
-        w.res_left = 0;
+    wave_sync();
+    for (uint32_t q = 0; q < a.n_parts; ++q) {
+        const uint4 st = w.parts[q];
+        const unsigned long long base = ((unsigned long long)uniform(st.y) << 32) | uniform(st.x);
+        const uint32_t left = uniform(st.z);
+        for (uint32_t i = w.lane; i < left; i += kWave) a.hit_keys[base + i] = ~0ull;
+        if (w.lane == 0 && left) atomicAdd(&a.counters[kCntPart + 4 * q + 1], (unsigned long long)left);
     }
 }
 
@@ -781,24 +790,14 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
         key = ((uint64_t)gid_of << 33) | ((uint64_t)strand << 32) | pos;
         val = ((uint32_t)__popc(t) << 23) | mask;
     }
-    // the hits of a pass belong to one output region, two at a boundary between read ranges
-    uint32_t region = 0;
-#pragma unroll
-    for (int i = 0; i + 1 < kParts; ++i) region += gid_of >= a.part_bound[i];
+    // the hits of a pass belong to one output region, two or three when the reads of the batch span region boundaries
+    const uint32_t region = gid_of >> a.part_shift;
     uint64_t todo = __ballot(hit);
     while (todo != 0) {
         const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)region, (int)__builtin_ctzll(todo));
-        if (p != w.cp) sliced_switch_region(a, w, p);
         const bool mine = hit && region == p;
         const uint64_t b = __ballot(mine);
-        if (mine) {
-            const uint32_t at = lanes_below(b, w.hn);
-            w.hkey[at] = key;
-            w.hval[at] = val;
-        }
-        wave_sync();
-        w.hn += (uint32_t)__popcll(b);
-        if (w.hn > kSeedHitCap - kWave) sliced_flush_hits(a, w);
+        sliced_store(a, w, p, b, mine, key, val);
         todo &= ~b;
     }
 }
@@ -856,8 +855,6 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     const SeedArgs a)
 {
     __shared__ uint4 s_tok[kWavesPerGroup][kSlicedTokCap];
-    __shared__ uint64_t s_hkey[kWavesPerGroup][kSeedHitCap];
-    __shared__ uint32_t s_hval[kWavesPerGroup][kSeedHitCap];
     __shared__ uint4 s_list[kWavesPerGroup][kWave];  // the current tile of 64 read-list entries
     __shared__ uint4 s_parts[kWavesPerGroup][kParts];
 
@@ -866,8 +863,8 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     w.lane = threadIdx.x % kWave;
     w.tok = nullptr;
     w.tok4 = s_tok[wave];
-    w.hkey = s_hkey[wave];
-    w.hval = s_hval[wave];
+    w.hkey = nullptr;
+    w.hval = nullptr;
     w.ntok = 0;
     w.thead = 0;
     w.hn = 0;
