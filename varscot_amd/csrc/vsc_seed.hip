@@ -690,38 +690,43 @@ __device__ __forceinline__ bool sliced_reserve(const SeedArgs &a, const SeedWave
     return true;
 }
 
-// lanes in `mask` (all of region p, wave-uniform) store their record
+// lanes in `mask` (all of region p, wave-uniform) store their record.  The open block of the region in
+// use lives in registers (w.cp, w.res_base, w.res_left); the LDS table is touched on a change of region only.
 __device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, uint32_t p, uint64_t mask, bool mine,
                                              uint64_t key, uint32_t val)
 {
-    const uint4 st = w.parts[p];
-    unsigned long long base = ((unsigned long long)uniform(st.y) << 32) | uniform(st.x);
-    uint32_t left = uniform(st.z);
+    if (p != w.cp) {
+        if (w.lane == 0) w.parts[w.cp] = make_uint4((uint32_t)w.res_base, (uint32_t)(w.res_base >> 32), w.res_left, 0u);
+        wave_sync();
+        const uint4 st = w.parts[p];
+        w.res_base = ((unsigned long long)uniform(st.y) << 32) | uniform(st.x);
+        w.res_left = uniform(st.z);
+        w.cp = p;
+    }
     const uint32_t n = (uint32_t)__popcll(mask);
     const uint32_t rank = lanes_below(mask);
-    unsigned long long next = base;
+    const uint32_t left = w.res_left;
+    unsigned long long next = w.res_base;
     bool ok = true;
     if (left < n) ok = sliced_reserve(a, w, p, n - left, next);  // the open block takes `left`, a new one the rest
     if (mine && (rank < left || ok)) {
-        const unsigned long long at = rank < left ? base + rank : next + (rank - left);
+        const unsigned long long at = rank < left ? w.res_base + rank : next + (rank - left);
         a.hit_keys[at] = key;
         a.hit_vals[at] = val;
     }
     if (left < n) {
-        base = ok ? next + (n - left) : base + left;
-        left = ok ? a.reserve - (n - left) : 0;
+        w.res_base = ok ? next + (n - left) : w.res_base + left;
+        w.res_left = ok ? a.reserve - (n - left) : 0;
     } else {
-        base += n;
-        left -= n;
+        w.res_base += n;
+        w.res_left -= n;
     }
-    wave_sync();
-    if (w.lane == 0) w.parts[p] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), left, 0u);
-    wave_sync();
 }
 
 // end of the kernel: the open blocks are filled up with sentinel keys that sort behind every real hit
 __device__ __forceinline__ void sliced_finish_hits(const SeedArgs &a, SeedWave &w)
 {
+    if (w.lane == 0) w.parts[w.cp] = make_uint4((uint32_t)w.res_base, (uint32_t)(w.res_base >> 32), w.res_left, 0u);
     wave_sync();
     for (uint32_t q = 0; q < a.n_parts; ++q) {
         const uint4 st = w.parts[q];
