@@ -37,7 +37,9 @@ constexpr int kSlicedChunk = kWave * kSlicedSites;  // 2048 sites per wave and c
 constexpr int kRestBases = VSC_READ_LEN - kSegBases;  // 16 read positions outside the seed segment
 constexpr int kListDistShift = 30;              // list entry y: read index | seed distance << 30
 constexpr int kTokLaneShift = 26;               // sliced hit token, high word: read index | lane << 26
-constexpr int kSlicedTokCap = 320;              // sliced kernel: per-wave LDS ring of 16-byte hit tokens
+constexpr int kSlicedResolve = 3;                // sliced kernel: resolve when this many passes of 64 tokens wait (the
+                                                // gathers of the later passes overlap the earlier ones)
+constexpr int kSlicedTokCap = (kSlicedResolve + 4) * 64;  // per-wave LDS ring of 16-byte hit tokens: a group of four reads adds <= 256
 constexpr int kSlicedGrab = 4;                  // chunks of 2048 sites per grab of the work counter (sliced kernel)
 constexpr int kSeedGrab = 16;                   // chunks (<= 512 sites of one bucket) per grab of the work counter
 

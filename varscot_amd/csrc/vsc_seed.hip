@@ -970,7 +970,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
                         w.ntok += (uint32_t)__popcll(b);
                     }
                     // a group of four reads adds at most 4 x 64 tokens, a resolve leaves fewer than 64
-                    if (w.ntok >= (uint32_t)kWave) sliced_resolve(a, w, cur.x, seg, false);
+                    if (w.ntok >= (uint32_t)kSlicedResolve * kWave) sliced_resolve(a, w, cur.x, seg, false);
                 }
             }
             if (w.ntok) sliced_resolve(a, w, cur.x, seg, true);
