@@ -777,24 +777,22 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
         if (rest != 0) w.tok4[ring_slot(lanes_below(again, ring_tail(w)))] = make_uint4(rest, f.hi, f.gp.x, f.gp.y);
         w.ntok += (uint32_t)__popcll(again);
     }
+    // Straight-line, computed for every lane (a lane without a token works on zeros): branches around the
+    // few instructions cost more scalar mask bookkeeping than the instructions themselves.  Only the
+    // right-edge rule - a binary search, needed by windows that end a contig - sits behind a wave-uniform test.
     const uint32_t gid_of = f.hi & ((1u << kTokLaneShift) - 1u);
-    uint64_t key = 0;
-    uint32_t val = 0;
-    if (hit) {
-        const uint32_t t = ((f.rec.x ^ f.gp.x) | (f.rec.y ^ f.gp.y)) & kMask23;
-        const uint32_t strand = (f.rec.x >> kSiteStrandBit) & 1u;
-        const uint32_t pos = f.rec.z;
-        // (pairs that an earlier segment reports never become tokens: sliced_within)
-        const uint32_t mask = strand ? reverse23(t) : t;
-        // right-edge rule, bidir_mapping.cpp:51-52 (see emit_hits in vsc_kernels.hip)
-        if (hit && ((f.rec.x >> kSiteEdgeBit) & 1u)) {
-            if ((uint32_t)__popc(mask >> (VSC_READ_LEN / 2)) > a.k_half &&
-                is_contig_end(a.contig_end, a.n_contigs, pos + VSC_READ_LEN))
-                hit = false;
-        }
-        key = ((uint64_t)gid_of << 33) | ((uint64_t)strand << 32) | pos;
-        val = ((uint32_t)__popc(t) << 23) | mask;
+    const uint32_t t = ((f.rec.x ^ f.gp.x) | (f.rec.y ^ f.gp.y)) & kMask23;
+    const uint32_t strand = (f.rec.x >> kSiteStrandBit) & 1u;
+    const uint32_t pos = f.rec.z;
+    // (pairs that an earlier segment reports never become tokens: sliced_within)
+    const uint32_t mask = strand ? reverse23(t) : t;
+    // right-edge rule, bidir_mapping.cpp:51-52 (see emit_hits in vsc_kernels.hip)
+    const bool at_edge = hit && ((f.rec.x >> kSiteEdgeBit) & 1u) && (uint32_t)__popc(mask >> (VSC_READ_LEN / 2)) > a.k_half;
+    if (__ballot(at_edge) != 0) {
+        if (at_edge && is_contig_end(a.contig_end, a.n_contigs, pos + VSC_READ_LEN)) hit = false;
     }
+    const uint64_t key = ((uint64_t)gid_of << 33) | ((uint64_t)strand << 32) | pos;
+    const uint32_t val = ((uint32_t)__popc(t) << 23) | mask;
     // the hits of a pass belong to one output region, two or three when the reads of the batch span region boundaries
     const uint32_t region = gid_of >> a.part_shift;
     uint64_t todo = __ballot(hit);
