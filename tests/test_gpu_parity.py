@@ -547,3 +547,21 @@ def test_output_regions_by_read_range(ctx, oracle, parts, monkeypatch):
     for _ in range(2):  # the second search reuses the grown buffers
         got = gpu_search(ctx, contigs, guides, 8, algo="seed")
         assert hits_as_tuples(got) == hits_as_tuples(want)
+
+
+def test_output_regions_of_512_reads(ctx, oracle, monkeypatch):
+    """More than 512 reads: the default region size applies (region = read index >> 9), here forced on for
+    a small genome; reads at the region boundaries 511 / 512 / 1023 / 1024 get planted sites."""
+    monkeypatch.setenv("VSC_SEED_PARTS", "32")
+    rng = np.random.default_rng(5150)
+    guides = random_guides(rng, 1100)
+    contigs = make_genome(5150, [200000, 80000, 30000], guides, 7, n_plant=600, n_runs=4)
+    seq = contigs[0]
+    for k, gi in enumerate([0, 511, 512, 1023, 1024, 1099]):
+        at = 1000 + 400 * k
+        seq = seq[:at] + mutate(rng, guides[gi], 3, 0, 20) + seq[at + 23:]
+    contigs[0] = seq
+    want = oracle.search_fast(contigs, guides, 7)
+    got = gpu_search(ctx, contigs, guides, 7, algo="seed")
+    assert {int(g) for g in want["guide"]} >= {0, 511, 512, 1023, 1024, 1099}
+    assert hits_as_tuples(got) == hits_as_tuples(want)
