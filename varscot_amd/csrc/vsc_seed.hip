@@ -251,6 +251,7 @@ struct SeedWave {
     uint32_t res_left;
     uint32_t cp;     // sliced kernel: the output region the staged hits and the reservation belong to
     uint4 *parts;    // sliced kernel: {res_base lo, hi, res_left, 0} of the regions this wave is not writing to
+    uint32_t *first; // sliced kernel: first site of every chunk of the current grab (tokens name their chunk by slot)
 };
 
 // Moves the resolved hits of this wave to the global hit arrays.  A single device-wide cursor
@@ -659,7 +660,7 @@ __device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[2 * kRestB
 // back into the ring with that bit cleared, so every pass over 64 tokens is dense.  The gather of the next
 // 64 tokens is issued before the current 64 are consumed.
 struct SlicedFetch {
-    uint32_t word, hi, site0;
+    uint32_t word, hi, site0, z;  // z = read hi plane | chunk slot << 23, as in the token
     uint2 gp;   // read planes
     uint4 rec;  // site record of the lowest set bit
 };
@@ -744,21 +745,23 @@ __device__ __forceinline__ uint32_t ring_slot(uint32_t p)
 }
 
 // ring slots head .. head + n - 1 -> one token per lane (lanes >= n stay empty), gather issued
-__device__ __forceinline__ SlicedFetch sliced_fetch(const SeedArgs &a, const SeedWave &w, uint32_t head, uint32_t n,
-                                                    uint32_t chunk_first)
+__device__ __forceinline__ SlicedFetch sliced_fetch(const SeedArgs &a, const SeedWave &w, uint32_t head, uint32_t n)
 {
     SlicedFetch f;
     f.word = 0;
     f.hi = 0;
     f.site0 = 0;
+    f.z = 0;
     f.gp = make_uint2(0u, 0u);
     f.rec = make_uint4(0u, 0u, 0u, 0u);
     if (w.lane < n) {
         const uint4 tk = w.tok4[ring_slot(head + w.lane)];
         f.word = tk.x;
         f.hi = tk.y;
-        f.gp = make_uint2(tk.z, tk.w);
-        f.site0 = chunk_first + (tk.y >> kTokLaneShift) * kSlicedSites;
+        f.z = tk.z;
+        f.gp = make_uint2(tk.z & kMask23, tk.w);
+        // the token's chunk is one of the kSlicedGrab chunks of the current grab (w.first = their first sites)
+        f.site0 = w.first[tk.z >> 23] + (tk.y >> kTokLaneShift) * kSlicedSites;
         f.rec = a.sites[f.site0 + (uint32_t)__builtin_ctz(tk.x)];
     }
     return f;
@@ -767,14 +770,14 @@ __device__ __forceinline__ SlicedFetch sliced_fetch(const SeedArgs &a, const See
 // w.ntok tokens wait in the ring from slot w.thead on; `tail` = first free slot
 __device__ __forceinline__ uint32_t ring_tail(const SeedWave &w) { return ring_slot(w.thead + w.ntok); }
 
-__device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, const SlicedFetch &f, uint32_t seg)
+__device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, const SlicedFetch &f)
 {
     bool hit = f.word != 0;
     // more hits of the same (block, read): back into the ring
     const uint32_t rest = f.word & (f.word - 1);
     const uint64_t again = __ballot(rest != 0);
     if (again != 0) {
-        if (rest != 0) w.tok4[ring_slot(lanes_below(again, ring_tail(w)))] = make_uint4(rest, f.hi, f.gp.x, f.gp.y);
+        if (rest != 0) w.tok4[ring_slot(lanes_below(again, ring_tail(w)))] = make_uint4(rest, f.hi, f.z, f.gp.y);
         w.ntok += (uint32_t)__popcll(again);
     }
     // Straight-line, computed for every lane (a lane without a token works on zeros): branches around the
@@ -806,20 +809,20 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
 }
 
 // Resolves tokens in passes of 64.  drain = false: full passes only - what is left (< 64 tokens) waits
-// for more, so that every pass is dense; drain = true (end of the chunk): everything.
-__device__ __forceinline__ void sliced_resolve(const SeedArgs &a, SeedWave &w, uint32_t chunk_first, uint32_t seg, bool drain)
+// for more, so that every pass is dense; drain = true (end of a grab of chunks): everything.
+__device__ __forceinline__ void sliced_resolve(const SeedArgs &a, SeedWave &w, bool drain)
 {
     wave_sync();
     bool have = false;
-    SlicedFetch f = sliced_fetch(a, w, 0, 0, chunk_first);
+    SlicedFetch f = sliced_fetch(a, w, 0, 0);
     for (;;) {
         uint32_t n = min(w.ntok, (uint32_t)kWave);
         if (!drain && n < (uint32_t)kWave) n = 0;
         if (n == 0 && !have) break;
-        const SlicedFetch nf = sliced_fetch(a, w, w.thead, n, chunk_first);  // n == 0: empty
+        const SlicedFetch nf = sliced_fetch(a, w, w.thead, n);  // n == 0: empty
         w.thead = ring_slot(w.thead + n);
         w.ntok -= n;
-        if (have) sliced_consume(a, w, f, seg);  // may append to the ring
+        if (have) sliced_consume(a, w, f);  // may append to the ring
         wave_sync();
         f = nf;
         have = n != 0;
@@ -860,6 +863,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     __shared__ uint4 s_tok[kWavesPerGroup][kSlicedTokCap];
     __shared__ uint4 s_list[kWavesPerGroup][kWave];  // the current tile of 64 read-list entries
     __shared__ uint4 s_parts[kWavesPerGroup][kParts];
+    __shared__ uint32_t s_first[kWavesPerGroup][kSlicedGrab];
 
     const uint32_t wave = threadIdx.x / kWave;
     SeedWave w;
@@ -875,6 +879,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     w.res_left = 0;
     w.cp = 0;
     w.parts = s_parts[wave];
+    w.first = s_first[wave];
     if (w.lane < (uint32_t)kParts) w.parts[w.lane] = make_uint4(0u, 0u, 0u, 0u);
 
     uint4 *const lt = s_list[wave];
@@ -933,6 +938,9 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
             p1b = poff[t1.z + 1];
             t2 = ctab[min(c + 3, last - 1)];
             if (g0 == g1) continue;  // no read has this bucket in its neighbourhood
+            const uint32_t slot_tag = (c - first) << 23;  // the tokens of this chunk carry its slot in the grab
+            if (w.lane == 0) w.first[c - first] = cur.x;
+            wave_sync();
             const uint32_t seg = cur.z / (uint32_t)kBucketsPerSeg;
             // sites of this lane's block that exist
             const int32_t left = (int32_t)cur.y - (int32_t)(w.lane * kSlicedSites);
@@ -964,15 +972,15 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
                         if (b == 0) continue;
                         const uint32_t gid = ry & ((1u << kListDistShift) - 1u);
                         if (word != 0)
-                            w.tok4[ring_slot(lanes_below(b, ring_tail(w)))] = make_uint4(word, gid | lane_tag, rd[u].z, rd[u].w);
+                            w.tok4[ring_slot(lanes_below(b, ring_tail(w)))] = make_uint4(word, gid | lane_tag, rd[u].z | slot_tag, rd[u].w);
                         w.ntok += (uint32_t)__popcll(b);
                     }
                     // a group of four reads adds at most 4 x 64 tokens, a resolve leaves fewer than 64
-                    if (w.ntok >= (uint32_t)kSlicedResolve * kWave) sliced_resolve(a, w, cur.x, seg, false);
+                    if (w.ntok >= (uint32_t)kSlicedResolve * kWave) sliced_resolve(a, w, false);
                 }
             }
-            if (w.ntok) sliced_resolve(a, w, cur.x, seg, true);
         }
+        if (w.ntok) sliced_resolve(a, w, true);  // the tokens name chunks of this grab: all out before the next
     }
     sliced_finish_hits(a, w);
     if (w.lane == 0 && pairs) {
