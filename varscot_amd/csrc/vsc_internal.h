@@ -40,7 +40,7 @@ constexpr int kTokLaneShift = 26;               // sliced hit token, high word: 
 constexpr int kSlicedResolve = 3;                // sliced kernel: resolve when this many passes of 64 tokens wait (the
                                                 // gathers of the later passes overlap the earlier ones)
 constexpr int kSlicedTokCap = (kSlicedResolve + 4) * 64;  // per-wave LDS ring of 16-byte hit tokens: a group of four reads adds <= 256
-constexpr int kSlicedGrab = 4;                  // chunks of 2048 sites per grab of the work counter (sliced kernel)
+constexpr int kSlicedGrab = 8;                  // chunks of 2048 sites per grab of the work counter (sliced kernel)
 constexpr int kSeedGrab = 16;                   // chunks (<= 512 sites of one bucket) per grab of the work counter
 
 // counters[] slots of one scan launch
