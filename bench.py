@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of synthetic input: all reads of the workload
-searched (both strands) against the resident synthetic 3 Gbp genome - scan kernel, radix sort of the
+searched (both strands) against the resident synthetic 3 Gbp genome - search kernel, bin sort of the
 hits, record assembly - and, for N > 1, the RCCL gather of the hit records to rank 0 plus the merge
 there.  Inputs (packed genome planes) are resident in HBM before the timed region starts; results
 stay in HBM.  The genome is sharded by position range across ranks (total work fixed => strong
@@ -35,7 +35,6 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz (32-bit integer lane-ops / s)
 LANE_OPS_PER_COMPARE = {"scan": 3.5,     # v_xor + v_bitop3 + v_bcnt + 1/2 v_min3 per (site, read) pair
-                        "pairs": 4.0,    # v_xor + v_bitop3 + v_bcnt + v_cmp
                         "sliced": 2.25}  # 72 instructions per read and 32 sites: 16 x 2 mismatch vectors + adder tree + test
 
 
@@ -99,15 +98,14 @@ def cpu_baseline(total_bases, max_mm, sample_bases, sample_guides, seqs):
     }
 
 
-def sort_roofline(n_reads, n_hits, sort_ms):
-    gb = 1
-    while (1 << gb) < n_reads:
-        gb += 1
-    end_bit = 33 + gb + (1 if n_reads == (1 << gb) else 0)
-    passes = -(-(end_bit - 16) // 8)  # vsc_search leaves up to 16 low position bits to finalize_kernel
-    return {"bound": "hbm", "kernel": "rocprim onesweep radix sort (u64 key, u32 value)",
-            "achieved": 24.0 * n_hits * passes / (max(sort_ms, 1e-9) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "launch_ms": sort_ms, "passes": passes, "key_bits_sorted": 8 * passes, "key_bits_left_to_finalize": end_bit - 8 * passes}
+def sort_roofline(timing_sums, steps):
+    """The bin sort (vsc_sort.hip): bytes its kernels moved (vsc_timing.sort_bytes: 8 per packed record read or
+    written, 16 per result record) over the time from the end of the search kernel to the last result record."""
+    ms = (timing_sums["sort_ms"] + timing_sums["finalize_ms"]) / steps
+    return {"bound": "hbm", "kernel": "bin_hist + bin_partition + bin_finalize (hand-written, vsc_sort.hip)",
+            "achieved": timing_sums["sort_bytes"] / steps / (max(ms, 1e-9) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "launch_ms": ms, "partition_levels": timing_sums["sort_levels"], "first_level_bin_bits": timing_sums["sort_bin_bits"],
+            "bytes": timing_sums["sort_bytes"] / steps}
 
 
 def main():
@@ -205,112 +203,102 @@ def main():
         torch.cuda.synchronize()
 
     streamed = args.workload == "c5"
-    score_ms = []
 
     # more pieces = more of the exchange hidden, but every piece visits all site chunks again (c3 on one GPU:
     # 102 ms in one piece, 116 ms in four): 4 pieces at 2 ranks (13 GB over one link), 2 at 4, 1 at 8
     sub_batches = args.sub_batches if args.sub_batches is not None else {2: 4, 3: 2, 4: 2}.get(world, 1)
     pipelined = use_dist and args.exchange == "reads" and sub_batches > 1 and args.workload in ("c2", "c3")
 
-    class Pieces:
-        """Result of a pipelined multi-rank search: this rank's merged share of every piece of the read set."""
+    # per-step sums of the library's device timings (vsc_timing): every step function returns
+    # (objects to close, records of this rank's final result, sums)
+    T_SUM = ("scan_ms", "sort_ms", "finalize_ms", "prep_ms", "score_ms", "hits", "pairs", "genome_bytes", "sort_bytes")
+    T_MAX = ("sort_levels", "sort_bin_bits", "passes", "sites", "read_passes")
 
-        def __init__(self, parts):
-            self.parts = parts
+    def new_acc():
+        return dict.fromkeys(T_SUM + T_MAX, 0)
 
-        def __len__(self):
-            return sum(len(m) for _, m in self.parts)
+    def add_timing(acc, t, score=False):
+        for k in T_SUM:
+            if k != "score_ms" or score:
+                acc[k] += t[k]
+        for k in T_MAX:
+            acc[k] = max(acc[k], t[k])
 
-        def close(self):
-            for _, m in self.parts:
-                m.close()
-
-    def step_pipelined():
-        timings = []
-        parts = vdist.sharded_search_pipelined(ctx, genome, codes, max_mm, device=xdev, algorithm=algorithm,
-                                               sub_batches=sub_batches, timings=timings)
-        acc = {k: sum(t[k] for t in timings) for k in ("scan_ms", "sort_ms", "finalize_ms", "prep_ms", "hits", "pairs", "genome_bytes")}
-        acc["score_ms"] = 0.0
-        step.acc, step.total = acc, len(Pieces(parts))
-        return Pieces(parts), None
-
-    def search_batch(batch_codes):
+    def search_batch(batch_codes, acc):
         if not use_dist:
-            return genome.search(batch_codes, max_mm, algorithm=algorithm), None
+            h = genome.search(batch_codes, max_mm, algorithm=algorithm)
+            add_timing(acc, ctx.timing())
+            return h, None
         merged, local = vdist.sharded_search(ctx, genome, batch_codes, max_mm, device=xdev, algorithm=algorithm,
                                              exchange=args.exchange)
+        add_timing(acc, ctx.timing())
         return local, merged
+
+    def step_pipelined():
+        timings, acc = [], new_acc()
+        parts = vdist.sharded_search_pipelined(ctx, genome, codes, max_mm, device=xdev, algorithm=algorithm,
+                                               sub_batches=sub_batches, timings=timings)
+        for t in timings:
+            add_timing(acc, t)
+        return [m for _, m in parts], sum(len(m) for _, m in parts), acc
 
     def step_c4():
         """Reference genome and SNP genome, one after the other (the reference runs them as two jobs)."""
+        acc = new_acc()
         h_ref = genome.search(codes, max_mm, algorithm=algorithm)
-        t_ref = ctx.timing()
+        add_timing(acc, ctx.timing())
         h_snp = snp_genome.search(codes, max_mm, algorithm=algorithm)
-        t_snp = ctx.timing()
-        step.acc = {k: t_ref[k] + t_snp[k] for k in ("scan_ms", "sort_ms", "finalize_ms", "prep_ms", "hits", "pairs", "genome_bytes")}
-        step.acc["score_ms"] = 0.0
-        step.total = len(h_ref) + len(h_snp)
-        h_snp.close()
-        return h_ref, None
+        add_timing(acc, ctx.timing())
+        return [h_ref, h_snp], len(h_ref) + len(h_snp), acc
+
+    def step_streamed():
+        """c5: the reads are streamed in batches; every batch's hits get their packed feature rows (+ MIT score)
+        on the GPU that owns the shard, before any gather.  One rank: the whole loop runs behind the C ABI
+        (vsc_search_stream, scoring from the batch callback)."""
+        acc = new_acc()
+        if not use_dist:
+            genome.search_streamed(codes, max_mm, lambda h, first, count: h.packed_features(to_host=False, mit=False),
+                                   batch=args.batch, algorithm=algorithm)
+            add_timing(acc, ctx.timing(), score=True)
+            return [], acc["hits"], acc
+        total = 0
+        for b in range(0, n_guides, args.batch):
+            local, merged = search_batch(codes[b:b + args.batch], acc)
+            local.packed_features(to_host=False, mit=False)
+            acc["score_ms"] += ctx.timing()["score_ms"]
+            total += len(merged)
+            local.close()
+            merged.close()
+        return [], total, acc
 
     def step():
-        """One pass over the workload.  c5: the reads are streamed in batches; every batch's hits get
-        their packed feature rows + MIT scores on the GPU that owns the shard, before any gather."""
         if args.workload == "c4":
             return step_c4()
         if pipelined:
             return step_pipelined()
-        if not streamed:
-            return search_batch(codes)
-        total, last = 0, None
-        acc = {"scan_ms": 0.0, "sort_ms": 0.0, "finalize_ms": 0.0, "prep_ms": 0.0, "score_ms": 0.0, "hits": 0, "pairs": 0,
-               "genome_bytes": 0}
-        for b in range(0, n_guides, args.batch):
-            if last is not None:
-                last[0].close()
-                if last[1] is not None:
-                    last[1].close()
-            last = search_batch(codes[b:b + args.batch])
-            t = ctx.timing()
-            last[0].packed_features(to_host=False, mit=False)
-            t2 = ctx.timing()
-            for k in ("scan_ms", "sort_ms", "finalize_ms", "prep_ms"):
-                acc[k] += t[k]
-            acc["score_ms"] += t2["score_ms"]
-            for k in ("hits", "pairs", "genome_bytes"):
-                acc[k] += t[k]
-            total += len(last[1]) if last[1] is not None else len(last[0])
-        step.acc, step.total = acc, total
-        return last
+        if streamed:
+            return step_streamed()
+        acc = new_acc()
+        h, m = search_batch(codes, acc)
+        return [x for x in (h, m) if x is not None], len(m) if m is not None else len(h), acc
 
-    scan_ms, sort_ms, fin_ms, prep_ms, hits_local, sites_local, passes = [], [], [], [], 0, 0, 0
-    pairs_local, stream_bytes = 0, 0
-    total_hits = 0
     for i in range(args.warmup):
-        h, m = step()
-        h.close()
-        if m is not None:
-            m.close()
+        objs, _, _ = step()
+        for o in objs:
+            o.close()
     barrier()
+    sums = new_acc()
+    total_hits = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        h, m = step()
-        t = dict(ctx.timing())
-        if streamed or pipelined or args.workload == "c4":
-            t.update(step.acc)
-            score_ms.append(step.acc["score_ms"])
-        scan_ms.append(t["scan_ms"])
-        sort_ms.append(t["sort_ms"])
-        fin_ms.append(t["finalize_ms"])
-        prep_ms.append(t["prep_ms"])
-        hits_local, sites_local, passes = t["hits"], t["sites"], max(passes, t["passes"])
-        pairs_local, stream_bytes = t["pairs"], t["genome_bytes"]
-        total_hits = step.total if (streamed or pipelined or args.workload == "c4") else (len(m) if m is not None else len(h))
-        h.close()
-        if m is not None:
-            m.close()
+        objs, total_hits, acc = step()
+        add_timing(sums, acc, score=True)
+        for o in objs:
+            o.close()
     barrier()
     dt = time.perf_counter() - t0
+    hits_local, sites_local, passes = sums["hits"] // args.steps, sums["sites"], sums["passes"]
+    pairs_local, stream_bytes = sums["pairs"] // args.steps, sums["genome_bytes"] // args.steps
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -326,34 +314,35 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         guides_per_s = n_guides * args.steps / dt
-        # roofline of the dominant kernel, per launch, this rank's shard
+        # roofline of the dominant kernel (the search kernel), per step, this rank's shard
         own_bases = (we - wb) * 32
-        scan_avg_ms = float(np.mean(scan_ms))
+        scan_avg_ms = sums["scan_ms"] / args.steps
+        read_passes = -(-n_guides // args.batch) if streamed else max(1, sums["read_passes"])
+        # per genome pass 0.375 B/base of planes, + 16 B per hit + 16 B per read - the figure for
+        # ANY search of this shape, whatever data structure the kernel reads.  roofline.frac is this one.
+        survey_bytes = 0.375 * own_bases * read_passes + 16.0 * hits_local + 16.0 * n_guides
         if algorithm == "scan":
-            kernel = "scan_kernel"
-            # 0.375 B/base of planes + 16 B per hit + 16 B per read
-            alg_bytes = 0.375 * own_bases + 16.0 * hits_local + 16.0 * n_guides
+            kernel, ops_per_compare = "scan_kernel", LANE_OPS_PER_COMPARE["scan"]
+            structure_bytes = 0.375 * own_bases * read_passes + 12.0 * hits_local + 8.0 * n_guides
         else:
-            sliced = os.environ.get("VSC_SEED_KERNEL") != "pairs"
-            kernel = "seed_sliced_kernel" if sliced else "seed_compare_kernel"
+            kernel, ops_per_compare = "seed_sliced_kernel", LANE_OPS_PER_COMPARE["sliced"]
             k_seg = max_mm // 3
-            list_entries = n_guides * 3 * (1, 22, 211)[k_seg]  # summed over the batches of a streamed run
-            if sliced:
-                # bit-sliced sites of the visited buckets (4 B each, read once) + the per-bucket read lists
-                # (16 B per entry) + per hit one 16 B site record read and 12 B written
-                alg_bytes = float(stream_bytes) + 16.0 * list_entries + 28.0 * hits_local
-            else:
-                # site records of the visited buckets (8 B each) + read lists (12 B per entry) + 12 B per hit written
-                alg_bytes = float(stream_bytes) + 12.0 * list_entries + 12.0 * hits_local
-        achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
+            list_entries = n_guides * 3 * (1, 22, 211)[k_seg]
+            # what THIS kernel has to move: bit-sliced sites of the visited buckets (4 B each, read once) + the
+            # per-bucket read lists (16 B per entry) + per hit one 16 B site record read and 8 B written
+            structure_bytes = float(stream_bytes) + 16.0 * list_entries + 24.0 * hits_local
+        achieved = survey_bytes / (scan_avg_ms * 1e-3) / 1e9
         compares = float(pairs_local)
-        ops_per_compare = LANE_OPS_PER_COMPARE["scan" if algorithm == "scan" else ("sliced" if sliced else "pairs")]
         lane_ops = compares * ops_per_compare / (scan_avg_ms * 1e-3)
-        traffic = None
+        # HBM traffic of the same kernel from the PMC passes of tools/collect_profiles.sh (FETCH_SIZE x 2 per the
+        # guide's gfx950 correction + WRITE_SIZE, one counter group per run), looked up - not measured in this run
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%s/%s/%d" % (args.workload, algorithm, world))
+                tj = json.load(open(tpath))
+                traffic = tj.get("%s/%s/%d" % (args.workload, algorithm, world))
+                traffic_source = tj.get("_source", "profiles/scan_traffic.json") if traffic is not None else None
             except Exception:
                 traffic = None
         out = {
@@ -363,28 +352,29 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, desc), "guides": n_guides, "genome_bases": total_bases,
                        "max_mismatches": max_mm, "parallelism": "genome-shard x%d" % world, "algorithm": algorithm,
+                       "multi_gpu_path": ("torch.distributed (RCCL) one process per GPU: varscot_amd/dist.py" if use_dist else None),
                        "exchange": (args.exchange if use_dist else None), "sub_batches": (sub_batches if pipelined else 1),
                        "hits_per_step": int(total_hits), "candidate_sites_per_s": total_hits * args.steps / dt,
-                       "pam_valid_sites": int(total_sites), "scan_passes": passes,
+                       "pam_valid_sites": int(total_sites), "search_launches": passes, "read_passes": read_passes,
                        "batch": args.batch if streamed else n_guides, "variant_genome": snp_info},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel, "launch_ms": scan_avg_ms, "algorithmic_bytes": alg_bytes,
-                         # SURVEY.md 8(d)'s figure for ANY search of this shape (planes once + 16 B per hit and read),
-                         # whatever data structure the kernel actually reads
-                         "survey_bytes": 0.375 * own_bases + 16.0 * hits_local + 16.0 * n_guides,
-                         "survey_frac": (0.375 * own_bases + 16.0 * hits_local + 16.0 * n_guides) / (scan_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel, "launch_ms": scan_avg_ms, "algorithmic_bytes": survey_bytes,
+                         "bytes_model": "SURVEY.md 8(d): 0.375 B/base per genome pass + 16 B/hit + 16 B/read",
+                         # the bytes this kernel's own data structure makes it move, for comparison with `traffic`
+                         "structure_bytes": structure_bytes,
+                         "structure_frac": structure_bytes / (scan_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "whole_step_frac": survey_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "integer/bitwise compare kernel; VALU issue is the binding resource next to HBM "
                                  "(DESIGN.md section 4) - both are reported; valu counts the comparison only, not the hit path",
                          "valu": {"pair_compares_per_s": compares / (scan_avg_ms * 1e-3),
                                   "lane_ops_per_compare": ops_per_compare, "achieved_lane_ops_per_s": lane_ops,
                                   "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK, "frac": lane_ops / VALU_LANE_OPS_PEAK}},
-            # the library sort (rocPRIM onesweep) moves every 12-byte (key, value) pair once in and once
-            # out per 8-bit digit; at m = 8 it is as long as the search kernel, so it gets its own line.
-            # vsc_search sorts key bits [begin, end): end = 33 + guide bits, up to 16 low bits are left to finalize
-            "roofline_sort": sort_roofline(args.batch if streamed else n_guides, hits_local, float(np.mean(sort_ms))),
-            "kernels_ms": {"search": scan_avg_ms, "prep": float(np.mean(prep_ms)), "sort": float(np.mean(sort_ms)),
-                           "finalize": float(np.mean(fin_ms)), "score": float(np.mean(score_ms)) if score_ms else None},
+            # the ordering of the hits (hand-written bin sort) is the second largest share of a step at m = 8
+            "roofline_sort": sort_roofline(sums, args.steps),
+            "kernels_ms": {"search": scan_avg_ms, "prep": sums["prep_ms"] / args.steps, "sort": sums["sort_ms"] / args.steps,
+                           "finalize": sums["finalize_ms"] / args.steps,
+                           "score": (sums["score_ms"] / args.steps) if streamed else None},
             "setup": {"genome_generate_s": t_gen, "genome_hbm_bytes": genome.device_bytes, "index_build_ms": index_ms},
         }
         if world == 1 and not args.no_cpu_baseline:

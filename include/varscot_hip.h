@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VSC_ABI_VERSION 1
+#define VSC_ABI_VERSION 2
 
 #define VSC_OK 0
 #define VSC_ERR_INVALID (-22)  /* EINVAL: bad argument (e.g. mismatches outside 0..8)          */
@@ -97,8 +97,8 @@ typedef struct {
 typedef struct {
     double scan_ms;          /* the dominant search kernel: scan_kernel or seed_sliced_kernel (last pass) */
     double prep_ms;          /* read upload (+ per-bucket read lists for VSC_ALGO_SEED) */
-    double sort_ms;          /* radix sort of the hit keys */
-    double finalize_ms;      /* contig resolution + record assembly */
+    double sort_ms;          /* bin sort of the hit records: histogram + partition level(s) */
+    double finalize_ms;      /* ordering inside the bins + contig resolution + record assembly (+ deeper sort levels) */
     double score_ms;         /* last vsc_score_hits call */
     double total_ms;         /* first launch to last completion of the last vsc_search */
     double index_ms;         /* last seed-index build on this context */
@@ -106,8 +106,13 @@ typedef struct {
     uint64_t pairs;          /* (window, read) comparisons made */
     uint64_t hits;           /* hits reported */
     uint64_t genome_bytes;   /* genome bytes the search kernel streamed: planes (SCAN) or visited site records (SEED) */
-    uint32_t passes;         /* search launches needed (1 unless the hit buffer overflowed) */
+    uint32_t passes;         /* search launches needed (1 per read pass unless a hit buffer overflowed) */
     uint32_t algorithm;      /* VSC_ALGO_SCAN or VSC_ALGO_SEED: what ran */
+    uint64_t sort_bytes;     /* bytes the sort kernels moved (8 per packed record read or written, 16 per result record) */
+    uint32_t sort_levels;    /* partition levels the bin sort ran (0: the regions fitted its last stage as they were) */
+    uint32_t sort_bin_bits;  /* key bits of the first partition level */
+    uint32_t read_passes;    /* passes over the read set (a pass takes at most 16 384 reads) */
+    uint32_t reserved;
 } vsc_timing;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -177,6 +182,19 @@ uint64_t vsc_genome_device_bytes(const vsc_genome *genome);
  */
 int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
                const vsc_search_params *params, vsc_hits **out);
+/*
+ * The same search for read sets whose result does not fit the device at once (100 000 reads at 8
+ * mismatches on 3 Gbp are 1.6e10 records): the reads are searched in batches of batch_reads (0 or more
+ * than 16 384: 16 384) and every batch's result - same record order, guide = index into `guides` - is
+ * handed to on_batch and freed when it returns.  The callback may use the result with any vsc_hits_* /
+ * vsc_score_hits* call on the same context; a non-zero return value stops the stream and is returned.
+ * Replaces the OpenMP loop over reads of read_mapping/bidir_mapping.cpp:285-295 for workloads where the
+ * reference appends every read's records to its output buffer and moves on.
+ * vsc_ctx_timing afterwards reports sums over the batches (score_ms: the callbacks' scoring calls).
+ */
+typedef int (*vsc_batch_fn)(void *user, vsc_hits *batch, uint32_t first_guide, uint32_t n_guides);
+int vsc_search_stream(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
+                      const vsc_search_params *params, uint32_t batch_reads, vsc_batch_fn on_batch, void *user);
 uint64_t vsc_hits_count(const vsc_hits *hits);
 /* Device pointer to vsc_hits_count() records of type vsc_hit (valid until vsc_hits_free). */
 const void *vsc_hits_data_dev(const vsc_hits *hits);

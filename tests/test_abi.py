@@ -23,7 +23,7 @@ def test_header_symbols_are_exported_and_bound():
     L = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert va.lib().vsc_abi_version() == 1
+    assert va.lib().vsc_abi_version() == 2
 
 
 def test_no_device_fails_loudly():

@@ -477,16 +477,18 @@ def test_shard_merge_kernels(ctx, oracle, world):
     assert got.tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("low_bits", ["0", "3", "8", None])
+@pytest.mark.parametrize("cap,max_bits", [(None, None), ("4096", "11"), ("256", "3"), ("16", "1")])
 @pytest.mark.parametrize("algo", ALGOS)
-def test_low_position_bits_left_to_finalize(ctx, oracle, algo, low_bits, monkeypatch):
-    """The sort skips the low position bits and finalize ranks each group of neighbours: homopolymer
-    runs give one read a hit at EVERY position, i.e. full groups of 2^low_bits records, also across the
-    256-record blocks of the kernel; VSC_SORT_LOW_BITS=0 is the plain full-key sort."""
-    if low_bits is None:
-        monkeypatch.delenv("VSC_SORT_LOW_BITS", raising=False)
-    else:
-        monkeypatch.setenv("VSC_SORT_LOW_BITS", low_bits)
+def test_sort_levels_on_dense_position_runs(ctx, oracle, algo, cap, max_bits, monkeypatch):
+    """The bin sort (vsc_sort.hip): homopolymer runs give one read a hit at EVERY position - dense sub-bins that
+    the finalize kernel has to rank, bins far larger than their neighbours.  VSC_SORT_CAP / VSC_SORT_MAX_BITS
+    shrink the LDS capacity and the bits per partition level so that the partition levels and the oversize
+    path (bins handed to a further level, up to dozens of levels) run on a few thousand records."""
+    for k, v in (("VSC_SORT_CAP", cap), ("VSC_SORT_MAX_BITS", max_bits)):
+        if v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, v)
     rng = np.random.default_rng(77)
     guides = ["G" * 23, "C" * 23, "G" * 11 + "A" + "G" * 11] + random_guides(rng, 5)
     contigs = ["G" * 1500 + random_seq(rng, 300) + "C" * 900, random_seq(rng, 2000), "G" * 700]
@@ -494,6 +496,8 @@ def test_low_position_bits_left_to_finalize(ctx, oracle, algo, low_bits, monkeyp
     got = gpu_search(ctx, contigs, guides, 3, None, algo=algo)
     assert len(want) > 5000
     assert hits_as_tuples(got) == hits_as_tuples(want)
+    levels = ctx.timing()["sort_levels"]
+    assert (levels == 0) if cap is None else (levels >= 1)
 
 
 @pytest.mark.parametrize("algo", ALGOS)
@@ -511,30 +515,13 @@ def test_baseline_config_c1(ctx, oracle, algo):
     assert hits_as_tuples(got) == hits_as_tuples(want)
 
 
-def test_pair_kernel_still_matches(oracle, monkeypatch):
-    """VSC_SEED_KERNEL=pairs: the per-pair comparison kernel (8-byte site records, chunks of 512) stays a
-    selectable variant of the seed search and must give the same records."""
-    monkeypatch.setenv("VSC_SEED_KERNEL", "pairs")
-    c = va.Context(0)
-    try:
-        rng = np.random.default_rng(31)
-        guides = random_guides(rng, 24)
-        contigs = make_genome(31, [400000, 150000, 23, 5000], guides, 8, n_plant=300, n_runs=8)
-        for m in (8, 4, 1):
-            want = oracle.search_fast(contigs, guides, m)
-            got = gpu_search(c, contigs, guides, m, algo="seed")
-            assert hits_as_tuples(got) == hits_as_tuples(want)
-    finally:
-        c.close()
-
-
-@pytest.mark.parametrize("parts", ["1", "4"])
-def test_output_regions_by_read_range(ctx, oracle, parts, monkeypatch):
-    """The sliced kernel writes its hits into regions by read range that are sorted and finalized
-    concurrently (on by default only for long read lists): forced on and off here, with a hit buffer that
-    has to grow, reads whose hits straddle the region boundaries, and a read count that is not a multiple
-    of four."""
-    monkeypatch.setenv("VSC_SEED_PARTS", parts)
+@pytest.mark.parametrize("cap", [None, "512"])
+def test_hit_buffer_growth_and_sort_partition(ctx, oracle, cap, monkeypatch):
+    """Thousands of hits per read on a small genome: the hit buffer sized from the uniform-genome model has to
+    grow (second search launch), the second search reuses the grown buffers; with a reduced bin capacity the
+    region goes through the partition level.  A read count that is not a multiple of four."""
+    if cap:
+        monkeypatch.setenv("VSC_SORT_CAP", cap)
     rng = np.random.default_rng(909)
     guides = random_guides(rng, 37)
     pieces = []
@@ -549,19 +536,73 @@ def test_output_regions_by_read_range(ctx, oracle, parts, monkeypatch):
         assert hits_as_tuples(got) == hits_as_tuples(want)
 
 
-def test_output_regions_of_512_reads(ctx, oracle, monkeypatch):
-    """More than 512 reads: the default region size applies (region = read index >> 9), here forced on for
-    a small genome; reads at the region boundaries 511 / 512 / 1023 / 1024 get planted sites."""
-    monkeypatch.setenv("VSC_SEED_PARTS", "32")
+@pytest.mark.parametrize("algo", ALGOS)
+def test_output_regions_of_128_reads(ctx, oracle, algo):
+    """More than 128 reads: several output regions (region = read index >> 7; the scan reaches them through
+    level 0 of the sort); reads at the region boundaries 127 / 128 / 255 / 256 / 1023 / 1024 get planted sites."""
     rng = np.random.default_rng(5150)
     guides = random_guides(rng, 1100)
     contigs = make_genome(5150, [200000, 80000, 30000], guides, 7, n_plant=600, n_runs=4)
     seq = contigs[0]
-    for k, gi in enumerate([0, 511, 512, 1023, 1024, 1099]):
+    marked = [0, 127, 128, 255, 256, 1023, 1024, 1099]
+    for k, gi in enumerate(marked):
         at = 1000 + 400 * k
         seq = seq[:at] + mutate(rng, guides[gi], 3, 0, 20) + seq[at + 23:]
     contigs[0] = seq
     want = oracle.search_fast(contigs, guides, 7)
-    got = gpu_search(ctx, contigs, guides, 7, algo="seed")
-    assert {int(g) for g in want["guide"]} >= {0, 511, 512, 1023, 1024, 1099}
+    got = gpu_search(ctx, contigs, guides, 7, algo=algo)
+    assert {int(g) for g in want["guide"]} >= set(marked)
     assert hits_as_tuples(got) == hits_as_tuples(want)
+
+
+def test_more_reads_than_one_pass_takes(ctx, oracle):
+    """16 384 reads fill the 128 output regions of a pass: vsc_search runs larger read sets pass by pass and
+    the passes' results follow each other (read index = major sort key).  Reads on either side of the pass
+    boundary get planted sites; the second pass has an odd read count."""
+    rng = np.random.default_rng(4242)
+    guides = random_guides(rng, 16384 + 301)
+    contigs = make_genome(4242, [120000, 50000], guides[:40], 5, n_plant=200, n_runs=3)
+    seq = contigs[1]
+    marked = [16383, 16384, 16385, 16384 + 300]
+    for k, gi in enumerate(marked):
+        at = 2000 + 300 * k
+        seq = seq[:at] + mutate(rng, guides[gi], 2, 0, 20) + seq[at + 23:]
+    contigs[1] = seq
+    want = oracle.search_fast(contigs, guides, 5)
+    got = gpu_search(ctx, contigs, guides, 5, algo="seed")
+    assert ctx.timing()["read_passes"] == 2
+    assert {int(g) for g in want["guide"]} >= set(marked)
+    assert hits_as_tuples(got) == hits_as_tuples(want)
+
+
+def test_streamed_search_equals_one_search(ctx, oracle):
+    """vsc_search_stream (the c5 shape: batches of reads, each batch's result handed to a callback and freed):
+    the concatenated batches are the records of one search, read indices included, and per-batch scoring
+    inside the callback sees the right reads."""
+    rng = np.random.default_rng(99)
+    guides = random_guides(rng, 700)
+    contigs = make_genome(99, [150000, 40000, 23], guides[:60], 6, n_plant=400, n_runs=3)
+    packed = va.PackedGenome.from_sequences(contigs)
+    gen = ctx.load_genome(packed)
+    whole = gen.search(guides, 6, algorithm="seed")
+    want = whole.to_numpy()
+    want_mit, _, _ = whole.scores(mit=True)
+    want_rows, _ = whole.packed_features()
+    whole.close()
+    parts, mits, rows, spans = [], [], [], []
+
+    def on_batch(h, first, count):
+        spans.append((first, count))
+        parts.append(h.to_numpy())
+        mits.append(h.scores(mit=True)[0])
+        rows.append(h.packed_features()[0])
+
+    gen.search_streamed(guides, 6, on_batch, batch=256, algorithm="seed")
+    gen.close()
+    assert spans == [(0, 256), (256, 256), (512, 188)]
+    got = np.concatenate(parts)
+    assert got.tobytes() == want.tobytes()
+    assert np.array_equal(np.concatenate(mits), want_mit)
+    assert np.array_equal(np.concatenate(rows), want_rows)
+    ref = oracle.search_fast(contigs, guides, 6)
+    assert hits_as_tuples(got) == hits_as_tuples(ref)

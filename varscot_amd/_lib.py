@@ -38,11 +38,15 @@ class Timing(C.Structure):
     _fields_ = [("scan_ms", C.c_double), ("prep_ms", C.c_double), ("sort_ms", C.c_double),
                 ("finalize_ms", C.c_double), ("score_ms", C.c_double), ("total_ms", C.c_double),
                 ("index_ms", C.c_double), ("sites", C.c_uint64), ("pairs", C.c_uint64), ("hits", C.c_uint64),
-                ("genome_bytes", C.c_uint64), ("passes", C.c_uint32), ("algorithm", C.c_uint32)]
+                ("genome_bytes", C.c_uint64), ("passes", C.c_uint32), ("algorithm", C.c_uint32),
+                ("sort_bytes", C.c_uint64), ("sort_levels", C.c_uint32), ("sort_bin_bits", C.c_uint32),
+                ("read_passes", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
+
+BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32)  # vsc_batch_fn
 
 # every symbol include/varscot_hip.h declares: (name, restype, argtypes)
 _u32p = C.POINTER(C.c_uint32)
@@ -66,6 +70,7 @@ SYMBOLS = [
     ("vsc_genome_build_index", C.c_int, [_vp, _vp, C.POINTER(SearchParams)]),
     ("vsc_genome_device_bytes", C.c_uint64, [_vp]),
     ("vsc_search", C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(SearchParams), C.POINTER(_vp)]),
+    ("vsc_search_stream", C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(SearchParams), C.c_uint32, BATCH_FN, _vp]),
     ("vsc_hits_count", C.c_uint64, [_vp]),
     ("vsc_hits_data_dev", _vp, [_vp]),
     ("vsc_hits_data", C.c_int, [_vp, C.POINTER(_vp)]),

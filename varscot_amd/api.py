@@ -218,14 +218,44 @@ class Genome:
         check(lib().vsc_search(self.ctx._h, self._h, ptr(codes), len(codes), C.byref(p), C.byref(h)), self.ctx._h)
         return Hits(self, h, codes)
 
+    def search_streamed(self, guides, max_mismatches, on_batch, batch=0, extra_pam=None, algorithm="auto"):
+        """vsc_search_stream: the reads are searched in batches of `batch` (0 = the library's maximum, 16 384)
+        and on_batch(hits, first_guide, n_guides) is called with every batch's result - a Hits object that is
+        only valid inside the call (score it, copy it out, gather it; the library frees it afterwards).
+        Record order and read indices are those of one big search.  ctx.timing() afterwards holds sums."""
+        codes = guides if isinstance(guides, np.ndarray) else pack_guides(guides)
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        p = self._params(max_mismatches, extra_pam, algorithm)
+        failure = []
+
+        def trampoline(_user, handle, first, count):
+            try:
+                h = Hits(self, C.c_void_p(handle), codes, owned=False)
+                try:
+                    on_batch(h, int(first), int(count))
+                finally:
+                    h.close()
+                return 0
+            except BaseException as e:  # no exception may cross the C boundary
+                failure.append(e)
+                return -5
+
+        cb = _lib.BATCH_FN(trampoline)
+        rc = lib().vsc_search_stream(self.ctx._h, self._h, ptr(codes), len(codes), C.byref(p), int(batch), cb, None)
+        if failure:
+            raise failure[0]
+        check(rc, self.ctx._h)
+
 
 class Hits:
     """Result of one search (vsc_hits): records sorted by (guide, strand, contig, pos)."""
 
-    def __init__(self, genome, handle, codes):
+    def __init__(self, genome, handle, codes, owned=True):
         self.genome, self._h, self.codes = genome, handle, codes
         self.ctx = genome.ctx
-        self.ctx._children.add(self)
+        self._owned = owned  # a batch of search_streamed belongs to the library: never freed from here
+        if owned:
+            self.ctx._children.add(self)
 
     def __len__(self):
         return int(lib().vsc_hits_count(self._h))
@@ -269,7 +299,8 @@ class Hits:
 
     def close(self):
         if self._h:
-            lib().vsc_hits_free(self._h)
+            if self._owned:
+                lib().vsc_hits_free(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -284,6 +315,7 @@ class MergedHits(Hits):
 
     def __init__(self, ctx, handle):
         self.ctx, self._h, self.codes, self.genome = ctx, handle, None, None
+        self._owned = True
         ctx._children.add(self)
 
     def to_numpy(self):

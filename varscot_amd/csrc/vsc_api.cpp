@@ -68,13 +68,12 @@ struct vsc_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    // the output regions of a sliced search are sorted and finalized concurrently: region 0 on `stream`, the others here
-    hipStream_t aux[kSortStreams - 1] = {};
-    hipEvent_t sorted_ev[kParts] = {}, done_ev[kSortStreams] = {};
     std::string err;
     vsc_timing timing{};
-    DeviceBuf counters, guides, keys_a, keys_b, vals_a, vals_b, sort_temp, score_mit, score_flags, score_feat;
-    DeviceBuf seed_k1, seed_k2, seed_v1, seed_v2, seed_off, seed_poff, seed_lplanes, seed_lgid, seed_lrest;  // per-search read lists
+    // keys_a / keys_b: the two record buffers the bin sort alternates between (keys_a + vals_a: the scan's (key, value) pairs)
+    DeviceBuf counters, guides, keys_a, keys_b, vals_a, sort_temp, score_mit, score_flags, score_feat;
+    DeviceBuf sort_segs, sort_tabs, sort_over;  // bin sort: segment table + tile starts, per-bin tables, oversize list + counter
+    DeviceBuf seed_k1, seed_k2, seed_v1, seed_v2, seed_off, seed_poff, seed_lrest;  // per-search read lists
     // record buffers of freed results, kept for the next search: hipMalloc / hipFree of tens of GB
     // cost hundreds of milliseconds each
     std::vector<DeviceBuf> spare_records;
@@ -94,11 +93,10 @@ struct vsc_genome {
     uint8_t index_has_extra_pam = 0;
     char index_extra_pam[2] = {0, 0};
     uint64_t index_sites = 0;  // S
-    uint2 *d_ix_planes = nullptr;
-    uint32_t *d_ix_pos = nullptr, *d_ix_bucket_start = nullptr;
+    uint32_t *d_ix_bucket_start = nullptr;
     uint4 *d_ix_chunk_tab = nullptr;
-    uint32_t *d_ix_vert = nullptr;  // bit-sliced blocks of 32 sites (null: index built for the pair kernel)
-    uint4 *d_ix_sites = nullptr;    // sliced kernel: 16-byte site records (instead of d_ix_planes / d_ix_pos)
+    uint32_t *d_ix_vert = nullptr;  // bit-sliced blocks of 32 sites
+    uint4 *d_ix_sites = nullptr;    // 16-byte site records
     uint32_t ix_chunks = 0;
     uint64_t index_bytes = 0;
     double index_ms = 0;
@@ -247,16 +245,6 @@ int vsc_ctx_create(int device_id, vsc_ctx **out)
             vsc_ctx_destroy(ctx);
             return VSC_ERR_DEVICE;
         }
-    for (int i = 0; i < kParts; ++i)
-        if (hipEventCreate(&ctx->sorted_ev[i]) != hipSuccess) {
-            vsc_ctx_destroy(ctx);
-            return VSC_ERR_DEVICE;
-        }
-    for (int i = 0; i < kSortStreams; ++i)
-        if (hipEventCreate(&ctx->done_ev[i]) != hipSuccess || (i + 1 < kSortStreams && hipStreamCreate(&ctx->aux[i]) != hipSuccess)) {
-            vsc_ctx_destroy(ctx);
-            return VSC_ERR_DEVICE;
-        }
     *out = ctx;
     return VSC_OK;
 }
@@ -266,23 +254,14 @@ int vsc_ctx_destroy(vsc_ctx *ctx)
     if (!ctx) return VSC_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->vals_b,
-                         &ctx->sort_temp, &ctx->score_mit, &ctx->score_flags, &ctx->score_feat, &ctx->seed_k1,
-                         &ctx->seed_k2, &ctx->seed_v1, &ctx->seed_v2, &ctx->seed_off, &ctx->seed_poff,
-                         &ctx->seed_lplanes, &ctx->seed_lgid, &ctx->seed_lrest})
+    for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->sort_temp,
+                         &ctx->score_mit, &ctx->score_flags, &ctx->score_feat, &ctx->sort_segs, &ctx->sort_tabs,
+                         &ctx->sort_over, &ctx->seed_k1, &ctx->seed_k2, &ctx->seed_v1, &ctx->seed_v2, &ctx->seed_off,
+                         &ctx->seed_poff, &ctx->seed_lrest})
         b->release();
     for (auto &b : ctx->spare_records) b.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
-    for (int i = 0; i < kParts; ++i)
-        if (ctx->sorted_ev[i]) (void)hipEventDestroy(ctx->sorted_ev[i]);
-    for (int i = 0; i < kSortStreams; ++i) {
-        if (ctx->done_ev[i]) (void)hipEventDestroy(ctx->done_ev[i]);
-        if (i + 1 < kSortStreams && ctx->aux[i]) {
-            (void)hipStreamSynchronize(ctx->aux[i]);
-            (void)hipStreamDestroy(ctx->aux[i]);
-        }
-    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VSC_OK;
@@ -378,8 +357,7 @@ int vsc_genome_free(vsc_genome *g)
     if (!g) return VSC_OK;
     if (g->ctx) (void)hipSetDevice(g->ctx->device);
     for (void *p : {(void *)g->d_hi, (void *)g->d_lo, (void *)g->d_nm, (void *)g->d_contig_off, (void *)g->d_contig_end, (void *)g->d_hl,
-                    (void *)g->d_ix_planes, (void *)g->d_ix_pos, (void *)g->d_ix_bucket_start, (void *)g->d_ix_chunk_tab,
-                    (void *)g->d_ix_vert, (void *)g->d_ix_sites})
+                    (void *)g->d_ix_bucket_start, (void *)g->d_ix_chunk_tab, (void *)g->d_ix_vert, (void *)g->d_ix_sites})
         if (p) (void)hipFree(p);
     delete g;
     return VSC_OK;
@@ -429,18 +407,9 @@ int scan_groups(const vsc_ctx *ctx, uint32_t n_tiles)
     return (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
 }
 
-// VSC_SEED_KERNEL=pairs selects the per-pair comparison kernel (chunks of 512 sites, no bit-sliced
-// copy of the sites) for experiments; the default is the bit-sliced kernel.
-bool use_sliced_kernel()
-{
-    const char *o = std::getenv("VSC_SEED_KERNEL");
-    return !(o && std::strcmp(o, "pairs") == 0);
-}
-
 bool index_matches(const vsc_genome *g, const vsc_search_params *p)
 {
     if (!g->has_index) return false;
-    if (use_sliced_kernel() != (g->d_ix_vert != nullptr)) return false;
     const bool want = p && p->has_extra_pam && base_code(p->extra_pam[0]) < 4 && base_code(p->extra_pam[1]) < 4;
     if (want != (g->index_has_extra_pam != 0)) return false;
     return !want || (base_code(p->extra_pam[0]) == base_code(g->index_extra_pam[0]) &&
@@ -449,8 +418,7 @@ bool index_matches(const vsc_genome *g, const vsc_search_params *p)
 
 void free_index(vsc_genome *g)
 {
-    for (void **p : {(void **)&g->d_ix_planes, (void **)&g->d_ix_pos, (void **)&g->d_ix_bucket_start,
-                     (void **)&g->d_ix_chunk_tab, (void **)&g->d_ix_vert, (void **)&g->d_ix_sites}) {
+    for (void **p : {(void **)&g->d_ix_bucket_start, (void **)&g->d_ix_chunk_tab, (void **)&g->d_ix_vert, (void **)&g->d_ix_sites}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -496,13 +464,7 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
     size_t temp_bytes = 0;
     step(sort32_temp_bytes(S, 2 * kSegBases, &temp_bytes));
     step(tmp.ensure(std::max<size_t>(temp_bytes, 16)));
-    const bool sliced = use_sliced_kernel();
-    if (sliced) {
-        step(hipMalloc((void **)&g->d_ix_sites, std::max<uint64_t>(3 * S, 1) * sizeof(uint4)));
-    } else {
-        step(hipMalloc((void **)&g->d_ix_planes, std::max<uint64_t>(3 * S, 1) * sizeof(uint2)));
-        step(hipMalloc((void **)&g->d_ix_pos, std::max<uint64_t>(3 * S, 1) * sizeof(uint32_t)));
-    }
+    step(hipMalloc((void **)&g->d_ix_sites, std::max<uint64_t>(3 * S, 1) * sizeof(uint4)));
     step(hipMalloc((void **)&g->d_ix_bucket_start, (kBuckets + 1) * sizeof(uint32_t)));
     if (e == hipSuccess && S > 0) {
         // pass 2: emit
@@ -517,12 +479,8 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         step(launch_seed_keys((const uint32_t *)sx.p, (const uint32_t *)sl.p, S, s, (uint32_t *)k1.p, (uint32_t *)i1.p, st));
         step(launch_sort32(tmp.p, temp_bytes, (const uint32_t *)k1.p, (uint32_t *)k2.p, (const uint32_t *)i1.p,
                            (uint32_t *)i2.p, S, 2 * kSegBases, st));
-        if (sliced)
-            step(launch_seed_gather16((const uint32_t *)sx.p, (const uint32_t *)sl.p, (const uint32_t *)sp.p,
-                                      (const uint32_t *)i2.p, S, g->d_ix_sites + (size_t)s * S, st));
-        else
-            step(launch_seed_gather((const uint32_t *)sx.p, (const uint32_t *)sl.p, (const uint32_t *)sp.p,
-                                    (const uint32_t *)i2.p, S, g->d_ix_planes + (size_t)s * S, g->d_ix_pos + (size_t)s * S, st));
+        step(launch_seed_gather16((const uint32_t *)sx.p, (const uint32_t *)sl.p, (const uint32_t *)sp.p,
+                                  (const uint32_t *)i2.p, S, g->d_ix_sites + (size_t)s * S, st));
         step(launch_lower_bound((const uint32_t *)k2.p, S, kBucketsPerSeg, 0, (uint32_t)(s * S),
                                 g->d_ix_bucket_start + (size_t)s * kBucketsPerSeg, st));
     }
@@ -536,9 +494,9 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         free_index(g);
         return e;
     }
-    // chunks: at most kSlicedChunk sites of one bucket each (kBatch for the pair kernel); the sites of a
-    // chunk also exist bit-sliced, in blocks of 32, from block `vfirst` on
-    const uint64_t chunk_sites = sliced ? kSlicedChunk : kBatch;
+    // chunks: at most kSlicedChunk sites of one bucket each; the sites of a chunk also exist bit-sliced, in
+    // blocks of 32, from block `vfirst` on
+    const uint64_t chunk_sites = kSlicedChunk;
     std::vector<uint32_t> ctab;  // {first site, site count, bucket, first vertical block} per chunk
     ctab.reserve(4 * (3 * S / chunk_sites + kBuckets));
     uint64_t n_blocks = 0;
@@ -553,14 +511,12 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         }
     g->ix_chunks = (uint32_t)(ctab.size() / 4);
     const size_t cb = std::max<size_t>(ctab.size(), 4) * sizeof(uint32_t);
-    const size_t vb = sliced ? std::max<uint64_t>(n_blocks, 1) * 2 * kRestBases * sizeof(uint32_t) : 0;
+    const size_t vb = std::max<uint64_t>(n_blocks, 1) * 2 * kRestBases * sizeof(uint32_t);
     step(hipMalloc((void **)&g->d_ix_chunk_tab, cb));
     if (e == hipSuccess && !ctab.empty())
         step(hipMemcpyAsync(g->d_ix_chunk_tab, ctab.data(), ctab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    if (sliced) {
-        step(hipMalloc((void **)&g->d_ix_vert, vb));
-        if (e == hipSuccess) step(launch_seed_transpose(g->d_ix_sites, g->d_ix_chunk_tab, g->ix_chunks, g->d_ix_vert, st));
-    }
+    step(hipMalloc((void **)&g->d_ix_vert, vb));
+    if (e == hipSuccess) step(launch_seed_transpose(g->d_ix_sites, g->d_ix_chunk_tab, g->ix_chunks, g->d_ix_vert, st));
     step(hipEventRecord(ctx->ev[6], st));
     step(hipStreamSynchronize(st));
     if (e != hipSuccess) {
@@ -578,7 +534,7 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         g->index_extra_pam[0] = params->extra_pam[0];
         g->index_extra_pam[1] = params->extra_pam[1];
     }
-    g->index_bytes = 3 * S * (sliced ? sizeof(uint4) : sizeof(uint2) + sizeof(uint32_t)) + (kBuckets + 1) * sizeof(uint32_t) + cb + vb;
+    g->index_bytes = 3 * S * sizeof(uint4) + (kBuckets + 1) * sizeof(uint32_t) + cb + vb;
     return hipSuccess;
 }
 
@@ -600,66 +556,184 @@ int vsc_genome_build_index(vsc_ctx *ctx, vsc_genome *genome, const vsc_search_pa
     return VSC_OK;
 }
 
-int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
-               const vsc_search_params *params, vsc_hits **out)
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// search
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+unsigned ceil_log2(uint64_t x)
 {
-    if (!ctx || !out) return VSC_ERR_INVALID;
-    *out = nullptr;
-    ctx->err.clear();
-    if (!genome || !params || (n_guides && !guides)) return fail(ctx, VSC_ERR_INVALID, "vsc_search: null argument");
-    if (genome->ctx != ctx) return fail(ctx, VSC_ERR_INVALID, "vsc_search: genome belongs to another context");
-    if (params->max_mismatches > VSC_MAX_MISMATCHES)  // read_mapping/bidir_mapping.cpp:234-238
-        return fail(ctx, VSC_ERR_INVALID, "Maximum number of mismatches must lie between 0 and 8.");
-    if (params->algorithm > VSC_ALGO_SEED) return fail(ctx, VSC_ERR_INVALID, "vsc_search: unknown algorithm");
-    if (n_guides >= (1u << 31)) return fail(ctx, VSC_ERR_RANGE, "vsc_search: too many reads");
+    unsigned b = 0;
+    while (b < 63 && (1ull << b) < x) ++b;
+    return b;
+}
 
-    VSC_HIP(ctx, hipSetDevice(ctx->device));
-    vsc_hits *hits = new (std::nothrow) vsc_hits();
-    if (!hits) return fail(ctx, VSC_ERR_NOMEM, "vsc_search: out of host memory");
-    hits->ctx = ctx;
-    vsc_timing t{};
-    t.index_ms = ctx->timing.index_ms;
-    if (n_guides == 0) {
-        hits->host_valid = true;
-        ctx->timing = t;
-        *out = hits;
-        return VSC_OK;
-    }
-    auto cleanup = [&](int code) {
-        vsc_hits_free(hits);
-        return code;
-    };
-#define VSC_HIP_H(call)                                                              \
-    do {                                                                             \
-        hipError_t e_ = (call);                                                      \
-        if (e_ != hipSuccess)                                                        \
-            return cleanup(fail(ctx, e_ == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, #call, e_)); \
-    } while (0)
+// what one bin sort did (goes into vsc_timing)
+struct SortInfo {
+    unsigned levels = 0;     // partition levels run (0: every region fitted the finalize kernel as it was)
+    unsigned bin_bits = 0;   // key bits of the first partition level
+    uint64_t bytes = 0;      // bytes the sort kernels moved: 8 per record read or written, 16 per result record
+};
 
-    // ---- which search: streaming scan of the planes, or the seed-partitioned site tables -------------
-    const double own_bases = (double)genome->n_tiles * kTileBases;
-    int algo = params->algorithm;
-    if (algo == VSC_ALGO_AUTO) {
-        // the index costs about as much as scanning a few hundred reads; it pays for itself when it is
-        // already there or when the search is big enough
-        const bool worth_building = (double)n_guides * own_bases >= 2.0e10;
-        algo = (index_matches(genome, params) || worth_building) ? VSC_ALGO_SEED : VSC_ALGO_SCAN;
-    }
-    if (algo == VSC_ALGO_SEED && !index_matches(genome, params)) {
-        std::string why;
-        hipError_t e = build_index(ctx, const_cast<vsc_genome *>(genome), params, &why);
-        if (e != hipSuccess) {
-            if (params->algorithm == VSC_ALGO_SEED || why.empty())
-                return cleanup(fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE,
-                                    why.empty() ? "vsc_search: building the seed index" : why.c_str(), why.empty() ? e : hipSuccess));
-            algo = VSC_ALGO_SCAN;  // auto mode: a genome too large for the index is still searchable
-        } else {
-            t.index_ms = genome->index_ms;
+// Orders the packed records of `segs` (each segment independently, ascending) and writes the vsc_hit
+// records: hist -> scan -> partition per level, then finalize; bins too large for the finalize kernel come
+// back as the segments of the next level (vsc_sort.hip).  `src` holds the segments' records, `other` is a
+// buffer of the same size; `key_bits` = significant bits of record >> kRecPosShift inside a segment.
+// pair_keys != null: level 0 of the streaming scan - one segment of (key, value) pairs, partitioned by region
+// into `other` and packed on the way; the regions then are the segments.
+hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg> segs, uint64_t *src, uint64_t *other,
+                    unsigned key_bits, vsc_hit *out, hipEvent_t ev_sorted, SortInfo *info)
+{
+    hipStream_t st = ctx->stream;
+    unsigned rem = key_bits;  // key bits no partition level has used yet
+    bool sorted_marked = false;
+    // test knobs: a smaller bin capacity / fewer bits per level make the partition levels and the
+    // oversize path run on inputs of a few thousand records
+    uint64_t sort_cap = kSortCap;
+    unsigned max_bits = kSortMaxBinBits;
+    if (const char *o = std::getenv("VSC_SORT_CAP")) sort_cap = (uint64_t)std::min(kSortCap, std::max(16, std::atoi(o)));
+    if (const char *o = std::getenv("VSC_SORT_MAX_BITS")) max_bits = (unsigned)std::min(kSortMaxBinBits, std::max(1, std::atoi(o)));
+    for (unsigned level = 1; !segs.empty(); ++level) {
+        if (level > 48) return hipErrorUnknown;  // cannot happen: every level consumes key bits, keys are unique
+        uint64_t n_max = 0, n_all = 0;
+        for (const SortSeg &s : segs) {
+            n_max = std::max<uint64_t>(n_max, s.n_in);
+            n_all += s.n_in;
         }
+        unsigned bits = 0;
+        if (n_max > sort_cap) {
+            if (rem == 0) return hipErrorUnknown;
+            const uint64_t want = std::max<uint64_t>(1, sort_cap * 7 / 10);  // average bin: 70 % of what the finalize kernel holds
+            bits = std::min<unsigned>({std::max(1u, ceil_log2((n_max + want - 1) / want)), max_bits, rem});
+            while (bits > 1 && ((uint64_t)segs.size() << bits) > (1ull << 22)) --bits;  // bounded bin tables
+        }
+        const size_t n_segs = segs.size();
+        std::vector<uint32_t> tile0(n_segs + 1, 0);
+        uint64_t tiles = 0;
+        for (size_t i = 0; i < n_segs; ++i) {
+            tile0[i] = (uint32_t)tiles;
+            tiles += (segs[i].n_in + kSortTile - 1) / kSortTile;
+        }
+        if (tiles >= (1ull << 31)) return hipErrorInvalidValue;
+        tile0[n_segs] = (uint32_t)tiles;
+        const size_t seg_bytes = (n_segs * sizeof(SortSeg) + 255) / 256 * 256;
+        VSC_TRY(ctx->sort_segs.ensure(seg_bytes + tile0.size() * sizeof(uint32_t)));
+        SortSeg *d_segs = (SortSeg *)ctx->sort_segs.p;
+        uint32_t *d_tile0 = (uint32_t *)((char *)ctx->sort_segs.p + seg_bytes);
+        VSC_TRY(hipMemcpyAsync(d_segs, segs.data(), n_segs * sizeof(SortSeg), hipMemcpyHostToDevice, st));
+        VSC_TRY(hipMemcpyAsync(d_tile0, tile0.data(), tile0.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        const size_t n_bins = n_segs << bits;
+        VSC_TRY(ctx->sort_over.ensure(256 + n_bins * sizeof(SortSeg)));
+        uint32_t *d_n_over = (uint32_t *)ctx->sort_over.p;
+        VSC_TRY(hipMemsetAsync(d_n_over, 0, sizeof(uint32_t), st));
+        FinArgs f{};
+        f.segs = d_segs;
+        f.n_segs = (uint32_t)n_segs;
+        f.src = src;
+        if (bits) {
+            VSC_TRY(ctx->sort_tabs.ensure(3 * n_bins * sizeof(uint32_t)));
+            SortArgs a{};
+            a.segs = d_segs;
+            a.seg_tile0 = d_tile0;
+            a.n_segs = (uint32_t)n_segs;
+            a.n_tiles = (uint32_t)tiles;
+            a.in = src;
+            a.out = other;
+            a.hist = (uint32_t *)ctx->sort_tabs.p;
+            a.cursor = a.hist + n_bins;
+            a.bin_start = a.cursor + n_bins;
+            a.bin_bits = bits;
+            a.bin_shift = kRecPosShift + rem - bits;
+            VSC_TRY(hipMemsetAsync(a.hist, 0, n_bins * sizeof(uint32_t), st));
+            VSC_TRY(launch_bin_hist(a, st));
+            VSC_TRY(launch_bin_scan(a, st));
+            VSC_TRY(launch_bin_partition(a, st));
+            rem -= bits;
+            f.src = other;
+            f.hist = a.hist;
+            f.bin_start = a.bin_start;
+            f.bin_bits = bits;
+            if (info) {
+                if (info->levels == 0) info->bin_bits = bits;
+                info->levels++;
+                info->bytes += 24 * n_all;  // histogram read, partition read + write
+            }
+        }
+        if (!sorted_marked && ev_sorted) {
+            VSC_TRY(hipEventRecord(ev_sorted, st));
+            sorted_marked = true;
+        }
+        f.sub_bits = std::min<unsigned>(kSortSubBits, rem);
+        f.sub_shift = kRecPosShift + rem - f.sub_bits;
+        f.low_bits = rem - f.sub_bits;
+        f.over = (SortSeg *)((char *)ctx->sort_over.p + 256);
+        f.over_cap = (uint32_t)std::min<size_t>(n_bins, 0xFFFFFFFFu);
+        f.n_over = d_n_over;
+        f.cap = (uint32_t)sort_cap;
+        f.contig_off = genome->d_contig_off;
+        f.n_contigs = genome->n_contigs;
+        f.out = out;
+        VSC_TRY(launch_bin_finalize(f, st));
+        if (info) info->bytes += 24 * n_all;  // finalize: 8-byte read, 16-byte write
+        if (!bits) break;  // every segment fitted: nothing can come back
+        uint32_t n_over = 0;
+        VSC_TRY(hipMemcpyAsync(&n_over, d_n_over, sizeof n_over, hipMemcpyDeviceToHost, st));
+        VSC_TRY(hipStreamSynchronize(st));
+        if (n_over == 0) break;
+        segs.resize(n_over);
+        VSC_TRY(hipMemcpyAsync(segs.data(), f.over, (size_t)n_over * sizeof(SortSeg), hipMemcpyDeviceToHost, st));
+        VSC_TRY(hipStreamSynchronize(st));
+        std::swap(src, other);  // the listed bins are spans of the buffer this level wrote
     }
-    t.algorithm = (uint32_t)algo;
-    HostTimer ht;
+    return hipSuccess;
+}
 
+// Room for `n` more records behind the `used` records a result already holds (multi-pass searches grow
+// their result; `projected` = expected final size, allocated at once when the buffer has to grow).
+hipError_t result_room(vsc_ctx *ctx, vsc_hits *hits, uint64_t used, uint64_t n, uint64_t projected)
+{
+    const uint64_t need = used + n;
+    if (hits->storage.p && hits->storage.cap >= need * sizeof(vsc_hit)) return hipSuccess;
+    if (used == 0) {
+        if (hits->storage.p) {
+            ctx->spare_records.push_back(hits->storage);
+            hits->storage = DeviceBuf{};
+        }
+        VSC_TRY(take_records(ctx, hits, std::max(need, projected)));
+        return hipSuccess;
+    }
+    DeviceBuf bigger;
+    VSC_TRY(bigger.ensure(std::max(need, projected) * sizeof(vsc_hit)));
+    hipError_t e = hipMemcpyAsync(bigger.p, hits->storage.p, used * sizeof(vsc_hit), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        bigger.release();
+        return e;
+    }
+    hits->storage.release();
+    hits->storage = bigger;
+    hits->d_records = (vsc_hit *)bigger.p;
+    return hipSuccess;
+}
+
+struct PassResult {
+    uint64_t n = 0;  // records this pass appended to the result
+};
+
+// One search pass: reads guides[0 .. n_guides) (n_guides <= kMaxPassReads), reported as read indices
+// guide_base + i, appended to `hits` behind the `used` records it already holds.  Timings are ADDED to t.
+int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides, uint32_t guide_base,
+                const vsc_search_params *params, int algo, vsc_hits *hits, uint64_t used, uint64_t projected, vsc_timing &t,
+                PassResult *res)
+{
+#define VSC_HIP_H(call)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) return fail(ctx, e_ == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, #call, e_); \
+    } while (0)
+    HostTimer ht;
     // reads as (hi, lo) plane pairs, padded to the unroll factor with reads that can never match
     const uint32_t n_pad = (n_guides + kGuideUnroll - 1) / kGuideUnroll * kGuideUnroll;
     std::vector<uint32_t> gp((size_t)(n_pad + kGuideUnroll) * 2, 0xFFFFFFFFu);  // + one prefetch group
@@ -669,14 +743,14 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     VSC_HIP_H(hipEventRecord(ctx->ev[0], ctx->stream));
     VSC_HIP_H(hipMemcpyAsync(ctx->guides.p, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 
+    const double own_bases = (double)genome->n_tiles * kTileBases;
     const double sites_est = genome->sites ? (double)genome->sites : own_bases / 4;
     uint64_t cap = (uint64_t)(1.5 * sites_est * n_guides * hit_probability(params->max_mismatches)) + (1u << 20);
     unsigned long long cnt[kCntPart + 4 * kParts] = {};
+    const int n_parts = (int)((n_guides + kRegionReads - 1) / kRegionReads);  // output regions of 128 reads
 
     ScanArgs a{};
     SeedArgs sa{};
-    int n_parts = 0;             // > 0: sliced kernel, hits in n_parts output regions of part_cap records each
-    unsigned part_shift = 31;    // region of a hit = read index >> part_shift
     uint64_t part_cap = 0;
     int n_groups = 1;
     if (algo == VSC_ALGO_SCAN) {
@@ -687,7 +761,7 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         a.max_mm = params->max_mismatches;
         a.k_half = params->max_mismatches / 2;  // bidir_mapping.cpp:129-146
         n_groups = scan_groups(ctx, a.n_tiles);
-        t.genome_bytes = (uint64_t)genome->n_tiles * kTileWords * 3 * sizeof(uint32_t);
+        t.genome_bytes += (uint64_t)genome->n_tiles * kTileWords * 3 * sizeof(uint32_t);
         VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
     } else {
         // ---- per-bucket read lists: neighbourhood enumeration -> sort by bucket -> padded lists ------
@@ -695,35 +769,25 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         const uint32_t n_nbr = k_seg == 0 ? 1u : (k_seg == 1 ? 22u : 211u);
         const uint64_t n_pairs = (uint64_t)n_guides * kSegments * n_nbr;
         const uint64_t list_cap = n_pairs + (uint64_t)kBuckets * (kGuideUnroll - 1) + 2 * kGuideUnroll;
-        // hit tokens carry the read index in kTokLaneShift bits (sliced kernel), list entries in kListDistShift bits
-        if (list_cap >= (1ull << 32) - (1u << 20) || n_guides >= (genome->d_ix_vert ? (1u << kTokLaneShift) : (1u << kListDistShift)))
-            return cleanup(fail(ctx, VSC_ERR_RANGE, "vsc_search: too many reads for one seeded pass (split the read set)"));
         size_t temp_bytes = 0;
         VSC_HIP_H(sort32_temp_bytes(n_pairs, 16, &temp_bytes));
         VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
         for (DeviceBuf *b : {&ctx->seed_k1, &ctx->seed_k2, &ctx->seed_v1, &ctx->seed_v2}) VSC_HIP_H(b->ensure(n_pairs * sizeof(uint32_t)));
         VSC_HIP_H(ctx->seed_off.ensure((kBuckets + 1) * sizeof(uint32_t)));
         VSC_HIP_H(ctx->seed_poff.ensure((kBuckets + 1) * sizeof(uint32_t)));
-        VSC_HIP_H(ctx->seed_lplanes.ensure(list_cap * sizeof(uint2)));
-        VSC_HIP_H(ctx->seed_lgid.ensure(list_cap * sizeof(uint32_t)));
         VSC_HIP_H(ctx->seed_lrest.ensure(list_cap * sizeof(uint4)));
-        VSC_HIP_H(hipMemsetAsync(ctx->seed_lplanes.p, 0xFF, list_cap * sizeof(uint2), ctx->stream));  // padding never matches
-        VSC_HIP_H(hipMemsetAsync(ctx->seed_lrest.p, 0xFF, list_cap * sizeof(uint4), ctx->stream));    // y = ~0: skipped
+        VSC_HIP_H(hipMemsetAsync(ctx->seed_lrest.p, 0xFF, list_cap * sizeof(uint4), ctx->stream));  // padding: y = ~0, skipped
         VSC_HIP_H(launch_seed_enum((const uint2 *)ctx->guides.p, n_guides, n_nbr, (uint32_t *)ctx->seed_k1.p,
                                    (uint32_t *)ctx->seed_v1.p, ctx->stream));
         VSC_HIP_H(launch_sort32(ctx->sort_temp.p, temp_bytes, (const uint32_t *)ctx->seed_k1.p, (uint32_t *)ctx->seed_k2.p,
                                 (const uint32_t *)ctx->seed_v1.p, (uint32_t *)ctx->seed_v2.p, n_pairs, 16, ctx->stream));
         VSC_HIP_H(launch_seed_lists((const uint32_t *)ctx->seed_k2.p, (const uint32_t *)ctx->seed_v2.p, n_pairs,
                                     (uint32_t *)ctx->seed_off.p, (uint32_t *)ctx->seed_poff.p, (const uint2 *)ctx->guides.p,
-                                    (uint2 *)ctx->seed_lplanes.p, (uint32_t *)ctx->seed_lgid.p, (uint4 *)ctx->seed_lrest.p, ctx->stream));
+                                    (uint4 *)ctx->seed_lrest.p, ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
-        sa.planes = genome->d_ix_planes;
-        sa.pos = genome->d_ix_pos;
         sa.bucket_start = genome->d_ix_bucket_start;
         sa.chunk_tab = genome->d_ix_chunk_tab;
         sa.n_chunks = genome->ix_chunks;
-        sa.list_planes = (const uint4 *)ctx->seed_lplanes.p;
-        sa.list_gid = (const uint32_t *)ctx->seed_lgid.p;
         sa.vert = genome->d_ix_vert;
         sa.list_rest = (const uint4 *)ctx->seed_lrest.p;
         sa.sites = genome->d_ix_sites;
@@ -735,70 +799,40 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         sa.contig_end = genome->d_contig_end;
         sa.n_contigs = genome->n_contigs;
         sa.counters = (unsigned long long *)ctx->counters.p;
-        uint32_t groups_per_cu = genome->d_ix_vert ? 4 : 5;  // resident groups per CU (registers / LDS of the kernel)
+        uint32_t groups_per_cu = 4;  // resident groups per CU (registers / LDS of the kernel)
         if (const char *o = std::getenv("VSC_SEED_GROUPS_PER_CU")) groups_per_cu = (uint32_t)std::max(1, std::atoi(o));
         const uint32_t n_waves_max = (uint32_t)ctx->n_cus * groups_per_cu * kWavesPerGroup;
-        const uint32_t grab = genome->d_ix_vert ? kSlicedGrab : kSeedGrab;
-        const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, (sa.n_chunks + grab - 1) / grab));
+        const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, (sa.n_chunks + kSlicedGrab - 1) / kSlicedGrab));
         n_groups = (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
-        // block of records a wave reserves per atomic: large when many hits are expected, small otherwise
-        // (the unused tail of every wave's last block is sorted along as sentinels)
-        const uint64_t per_wave = cap / ((uint64_t)n_groups * kWavesPerGroup * 8);
-        sa.reserve = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(kSeedHitCap, per_wave / kWave * kWave));
-        if (genome->d_ix_vert) {
-            // output regions by read range: sorted and finalized concurrently below.  Many hits (long read
-            // lists): regions of `region_reads` reads (default 512: a region's sort then covers 33 + 9 - 18 = 24 key
-            // bits, 3 passes, with 18 bits left to finalize); a small result sorts faster in one piece.
-            unsigned gb = 1;
-            while (gb < 31 && (1ull << gb) < n_guides) ++gb;
-            part_shift = 31;
-            n_parts = 1;
-            int want_parts = (n_guides >= 64 && n_pairs >= 32ull * kBuckets) ? kParts : 1;
-            if (const char *o = std::getenv("VSC_SEED_PARTS")) want_parts = std::max(1, std::min(kParts, std::atoi(o)));
-            unsigned region_bits = 9;
-            if (const char *o = std::getenv("VSC_SEED_REGION_BITS")) region_bits = (unsigned)std::max(0, std::atoi(o));
-            if (want_parts > 1 && n_guides >= 4) {
-                part_shift = gb > region_bits ? region_bits : 0;
-                while (((n_guides - 1) >> part_shift) + 1 > (unsigned)want_parts) ++part_shift;  // at most want_parts regions
-                n_parts = (int)(((n_guides - 1) >> part_shift) + 1);
-            }
-            sa.part_shift = part_shift;
-            sa.n_parts = (uint32_t)n_parts;
-            if (n_parts > 1) sa.reserve = std::min<uint32_t>(sa.reserve, n_parts > 8 ? 256 : 1024);  // one open block per wave and region
-            if (const char *o = std::getenv("VSC_SEED_RESERVE")) sa.reserve = (uint32_t)std::atoi(o);
-            // a region gets its share of the expected hits + 15 % (read ranges differ) + the open blocks
-            part_cap = cap / n_parts + cap / n_parts / 7 + 4096 + (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
-            cap = part_cap * n_parts;
-        } else {
-            if (const char *o = std::getenv("VSC_SEED_RESERVE")) sa.reserve = (uint32_t)std::atoi(o);
-            cap += (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
-        }
+        // block of records a wave reserves per atomic and region: large when many hits are expected, small
+        // otherwise (the unused tail of every wave's last block is written as sentinels and read by the sort)
+        const uint64_t per_wave = cap / ((uint64_t)n_groups * kWavesPerGroup * 8 * n_parts);
+        sa.reserve = (uint32_t)std::min<uint64_t>(n_parts > 8 ? 256 : 1024, std::max<uint64_t>(kWave, per_wave / kWave * kWave));
+        if (const char *o = std::getenv("VSC_SEED_RESERVE"))  // experiments; a block must take the <= 64 hits of a pass
+            sa.reserve = (uint32_t)std::min(4096, std::max((int)kWave, std::atoi(o) / kWave * kWave));
+        sa.n_parts = (uint32_t)n_parts;
+        // a region gets its share of the expected hits + 15 % (read ranges differ) + the open blocks
+        part_cap = cap / n_parts + cap / n_parts / 7 + 4096 + (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
+        cap = part_cap * n_parts;
     }
 
     ht.lap("prep enqueue");
-    for (;;) {
+    for (unsigned tries = 0;; ++tries) {
+        if (algo == VSC_ALGO_SEED && part_cap >= (1ull << 32) - (1u << 20))
+            return fail(ctx, VSC_ERR_RANGE, "vsc_search: more than 2^32 hits in a block of 128 reads");
         VSC_HIP_H(ctx->keys_a.ensure(cap * sizeof(uint64_t)));
-        VSC_HIP_H(ctx->vals_a.ensure(cap * sizeof(uint32_t)));
         VSC_HIP_H(hipMemsetAsync(ctx->counters.p, 0, kCounterWords * sizeof(unsigned long long), ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[1], ctx->stream));
         if (algo == VSC_ALGO_SCAN) {
+            VSC_HIP_H(ctx->vals_a.ensure(cap * sizeof(uint32_t)));
             a.hit_keys = (uint64_t *)ctx->keys_a.p;
             a.hit_vals = (uint32_t *)ctx->vals_a.p;
             a.hit_cap = cap;
             VSC_HIP_H(launch_scan(a, n_groups, false, ctx->stream));
         } else {
-            sa.hit_keys = (uint64_t *)ctx->keys_a.p;
-            sa.hit_vals = (uint32_t *)ctx->vals_a.p;
-            sa.hit_cap = cap;
+            sa.hit_recs = (uint64_t *)ctx->keys_a.p;
             sa.part_cap = part_cap;
-            // the per-pair test beats the min-tree variant at every m measured (fewer registers, no
-            // re-derivation of hits); VSC_SEED_DENSE=0 selects the min-tree variant for experiments
-            bool dense = true;
-            if (const char *o = std::getenv("VSC_SEED_DENSE")) dense = o[0] == '1';
-            if (sa.vert)
-                VSC_HIP_H(launch_seed_sliced(sa, n_groups, ctx->stream));
-            else
-                VSC_HIP_H(launch_seed_compare(sa, n_groups, dense, ctx->stream));
+            VSC_HIP_H(launch_seed_sliced(sa, n_groups, ctx->stream));
         }
         VSC_HIP_H(hipEventRecord(ctx->ev[2], ctx->stream));
         VSC_HIP_H(hipMemcpyAsync(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
@@ -806,206 +840,223 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
         ht.lap("search kernel + sync");
         t.passes++;
         if (!cnt[kCntOverflow]) break;
-        if (t.passes >= 3) return cleanup(fail(ctx, VSC_ERR_DEVICE, "vsc_search: hit buffer overflowed repeatedly"));
-        // the counters hold the true total (SEED: records placed + records lost, + one block per wave)
-        if (n_parts > 0) {
+        if (tries >= 2) return fail(ctx, VSC_ERR_DEVICE, "vsc_search: hit buffer overflowed repeatedly");
+        // the counters hold the true totals (SEED: records placed + records lost per region, + one block per wave)
+        if (algo == VSC_ALGO_SEED) {
             uint64_t need = 0;
             for (int q = 0; q < n_parts; ++q) need = std::max<uint64_t>(need, cnt[kCntPart + 4 * q] + cnt[kCntPart + 4 * q + 2]);
             part_cap = need + (need >> 6) + 4096 + (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
             cap = part_cap * n_parts;
-            continue;
-        }
-        cap = cnt[kCntHits] + cnt[kCntLost];
-        cap += (cap >> 6) + 4096 + (algo == VSC_ALGO_SEED ? (uint64_t)n_groups * kWavesPerGroup * sa.reserve : 0);
-    }
-    // SEED: counters[kCntHits] counts reserved records, kCntPad of them are sentinels (key = all ones)
-    // that the sort moves behind the n real hits
-    uint64_t n_sort = cnt[kCntHits];
-    uint64_t n = n_sort - cnt[kCntPad];
-    uint64_t part_sort[kParts] = {}, part_n[kParts] = {};
-    if (n_parts > 0) {
-        n_sort = n = 0;
-        for (int q = 0; q < n_parts; ++q) {
-            part_sort[q] = cnt[kCntPart + 4 * q];
-            part_n[q] = part_sort[q] - cnt[kCntPart + 4 * q + 1];
-            n_sort += part_sort[q];
-            n += part_n[q];
+        } else {
+            cap = cnt[kCntHits] + (cnt[kCntHits] >> 6) + 4096;
         }
     }
+    float ms = 0;
+    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[7]));
+    t.prep_ms += ms;
+    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+    t.scan_ms += ms;
+
+    // ---- the segments of the sort: one per region ----------------------------------------------------
+    std::vector<SortSeg> segs;
+    uint64_t n = 0;
+    uint64_t *src = (uint64_t *)ctx->keys_a.p, *other = nullptr;
+    SortInfo info;
     if (algo == VSC_ALGO_SCAN) {
         const_cast<vsc_genome *>(genome)->sites = cnt[kCntSites];
         t.sites = cnt[kCntSites];
-        t.pairs = cnt[kCntSites] * n_guides;
+        t.pairs += cnt[kCntSites] * n_guides;
+        n = cnt[kCntHits];
+        if (n >= (1ull << 32)) return fail(ctx, VSC_ERR_RANGE, "vsc_search: more than 2^32 hits in one scan pass (split the read set)");
+        if (n > 0) {
+            // level 0: (key, value) pairs -> packed records, partitioned by region
+            VSC_HIP_H(ctx->keys_b.ensure(cap * sizeof(uint64_t)));
+            const unsigned bits0 = ceil_log2((uint64_t)n_parts);
+            const size_t n_bins = (size_t)1 << bits0;
+            VSC_HIP_H(ctx->sort_segs.ensure(512));
+            VSC_HIP_H(ctx->sort_tabs.ensure(3 * n_bins * sizeof(uint32_t)));
+            SortSeg s0{0, 0, 0, (uint32_t)n, guide_base};
+            const uint32_t tile0[2] = {0u, (uint32_t)((n + kSortTile - 1) / kSortTile)};
+            VSC_HIP_H(hipMemcpyAsync(ctx->sort_segs.p, &s0, sizeof s0, hipMemcpyHostToDevice, ctx->stream));
+            VSC_HIP_H(hipMemcpyAsync((char *)ctx->sort_segs.p + 256, tile0, sizeof tile0, hipMemcpyHostToDevice, ctx->stream));
+            SortArgs l0{};
+            l0.segs = (const SortSeg *)ctx->sort_segs.p;
+            l0.seg_tile0 = (const uint32_t *)((char *)ctx->sort_segs.p + 256);
+            l0.n_segs = 1;
+            l0.n_tiles = tile0[1];
+            l0.pair_keys = (const uint64_t *)ctx->keys_a.p;
+            l0.pair_vals = (const uint32_t *)ctx->vals_a.p;
+            l0.out = (uint64_t *)ctx->keys_b.p;
+            l0.hist = (uint32_t *)ctx->sort_tabs.p;
+            l0.cursor = l0.hist + n_bins;
+            l0.bin_start = l0.cursor + n_bins;
+            l0.bin_bits = bits0;
+            l0.bin_shift = kRecKeyBits;  // key >> 40 = read index >> 7 = region
+            VSC_HIP_H(hipMemsetAsync(l0.hist, 0, n_bins * sizeof(uint32_t), ctx->stream));
+            VSC_HIP_H(launch_bin_hist(l0, ctx->stream));
+            VSC_HIP_H(launch_bin_scan(l0, ctx->stream));
+            VSC_HIP_H(launch_bin_partition(l0, ctx->stream));
+            std::vector<uint32_t> tabs(3 * n_bins);
+            VSC_HIP_H(hipMemcpyAsync(tabs.data(), l0.hist, tabs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            VSC_HIP_H(hipStreamSynchronize(ctx->stream));
+            for (int q = 0; q < n_parts; ++q) {
+                const uint32_t count = tabs[q], start = tabs[2 * n_bins + q];
+                if (count) segs.push_back(SortSeg{start, start, used + start, count, guide_base + (uint32_t)q * kRegionReads});
+            }
+            src = (uint64_t *)ctx->keys_b.p;
+            other = (uint64_t *)ctx->keys_a.p;
+            info.bytes += 12 * n + 20 * n;  // histogram read; partition read 12, write 8
+        }
     } else {
         t.sites = genome->index_sites;
-        t.pairs = cnt[kCntSites];
-        // sites visited: 4 bytes each bit-sliced (16 compared positions x 2 planes / 32 sites per word), 8 as records
-        t.genome_bytes = cnt[kCntVisited] * (genome->d_ix_vert ? sizeof(uint32_t) : sizeof(uint2));
+        t.pairs += cnt[kCntSites];
+        t.genome_bytes += cnt[kCntVisited] * sizeof(uint32_t);  // sites visited, 4 bytes each bit-sliced
+        for (int q = 0; q < n_parts; ++q) {
+            const uint64_t placed = cnt[kCntPart + 4 * q], real = placed - cnt[kCntPart + 4 * q + 1];
+            if (placed) segs.push_back(SortSeg{(uint64_t)q * part_cap, (uint64_t)q * part_cap, used + n, (uint32_t)placed,
+                                               guide_base + (uint32_t)q * kRegionReads});
+            n += real;
+        }
+        if (n > 0) {
+            VSC_HIP_H(ctx->keys_b.ensure(cap * sizeof(uint64_t)));
+            other = (uint64_t *)ctx->keys_b.p;
+        }
     }
-    t.hits = n;
-
+    t.hits += n;
     if (n > 0) {
-        unsigned guide_bits = 1;
-        while (guide_bits < 31 && (1ull << guide_bits) < n_guides) ++guide_bits;
-        // sentinels (all ones) must sort behind every real key: one more bit when the all-ones guide id is in use
-        unsigned end_bit = 33 + guide_bits + ((n_sort != n && n_guides == (1ull << guide_bits)) ? 1 : 0);
-        if (n_parts > 1) {
-            // inside a region only the low part_shift bits of the read index vary.  A real key equals a sentinel in
-            // all sorted bits only with every sorted position bit set, i.e. within 2^24 bases of the 4 Gbase
-            // limit: such a genome gets one more bit
-            const bool near_limit = ((uint64_t)genome->first_word + genome->own_words) * 32 + (1ull << 24) >= (1ull << 32);
-            end_bit = 33 + part_shift + (near_limit ? 1 : 0);
-        }
-        // The sort costs one pass over all pairs per 8 key bits.  Low position bits are left out and
-        // finalize_kernel orders the records that agree in the rest; if it meets a group too large for that
-        // (> 257 hits of one read and strand within 2^low_bits bases), the sort is repeated with at most 8 bits
-        // left out, which always works.
-        auto low_bits_for = [&](unsigned max_low) {
-            const unsigned passes = (end_bit - std::min(end_bit, max_low) + 7) / 8;
-            return end_bit > 8 * passes ? end_bit - 8 * passes : 0u;
-        };
-        // how many bits can go: as many as keep the groups small - a group is one read's hits on one strand
-        // inside 2^low bases, n / (2 reads 2^(32 - low)) records on average.  Aim at <= 2 records, or at <= 8
-        // when that saves a pass (16 bits for 1.6e9 hits of 10 000 reads in one region, 18 in regions of 512
-        // reads; up to 24 for small results)
-        auto avg_group = [&](unsigned low) { return (double)n / (2.0 * n_guides * (double)(1ull << (32 - low))); };
-        unsigned max_low = 16;
-        while (max_low < 24 && avg_group(max_low + 1) <= 2.0) ++max_low;
-        unsigned begin_bit = low_bits_for(max_low);
-        for (unsigned more = max_low + 1; more <= 24 && avg_group(more) <= 8.0; ++more)
-            if ((end_bit - low_bits_for(more) + 7) / 8 < (end_bit - begin_bit + 7) / 8) {
-                begin_bit = low_bits_for(more);
-                break;
-            }
-        bool forced = false;
-        if (const char *o = std::getenv("VSC_SORT_LOW_BITS")) {
-            begin_bit = std::min(24u, (unsigned)std::atoi(o));
-            forced = true;
-        }
-        const uint64_t sorted_cap = n_parts > 0 ? cap : n_sort;
-        VSC_HIP_H(ctx->keys_b.ensure(sorted_cap * sizeof(uint64_t)));
-        VSC_HIP_H(ctx->vals_b.ensure(sorted_cap * sizeof(uint32_t)));
-        ht.lap("sort buffers ensure");
-        VSC_HIP_H(take_records(ctx, hits, n));
+        ht.lap("sort buffers");
+        VSC_HIP_H(result_room(ctx, hits, used, n, projected));
         ht.lap("record storage");
-        if (n_parts > 0) {
-            // one sort + finalize per output region, the regions taking turns on kSortStreams streams: the
-            // passes of one sort leave the memory system idle between kernels and at their tails, and
-            // finalize_kernel is not bandwidth-bound - interleaved they finish in less time than one after
-            // the other.  A region in which finalize meets a group too large to rank (flag per region:
-            // counters[kCntPart + 4 q + 3]) is sorted again, alone, with at most 8 bits left out.
-            uint64_t region_out[kParts];
-            uint64_t out_off = 0;
-            for (int q = 0; q < n_parts; ++q) {
-                region_out[q] = out_off;
-                out_off += part_n[q];
-            }
-            bool redo[kParts];
-            for (int q = 0; q < n_parts; ++q) redo[q] = true;
-            for (unsigned low = begin_bit;;) {
-                size_t temp_bytes = 0;
-                for (int q = 0; q < n_parts; ++q) {
-                    size_t tb = 0;
-                    VSC_HIP_H(sort_temp_bytes(std::max<uint64_t>(part_sort[q], 1), low, end_bit, &tb));
-                    temp_bytes = std::max(temp_bytes, (tb + 255) / 256 * 256);
-                }
-                VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes * kSortStreams, 16)));
-                int turn = 0;
-                for (int q = 0; q < n_parts; ++q) {
-                    if (!redo[q]) continue;
-                    const int lane = turn++ % kSortStreams;  // a stream works through its regions in order
-                    hipStream_t st = lane == 0 ? ctx->stream : ctx->aux[lane - 1];
-                    const uint64_t off = (uint64_t)q * part_cap;
-                    if (part_sort[q])
-                        VSC_HIP_H(launch_sort((char *)ctx->sort_temp.p + temp_bytes * lane, temp_bytes,
-                                              (const uint64_t *)ctx->keys_a.p + off, (uint64_t *)ctx->keys_b.p + off,
-                                              (const uint32_t *)ctx->vals_a.p + off, (uint32_t *)ctx->vals_b.p + off, part_sort[q],
-                                              low, end_bit, st));
-                    if (low == begin_bit) VSC_HIP_H(hipEventRecord(ctx->sorted_ev[q], st));
-                    FinalizeArgs f{};
-                    f.keys = (const uint64_t *)ctx->keys_b.p + off;
-                    f.vals = (const uint32_t *)ctx->vals_b.p + off;
-                    f.n = part_n[q];
-                    f.low_bits = low;
-                    f.overflow = (unsigned long long *)ctx->counters.p + kCntPart + 4 * q + 3;
-                    f.contig_off = genome->d_contig_off;
-                    f.n_contigs = genome->n_contigs;
-                    f.out = hits->d_records + region_out[q];
-                    VSC_HIP_H(launch_finalize(f, st));
-                }
-                for (int lane = 1; lane < kSortStreams; ++lane) {
-                    VSC_HIP_H(hipEventRecord(ctx->done_ev[lane], ctx->aux[lane - 1]));
-                    VSC_HIP_H(hipStreamWaitEvent(ctx->stream, ctx->done_ev[lane], 0));
-                }
-                if (low <= 8) break;  // groups of at most 256 records: always rankable
-                VSC_HIP_H(hipMemcpyAsync(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
-                VSC_HIP_H(hipStreamSynchronize(ctx->stream));
-                bool any = false;
-                for (int q = 0; q < n_parts; ++q) any |= (redo[q] = cnt[kCntPart + 4 * q + 3] != 0);
-                if (!any) break;
-                if (forced) return cleanup(fail(ctx, VSC_ERR_DEVICE, "vsc_search: VSC_SORT_LOW_BITS leaves groups too large to order"));
-                low = low_bits_for(8);
-            }
-        }
-        for (; n_parts == 0;) {
-            size_t temp_bytes = 0;
-            VSC_HIP_H(sort_temp_bytes(n_sort, begin_bit, end_bit, &temp_bytes));
-            VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
-            VSC_HIP_H(launch_sort(ctx->sort_temp.p, temp_bytes, (const uint64_t *)ctx->keys_a.p, (uint64_t *)ctx->keys_b.p,
-                                  (const uint32_t *)ctx->vals_a.p, (uint32_t *)ctx->vals_b.p, n_sort, begin_bit, end_bit, ctx->stream));
-            VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
-            FinalizeArgs f{};
-            f.keys = (const uint64_t *)ctx->keys_b.p;
-            f.vals = (const uint32_t *)ctx->vals_b.p;
-            f.n = n;
-            f.low_bits = begin_bit;
-            f.overflow = (unsigned long long *)ctx->counters.p + kCntGroups;
-            f.contig_off = genome->d_contig_off;
-            f.n_contigs = genome->n_contigs;
-            f.out = hits->d_records;
-            VSC_HIP_H(launch_finalize(f, ctx->stream));
-            if (begin_bit <= 8) break;  // groups of at most 256 records: always rankable
-            unsigned long long too_large = 0;
-            VSC_HIP_H(hipMemcpyAsync(&too_large, f.overflow, sizeof too_large, hipMemcpyDeviceToHost, ctx->stream));
-            VSC_HIP_H(hipStreamSynchronize(ctx->stream));
-            if (!too_large) break;
-            if (forced) return cleanup(fail(ctx, VSC_ERR_DEVICE, "vsc_search: VSC_SORT_LOW_BITS leaves groups too large to order"));
-            begin_bit = low_bits_for(8);
-        }
+        const unsigned key_bits = 33 + ceil_log2(std::min<uint32_t>(n_guides, kRegionReads));
+        VSC_HIP_H(bin_sort(ctx, genome, std::move(segs), src, other, key_bits, hits->d_records, ctx->ev[3], &info));
     } else {
         VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
     }
     VSC_HIP_H(hipEventRecord(ctx->ev[4], ctx->stream));
     VSC_HIP_H(hipStreamSynchronize(ctx->stream));
     ht.lap("sort + finalize + sync");
-    float ms = 0;
-    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[7]));
-    t.prep_ms = ms;
-    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
-    t.scan_ms = ms;
-    if (n_parts > 0 && n > 0) {
-        // regions overlap: "sort" = until the last region is sorted, "finalize" = what remains after that
-        float last_sorted = 0, total = 0;
-        for (int q = 0; q < n_parts; ++q) {
-            VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[2], ctx->sorted_ev[q]));
-            last_sorted = std::max(last_sorted, ms);
-        }
-        VSC_HIP_H(hipEventElapsedTime(&total, ctx->ev[2], ctx->ev[4]));
-        t.sort_ms = last_sorted;
-        t.finalize_ms = std::max(0.0f, total - last_sorted);
-    } else {
-        VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
-        t.sort_ms = ms;
-        VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
-        t.finalize_ms = ms;
-    }
+    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    t.sort_ms += ms;
+    VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+    t.finalize_ms += ms;
     VSC_HIP_H(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]));
-    t.total_ms = ms;
-    ctx->timing = t;
-    hits->n = n;
-    *out = hits;
+    t.total_ms += ms;
+    t.sort_levels = std::max(t.sort_levels, info.levels);
+    t.sort_bin_bits = std::max(t.sort_bin_bits, info.bin_bits);
+    t.sort_bytes += info.bytes;
+    t.read_passes++;
+    res->n = n;
     return VSC_OK;
 #undef VSC_HIP_H
+}
+
+// common front end of vsc_search / vsc_search_stream: argument checks, choice of the algorithm, index
+int search_setup(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
+                 const vsc_search_params *params, const char *who, int *algo_out, vsc_timing *t)
+{
+    ctx->err.clear();
+    if (!genome || !params || (n_guides && !guides)) return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": null argument").c_str());
+    if (genome->ctx != ctx) return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": genome belongs to another context").c_str());
+    if (params->max_mismatches > VSC_MAX_MISMATCHES)  // read_mapping/bidir_mapping.cpp:234-238
+        return fail(ctx, VSC_ERR_INVALID, "Maximum number of mismatches must lie between 0 and 8.");
+    if (params->algorithm > VSC_ALGO_SEED) return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": unknown algorithm").c_str());
+    if (n_guides >= (1u << 31)) return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": too many reads").c_str());
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    *t = vsc_timing{};
+    t->index_ms = ctx->timing.index_ms;
+    const double own_bases = (double)genome->n_tiles * kTileBases;
+    int algo = params->algorithm;
+    if (algo == VSC_ALGO_AUTO) {
+        // the index costs about as much as scanning a few hundred reads; it pays for itself when it is
+        // already there or when the search is big enough
+        const bool worth_building = (double)n_guides * own_bases >= 2.0e10;
+        algo = (index_matches(genome, params) || worth_building) ? VSC_ALGO_SEED : VSC_ALGO_SCAN;
+    }
+    if (n_guides && algo == VSC_ALGO_SEED && !index_matches(genome, params)) {
+        std::string why;
+        hipError_t e = build_index(ctx, const_cast<vsc_genome *>(genome), params, &why);
+        if (e != hipSuccess) {
+            if (params->algorithm == VSC_ALGO_SEED || why.empty())
+                return fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE,
+                            why.empty() ? "vsc_search: building the seed index" : why.c_str(), why.empty() ? e : hipSuccess);
+            algo = VSC_ALGO_SCAN;  // auto mode: a genome too large for the index is still searchable
+        } else {
+            t->index_ms = genome->index_ms;
+        }
+    }
+    t->algorithm = (uint32_t)algo;
+    *algo_out = algo;
+    return VSC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
+               const vsc_search_params *params, vsc_hits **out)
+{
+    if (!ctx || !out) return VSC_ERR_INVALID;
+    *out = nullptr;
+    vsc_timing t{};
+    int algo = 0;
+    const int rc = search_setup(ctx, genome, guides, n_guides, params, "vsc_search", &algo, &t);
+    if (rc != VSC_OK) return rc;
+    vsc_hits *hits = new (std::nothrow) vsc_hits();
+    if (!hits) return fail(ctx, VSC_ERR_NOMEM, "vsc_search: out of host memory");
+    hits->ctx = ctx;
+    // a pass takes at most kMaxPassReads reads (128 output regions of 128 reads); larger sets are searched
+    // pass by pass - the read index is the major sort key, so the passes' results simply follow each other
+    uint64_t used = 0;
+    for (uint32_t first = 0; first < n_guides; first += kMaxPassReads) {
+        const uint32_t count = std::min<uint32_t>(kMaxPassReads, n_guides - first);
+        const uint64_t projected = first ? (uint64_t)((double)used / first * n_guides * 1.02) + 4096 : 0;
+        PassResult r;
+        const int prc = search_pass(ctx, genome, guides + first, count, first, params, algo, hits, used, projected, t, &r);
+        if (prc != VSC_OK) {
+            vsc_hits_free(hits);
+            return prc;
+        }
+        used += r.n;
+    }
+    hits->n = used;
+    if (used == 0) hits->host_valid = true;
+    ctx->timing = t;
+    *out = hits;
+    return VSC_OK;
+}
+
+int vsc_search_stream(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
+                      const vsc_search_params *params, uint32_t batch_reads, vsc_batch_fn on_batch, void *user)
+{
+    if (!ctx) return VSC_ERR_INVALID;
+    vsc_timing t{};
+    int algo = 0;
+    const int rc = search_setup(ctx, genome, guides, n_guides, params, "vsc_search_stream", &algo, &t);
+    if (rc != VSC_OK) return rc;
+    if (!on_batch) return fail(ctx, VSC_ERR_INVALID, "vsc_search_stream: null callback");
+    if (batch_reads == 0 || batch_reads > (uint32_t)kMaxPassReads) batch_reads = kMaxPassReads;
+    for (uint32_t first = 0; first < n_guides; first += batch_reads) {
+        const uint32_t count = std::min<uint32_t>(batch_reads, n_guides - first);
+        vsc_hits *hits = new (std::nothrow) vsc_hits();
+        if (!hits) return fail(ctx, VSC_ERR_NOMEM, "vsc_search_stream: out of host memory");
+        hits->ctx = ctx;
+        PassResult r;
+        int prc = search_pass(ctx, genome, guides + first, count, first, params, algo, hits, 0, 0, t, &r);
+        if (prc == VSC_OK) {
+            hits->n = r.n;
+            if (r.n == 0) hits->host_valid = true;
+            ctx->timing = t;
+            ctx->timing.score_ms = 0;
+            prc = on_batch(user, hits, first, count);
+            t.score_ms += ctx->timing.score_ms;  // what the callback's scoring calls measured
+            if (prc != VSC_OK && ctx->err.empty()) ctx->err = "vsc_search_stream: the batch callback failed";
+        }
+        vsc_hits_free(hits);
+        if (prc != VSC_OK) return prc;
+    }
+    ctx->timing = t;
+    return VSC_OK;
 }
 
 uint64_t vsc_hits_count(const vsc_hits *hits) { return hits ? hits->n : 0; }
@@ -1077,7 +1128,7 @@ int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, con
     };
     // small work arrays reuse the search scratch buffers
     step(ctx->keys_b.ensure((nb + n_shards + 1) * sizeof(uint64_t)));
-    step(ctx->vals_b.ensure(((uint64_t)K + 1) * sizeof(uint64_t)));
+    step(ctx->vals_a.ensure(((uint64_t)K + 1) * sizeof(uint64_t)));
     step(take_records(ctx, hits, n));
     const vsc_hit *records_dev = (const vsc_hit *)records;
     if (!records_on_device) {
@@ -1092,7 +1143,7 @@ int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, con
         step(hipMemcpyAsync(shard_off_dev, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     step(hipEventRecord(ctx->ev[0], ctx->stream));
     if (e == hipSuccess)
-        step(launch_merge(records_dev, shard_off_dev, n_shards, K, bound, (uint64_t *)ctx->vals_b.p, hits->d_records, ctx->stream));
+        step(launch_merge(records_dev, shard_off_dev, n_shards, K, bound, (uint64_t *)ctx->vals_a.p, hits->d_records, ctx->stream));
     step(hipEventRecord(ctx->ev[1], ctx->stream));
     step(hipStreamSynchronize(ctx->stream));
     if (e != hipSuccess) {

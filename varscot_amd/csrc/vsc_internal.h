@@ -30,8 +30,7 @@ constexpr int kSegments = 3;                    // read positions [0,7) [7,14) [
 constexpr int kSegBases = 7;
 constexpr int kBucketsPerSeg = 1 << (2 * kSegBases);  // 16384 seven-mers
 constexpr int kBuckets = kSegments * kBucketsPerSeg;
-constexpr int kSeedTokCap = 512;                // per-wave LDS buffer of pending hit tokens
-constexpr int kSeedHitCap = 256;                // per-wave LDS buffer of resolved hits
+constexpr int kSeedHitCap = 256;                // smallest block of records a wave reserves per atomic
 constexpr int kSlicedSites = 32;                // sites per lane of the bit-sliced comparison (one bit each)
 constexpr int kSlicedChunk = kWave * kSlicedSites;  // 2048 sites per wave and chunk
 constexpr int kRestBases = VSC_READ_LEN - kSegBases;  // 16 read positions outside the seed segment
@@ -41,7 +40,6 @@ constexpr int kSlicedResolve = 3;                // sliced kernel: resolve when 
                                                 // gathers of the later passes overlap the earlier ones)
 constexpr int kSlicedTokCap = (kSlicedResolve + 4) * 64;  // per-wave LDS ring of 16-byte hit tokens: a group of four reads adds <= 256
 constexpr int kSlicedGrab = 8;                  // chunks of 2048 sites per grab of the work counter (sliced kernel)
-constexpr int kSeedGrab = 16;                   // chunks (<= 512 sites of one bucket) per grab of the work counter
 
 // counters[] slots of one scan launch
 enum { kCntHits = 0, kCntChunk = 1, kCntSites = 2, kCntOverflow = 3, kCntVisited = 4, kCntPad = 5, kCntLost = 6, kCntGroups = 7, kCntSlots = 8 };
@@ -49,17 +47,41 @@ enum { kCntHits = 0, kCntChunk = 1, kCntSites = 2, kCntOverflow = 3, kCntVisited
 // bytes apart behind the counters: one device-wide cursor sustains only ~90 atomics/us
 // (MI355X_MICROARCH.md), which for 270 000 grabs is 3 ms - as long as a whole 1 000-read search.
 // The sliced kernel writes its hits into up to kParts regions by read range (region = read index >>
-// part_shift): the regions are sorted and finalized independently, on kSortStreams streams, and their
-// concatenation is the result.  Inside a region the top read-index bits are constant, so its sort
-// covers fewer key bits: regions of 512 reads turn a 47-bit key into 24 sorted bits = 3 passes.
+// kRegionBits, 128 reads): inside a region a hit is one packed 8-byte record (below), and the regions
+// are ordered independently by the bin sort of vsc_sort.hip; their concatenation is the result.
 // Per region: counters[kCntPart + 4 p + {0, 1, 2}] = records reserved, sentinels among them, records lost.
-constexpr int kParts = 32;
-constexpr int kSortStreams = 4;
+constexpr int kRegionBits = 7;
+constexpr int kRegionReads = 1 << kRegionBits;
+constexpr int kParts = 128;
+constexpr int kMaxPassReads = kParts * kRegionReads;  // reads one search pass can take (vsc_search splits larger sets)
 constexpr int kCntPart = 8;
 constexpr int kCursors = 32;
 constexpr int kCursorStride = 16;  // in 8-byte words
-constexpr int kCursorBase = 144;    // first cursor, in 8-byte words from the start of the counter buffer
+constexpr int kCursorBase = kCntPart + 4 * kParts + 8;  // first cursor, in 8-byte words from the start of the counter buffer
 constexpr int kCounterWords = kCursorBase + kCursors * kCursorStride;
+
+// ---- packed hit record (what the search kernels hand to the sort) --------------------------------------
+//   bits  0..22  mismatch mask in forward-genome window coordinates (NM is its popcount)
+//   bits 23..54  global position of the window start
+//   bit  55      strand (1 = '-')
+//   bits 56..62  read index inside its region (read & 127)
+//   bit  63      0; the all-ones word is the sentinel that pads reserved-but-unused record slots
+// Ascending order of the records of one region = the result order (read, strand, position).
+constexpr int kRecPosShift = 23;
+constexpr int kRecStrandShift = 55;
+constexpr int kRecReadShift = 56;
+constexpr int kRecKeyBits = 33 + kRegionBits;  // sort key = rec >> kRecPosShift
+constexpr uint64_t kRecSentinel = ~0ull;
+
+// ---- bin sort (vsc_sort.hip) -------------------------------------------------------------------------
+constexpr int kSortThreads = 1024;
+constexpr int kSortItems = 16;
+constexpr int kSortTile = kSortThreads * kSortItems;  // records per partition tile; also the largest bin the
+constexpr int kSortCap = kSortTile;                   // finalize kernel orders in LDS
+constexpr int kSortMaxBinBits = 11;                   // <= 2048 bins per partition level
+constexpr int kSortSubBits = 12;                      // <= 4096 sub-bins inside the finalize kernel
+constexpr int kHistTiles = 8;                         // tiles a block of the histogram kernel walks through
+constexpr int kFinalizeContigs = 1024;                // contig table entries the finalize kernel stages in LDS
 
 // Required plane bits of the two PAM letters, expanded to all-ones / all-zero words.
 struct PamMasks {
@@ -88,13 +110,44 @@ struct ScanArgs {
     uint32_t *site_x, *site_l, *site_pos;
 };
 
-struct FinalizeArgs {
-    const uint64_t *keys;
-    const uint32_t *vals;
-    uint64_t n;
-    uint32_t low_bits;           // key bits [0, low_bits) were left out of the sort (<= 16)
-    unsigned long long *overflow;  // set to 1 when a group is too large to be ranked (only possible for low_bits > 8)
-    const uint32_t *contig_off;  // ascending global start positions of all contigs
+// One segment of the bin sort: a span of packed records that is ordered independently of all others (level 1:
+// one output region of the search kernel; deeper levels: one bin that was too large for the finalize kernel).
+struct SortSeg {
+    uint64_t in_off;     // first record of the segment in the level's source buffer
+    uint64_t out_off;    // first record of the segment's span in the level's destination buffer
+    uint64_t final_off;  // index of the segment's first vsc_hit in the result
+    uint32_t n_in;       // records in the source span (level 1: sentinels included)
+    uint32_t guide_base; // read index of the region's first read
+};
+
+struct SortArgs {
+    const SortSeg *segs;
+    const uint32_t *seg_tile0;     // [n_segs + 1] first tile of every segment (tile = kSortTile records)
+    uint32_t n_segs, n_tiles;
+    const uint64_t *in;            // packed records
+    const uint64_t *pair_keys;     // level 0 only (streaming scan): guide << 33 | strand << 32 | position ...
+    const uint32_t *pair_vals;     //                                ... and NM << 23 | mask; `in` is then unused
+    uint64_t *out;
+    uint32_t *hist;                // [n_segs << bin_bits] records per bin
+    uint32_t *cursor;              // [n_segs << bin_bits] next free record of every bin (relative to the segment)
+    uint32_t *bin_start;           // [n_segs << bin_bits] first record of every bin (relative to the segment)
+    uint32_t bin_bits, bin_shift;  // bin = (record >> bin_shift) & ((1 << bin_bits) - 1)
+};
+
+struct FinArgs {
+    const SortSeg *segs;
+    uint32_t n_segs;
+    const uint64_t *src;           // the buffer the last partition level wrote (or the search kernel, if none ran)
+    const uint32_t *hist;          // bins of the last partition level; null: every segment is one bin (its source span)
+    const uint32_t *bin_start;
+    uint32_t bin_bits;
+    uint32_t sub_shift, sub_bits;  // LDS counting sort on (record >> sub_shift) & ((1 << sub_bits) - 1) ...
+    uint32_t low_bits;             // ... then ranking on the key bits below (0: none left)
+    SortSeg *over;                 // bins with more than `cap` records are listed here for another level
+    uint32_t over_cap;
+    uint32_t cap;                  // <= kSortCap (smaller in tests only)
+    uint32_t *n_over;
+    const uint32_t *contig_off;    // ascending global start positions of all contigs
     uint32_t n_contigs;
     vsc_hit *out;
 };
@@ -113,30 +166,22 @@ struct ScoreArgs {
 };
 
 struct SeedArgs {
-    const uint2 *planes;           // pair kernel: [3 S] sites (x = hi plane | strand | edge, y = lo plane), bucket-sorted per segment
-    const uint32_t *pos;           // pair kernel: [3 S] global window starts, same order
     const uint32_t *bucket_start;  // [kBuckets + 1] first site of every bucket
     const uint4 *chunk_tab;        // [n_chunks] {first site, site count, bucket, first vertical block}
     const uint32_t *vert;          // bit-sliced copies of the sites: 32 words per block of 32 sites (see seed_transpose_kernel)
-    const uint4 *list_rest;        // sliced kernel: per list entry {rest(hi) | rest(lo) << 16, read | distance << 30, hi, lo}
-    const uint4 *sites;            // sliced kernel: {hi plane | strand | edge, lo plane, position, 0} per site (replaces planes, pos)
+    const uint4 *list_rest;        // per list entry {rest(hi) | rest(lo) << 16, read | distance << 30, hi, lo}
+    const uint4 *sites;            // {hi plane | strand | edge, lo plane, position, 0} per site
     const uint2 *guides;           // (hi plane, lo plane) per read
     uint32_t n_chunks;
-    const uint4 *list_planes;      // pair kernel: padded per-bucket read lists: two reads per uint4 (hi0, lo0, hi1, lo1)
-    const uint32_t *list_gid;      // pair kernel: read index of every list entry
     const uint32_t *poff;          // [kBuckets + 1] first list entry of every bucket (multiples of kGuideUnroll)
     uint32_t max_mm, k_half, k_seg;
     const uint32_t *contig_end;
     uint32_t n_contigs;
-    uint64_t *hit_keys;
-    uint32_t *hit_vals;
-    unsigned long long hit_cap;
-    uint32_t reserve;              // records a wave reserves per atomic on counters[kCntHits]
-    uint32_t part_shift;           // sliced kernel: output region of a hit = read index >> part_shift (31: one region)
-    uint32_t n_parts;              // sliced kernel: regions in use
-    unsigned long long part_cap;   // sliced kernel: records per region; region p = [p * part_cap, (p + 1) * part_cap)
-    unsigned long long *counters;  // kCntHits (reserved records), kCntPad (sentinels among them), kCntChunk,
-                                   // kCntSites (= pairs compared), kCntVisited, kCntOverflow
+    uint64_t *hit_recs;            // out: packed records (layout above), region p = [p * part_cap, (p + 1) * part_cap)
+    uint32_t reserve;              // records a wave reserves per atomic on its region's cursor
+    uint32_t n_parts;              // regions in use (region of a hit = read index >> kRegionBits)
+    unsigned long long part_cap;   // records per region
+    unsigned long long *counters;  // kCntPart + 4 p + {0,1,2}, kCntSites (= pairs compared), kCntVisited, kCntOverflow, cursors
 };
 
 // One node of a random-forest tree, 16 bytes: a node visit is one load.
@@ -150,11 +195,11 @@ struct RfNode {
 
 // Launch wrappers implemented in vsc_kernels.hip.  They only enqueue work on `stream`.
 hipError_t launch_scan(const ScanArgs &args, int n_groups, bool extract, hipStream_t stream);
-hipError_t sort_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit, size_t *bytes);
-hipError_t launch_sort(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
-                       const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
-                       hipStream_t stream);
-hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream);
+// vsc_sort.hip
+hipError_t launch_bin_hist(const SortArgs &args, hipStream_t stream);
+hipError_t launch_bin_scan(const SortArgs &args, hipStream_t stream);
+hipError_t launch_bin_partition(const SortArgs &args, hipStream_t stream);
+hipError_t launch_bin_finalize(const FinArgs &args, hipStream_t stream);
 hipError_t launch_rf_predict(const RfNode *nodes, uint32_t n_trees, uint32_t n_nodes, const uint8_t *features,
                              const double *activity, uint64_t n, uint32_t *votes_out, hipStream_t stream);
 hipError_t launch_interleave(const uint32_t *hi, const uint32_t *lo, uint64_t n, uint2 *hl, hipStream_t stream);
@@ -168,21 +213,17 @@ hipError_t launch_sort32(void *temp, size_t temp_bytes, const uint32_t *keys_in,
 // vsc_seed.hip
 hipError_t launch_seed_keys(const uint32_t *x, const uint32_t *l, uint64_t n, int seg, uint32_t *keys, uint32_t *idx,
                             hipStream_t stream);
-hipError_t launch_seed_gather(const uint32_t *x, const uint32_t *l, const uint32_t *pos, const uint32_t *idx, uint64_t n,
-                              uint2 *planes_out, uint32_t *pos_out, hipStream_t stream);
 hipError_t launch_lower_bound(const uint32_t *sorted_keys, uint64_t n, uint32_t n_buckets, uint32_t key_offset,
                               uint32_t base, uint32_t *out, hipStream_t stream);
 hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *keys, uint32_t *gids,
                             hipStream_t stream);
 hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted_gids, uint64_t n_pairs, uint32_t *off,
-                             uint32_t *poff, const uint2 *guides, uint2 *list_planes, uint32_t *list_gid,
-                             uint4 *list_rest, hipStream_t stream);
+                             uint32_t *poff, const uint2 *guides, uint4 *list_rest, hipStream_t stream);
 hipError_t launch_seed_gather16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, const uint32_t *idx, uint64_t n,
                                 uint4 *out, hipStream_t stream);
 hipError_t launch_seed_transpose(const uint4 *sites, const uint4 *chunk_tab, uint32_t n_chunks, uint32_t *vert,
                                  hipStream_t stream);
 hipError_t launch_seed_sliced(const SeedArgs &args, int n_groups, hipStream_t stream);
-hipError_t launch_seed_compare(const SeedArgs &args, int n_groups, bool dense, hipStream_t stream);
 hipError_t launch_merge(const vsc_hit *in, const uint64_t *shard_off_dev, uint32_t n_shards, uint32_t K, uint64_t *bound,
                         uint64_t *key_off, vsc_hit *out, hipStream_t stream);
 

@@ -3,7 +3,7 @@
 // scan_kernel     rows R1-R3 of DESIGN.md: for every read and both strands, every genome window that
 //                 the reference's pigeonhole search + verify delegate would accept
 //                 (VARSCOT_pipeline/read_mapping/bidir_mapping.cpp:31-148,150-162,285-295).
-// finalize_kernel global position -> (contig, offset) records (bidir_mapping.cpp:99-100).
+//                 (the hits are ordered and turned into vsc_hit records by vsc_sort.hip)
 // score_kernel    rows R5/R6: calcMitScore (variant_processing/mit_score.h:12-68) and
 //                 featureMatrixRecord (variant_processing/feature_matrix.h:25-126) per hit.
 //
@@ -301,146 +301,6 @@ hipError_t launch_scan(const ScanArgs &args, int n_groups, bool extract, hipStre
 }
 
 // ------------------------------------------------------------------------------------------------
-// sort (rocPRIM radix sort of the 64-bit hit keys with their 32-bit payload)
-// ------------------------------------------------------------------------------------------------
-hipError_t sort_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit, size_t *bytes)
-{
-    *bytes = 0;
-    return rocprim::radix_sort_pairs((void *)nullptr, *bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
-                                     (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, begin_bit, end_bit);
-}
-
-// Sorts on key bits [begin_bit, end_bit).  The library sort moves every pair once per 8-bit digit, so
-// the host drops up to 8 low position bits to save a whole pass; finalize_kernel puts the (few)
-// records that share the remaining bits in order.
-hipError_t launch_sort(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
-                       const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
-                       hipStream_t stream)
-{
-    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, begin_bit,
-                                     end_bit, stream);
-}
-
-// ------------------------------------------------------------------------------------------------
-// finalize: sorted (key, value) pairs -> vsc_hit records
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t contig_of(const uint32_t *contig_off, uint32_t n_contigs, uint32_t pos)
-{
-    uint32_t lo = 0, hi = n_contigs;  // last contig whose start is <= pos
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (contig_off[mid] <= pos) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-// The sort left records that agree in key bits [low_bits, 64) adjacent but in arbitrary order.  A block
-// stages its keys plus 256 on either side in LDS and every thread ranks its key inside its group:
-// destination = group start + number of smaller keys (keys are unique).  That works for groups of up
-// to 257 records: always when low_bits <= 8, and for practically every search when up to 16 position
-// bits are left out (a group is then one read's hits on one strand inside a 64 kb window); a larger
-// group raises *overflow and the host repeats the sort with low_bits <= 8.  low_bits = 0: no groups.
-constexpr int kFinalizeBlock = 256;
-constexpr int kFinalizeItems = 8;    // records per thread
-constexpr int kFinalizeHalo = 256;   // >= the largest group
-constexpr int kFinalizeTile = kFinalizeBlock * kFinalizeItems;
-constexpr int kFinalizeContigs = 1024;
-constexpr int kFinalizeNear = 3;     // neighbours per side ranked without a loop
-
-// kStaged: the contig table fits the LDS copy (a separate instantiation: merged into one loop the two table
-// pointers become a generic pointer and the binary search runs on flat loads)
-template <bool kStaged>
-__global__ __launch_bounds__(kFinalizeBlock) void finalize_kernel(const FinalizeArgs a)
-{
-    __shared__ uint64_t s_key[kFinalizeTile + 2 * kFinalizeHalo];
-    __shared__ uint32_t s_contig[kFinalizeContigs];  // contig starts: a genome has few, a variant genome millions
-    if (kStaged)
-        for (uint32_t t = threadIdx.x; t < a.n_contigs; t += kFinalizeBlock) s_contig[t] = a.contig_off[t];
-    const uint64_t block_first = (uint64_t)blockIdx.x * kFinalizeTile;
-    // tile = records [block_first - halo, block_first + tile + halo); slots outside [0, n) get a key no group shares
-    const int lo = a.low_bits ? 0 : kFinalizeHalo, hi = a.low_bits ? kFinalizeTile + 2 * kFinalizeHalo : kFinalizeHalo + kFinalizeTile;
-    for (int t = lo + threadIdx.x; t < hi; t += kFinalizeBlock) {
-        const uint64_t j = block_first + (uint64_t)t - kFinalizeHalo;  // wraps below zero -> >= n
-        s_key[t] = j < a.n ? a.keys[j] : ~0ull;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kFinalizeItems; ++k) {
-        const int me = kFinalizeHalo + k * kFinalizeBlock + (int)threadIdx.x;
-        const uint64_t i = block_first + (uint64_t)(me - kFinalizeHalo);
-        if (i >= a.n) break;
-        const uint64_t key = s_key[me];
-        uint64_t dst = i;
-        if (a.low_bits) {
-            // The first kNear neighbours on either side are tested with straight-line predicated code: written as
-            // loops with data-dependent exits the compiler spends ~370 scalar instructions per record on
-            // execution-mask bookkeeping (the kernel was bound by the CU's one scalar unit).  Groups that
-            // reach further - rare at <= 2 records per group on average - continue in a wave-uniform loop.
-            const uint64_t group = key >> a.low_bits;
-            uint32_t before = 0, smaller = 0, after = 0;
-            bool up = true, down = true;
-#pragma unroll
-            for (int d = 1; d <= kFinalizeNear; ++d) {
-                const uint64_t ku = s_key[me - d], kd = s_key[me + d];
-                up = up && (ku >> a.low_bits) == group;
-                down = down && (kd >> a.low_bits) == group;
-                before += up;
-                after += down;
-                smaller += (up && ku < key) + (down && kd < key);
-            }
-            if (__ballot(up || down) != 0) {  // wave-uniform: the whole wave walks on, predicated, until no lane needs to
-                for (int d = kFinalizeNear + 1; d <= kFinalizeHalo; ++d) {
-                    const uint64_t ku = s_key[me - d], kd = s_key[me + d];
-                    up = up && (ku >> a.low_bits) == group;
-                    down = down && (kd >> a.low_bits) == group;
-                    before += up;
-                    after += down;
-                    smaller += (up && ku < key) + (down && kd < key);
-                    if (__ballot(up || down) == 0) break;
-                }
-            }
-            // a group that reaches past the staged neighbourhood cannot be ranked here: the host sorts again
-            // with fewer bits left out
-            if (before == (uint32_t)kFinalizeHalo || after == (uint32_t)kFinalizeHalo) atomicMax(a.overflow, 1ull);
-            dst = i - before + smaller;
-        }
-        const uint32_t pos = (uint32_t)key;
-        const uint32_t strand = (uint32_t)(key >> 32) & 1u;
-        uint32_t c, start;
-        if (kStaged) {
-            uint32_t lo = 0, hi = a.n_contigs;  // contig_of on the LDS copy
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_contig[mid] <= pos) lo = mid; else hi = mid;
-            }
-            c = lo;
-            start = s_contig[c];
-        } else {
-            c = contig_of(a.contig_off, a.n_contigs, pos);
-            start = a.contig_off[c];
-        }
-        vsc_hit h;
-        h.guide = (uint32_t)(key >> 33);
-        h.contig = c;
-        h.pos = pos - start;
-        h.info = (strand << 31) | a.vals[i];
-        a.out[dst] = h;
-    }
-}
-
-hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream)
-{
-    if (args.n == 0) return hipSuccess;
-    if (args.low_bits > 24 || (args.low_bits && !args.overflow)) return hipErrorInvalidValue;
-    const unsigned blocks = (unsigned)((args.n + kFinalizeTile - 1) / kFinalizeTile);
-    if (args.n_contigs <= (uint32_t)kFinalizeContigs)
-        hipLaunchKernelGGL(finalize_kernel<true>, dim3(blocks), dim3(kFinalizeBlock), 0, stream, args);
-    else
-        hipLaunchKernelGGL(finalize_kernel<false>, dim3(blocks), dim3(kFinalizeBlock), 0, stream, args);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
 // merge of per-shard results.  Every shard's records are sorted by (guide, strand, contig, pos) and the
 // shards partition the positions in ascending order, so the global order is: for every (guide, strand)
 // key, the key's segment of shard 0, then of shard 1, ...  No sort is needed - three small kernels
@@ -513,6 +373,7 @@ hipError_t launch_merge(const vsc_hit *in, const uint64_t *shard_off_dev, uint32
     return hipGetLastError();
 }
 
+// 32-bit (key, value) sorts of the one-off index build and of the per-search read lists (a few million pairs): rocPRIM
 hipError_t sort32_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes)
 {
     *bytes = 0;

@@ -14,12 +14,10 @@
 // streaming scan's criterion - at most m mismatches over all 23 positions, the right-edge rule - so the
 // accepted set is identical; a pair that qualifies in several segments is reported by the first only.
 //
-// Two comparison kernels share the index build and the read lists:
-//   seed_sliced_kernel   (default) bit-sliced: 32 sites per lane and instruction, only the 16 positions
-//                        outside the bucket's segment are counted, the segment adds the list entry's
-//                        known distance; hits are resolved from 16-byte site records
-//   seed_compare_kernel  (VSC_SEED_KERNEL=pairs) one (site, read) pair per lane and iteration over all
-//                        23 positions, 8-byte site records
+// seed_sliced_kernel compares bit-sliced: 32 sites per lane and instruction, only the 16 positions outside
+// the bucket's segment are counted, the segment adds the list entry's known distance; hits are resolved
+// from the site records and leave the kernel as packed 8-byte records (vsc_internal.h), one output region
+// per 128 reads.
 #include "vsc_internal.h"
 #include "vsc_device.h"
 
@@ -42,19 +40,8 @@ __global__ __launch_bounds__(256) void seed_key_kernel(const uint32_t *x, const 
     idx[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(256) void seed_gather_kernel(const uint32_t *x, const uint32_t *l, const uint32_t *pos,
-                                                          const uint32_t *idx, uint64_t n, uint2 *planes_out,
-                                                          uint32_t *pos_out)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t j = idx[i];
-    planes_out[i] = make_uint2(x[j], l[j]);
-    pos_out[i] = pos[j];
-}
-
-// same, as 16-byte records {hi plane | strand | edge, lo plane, position, 0} (what the sliced kernel's hit path reads:
-// one gather per hit; two separate gathers - planes, position - cost the L1 a cache-line transaction per lane each)
+// the sites in bucket order as 16-byte records {hi plane | strand | edge, lo plane, position, 0}: what the hit path
+// reads, one gather per hit (two separate gathers - planes, position - cost the L1 a cache-line transaction per lane each)
 __global__ __launch_bounds__(256) void seed_gather16_kernel(const uint32_t *x, const uint32_t *l, const uint32_t *pos,
                                                             const uint32_t *idx, uint64_t n, uint4 *out)
 {
@@ -84,15 +71,6 @@ hipError_t launch_seed_keys(const uint32_t *x, const uint32_t *l, uint64_t n, in
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(seed_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, l, n, seg, keys, idx);
-    return hipGetLastError();
-}
-
-hipError_t launch_seed_gather(const uint32_t *x, const uint32_t *l, const uint32_t *pos, const uint32_t *idx, uint64_t n,
-                              uint2 *planes_out, uint32_t *pos_out, hipStream_t stream)
-{
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(seed_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, l, pos, idx, n,
-                       planes_out, pos_out);
     return hipGetLastError();
 }
 
@@ -194,12 +172,11 @@ __device__ __forceinline__ uint32_t rest_of(uint32_t v, uint32_t seg)
     return (v & 0x3FFFu) | ((v >> (3 * kSegBases)) << (2 * kSegBases));
 }
 
-// list_planes / list_gid: full planes + read index (pair kernel).  list_rest (sliced kernel): x = rest(hi) |
-// rest(lo) << 16, y = read index | seed distance << 30, z / w = the full hi / lo planes (for the hit path).
+// list_rest: x = rest(hi) | rest(lo) << 16, y = read index | seed distance << 30, z / w = the full hi / lo planes
+// (for the hit path).
 __global__ __launch_bounds__(256) void seed_list_kernel(const uint32_t *sorted_keys, const uint32_t *sorted_gids,
                                                         uint64_t n_pairs, const uint32_t *off, const uint32_t *poff,
-                                                        const uint2 *guides, uint2 *list_planes, uint32_t *list_gid,
-                                                        uint4 *list_rest)
+                                                        const uint2 *guides, uint4 *list_rest)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pairs) return;
@@ -207,8 +184,6 @@ __global__ __launch_bounds__(256) void seed_list_kernel(const uint32_t *sorted_k
     const uint32_t g = v & ((1u << kListDistShift) - 1u);
     const uint32_t dst = poff[b] + ((uint32_t)i - off[b]);
     const uint2 gp = guides[g];
-    list_planes[dst] = gp;
-    list_gid[dst] = g;
     const uint32_t seg = b / (uint32_t)kBucketsPerSeg;
     list_rest[dst] = make_uint4(rest_of(gp.x, seg) | (rest_of(gp.y, seg) << 16), v, gp.x, gp.y);
 }
@@ -224,8 +199,7 @@ hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_n
 }
 
 hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted_gids, uint64_t n_pairs, uint32_t *off,
-                             uint32_t *poff, const uint2 *guides, uint2 *list_planes, uint32_t *list_gid,
-                             uint4 *list_rest, hipStream_t stream)
+                             uint32_t *poff, const uint2 *guides, uint4 *list_rest, hipStream_t stream)
 {
     hipError_t e = launch_lower_bound(sorted_keys, n_pairs, kBuckets, 0, 0, off, stream);
     if (e != hipSuccess) return e;
@@ -233,287 +207,28 @@ hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted
     e = hipGetLastError();
     if (e != hipSuccess || n_pairs == 0) return e;
     hipLaunchKernelGGL(seed_list_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, sorted_keys,
-                       sorted_gids, n_pairs, (const uint32_t *)off, (const uint32_t *)poff, guides, list_planes, list_gid, list_rest);
+                       sorted_gids, n_pairs, (const uint32_t *)off, (const uint32_t *)poff, guides, list_rest);
     return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// compare kernel
-// ------------------------------------------------------------------------------------------------
-struct SeedWave {
-    uint4 *tok4;     // sliced kernel: pending hit tokens (see sliced_fetch)
-    uint64_t *tok;   // pending hits of the current chunk: t | slot << 23 | lane << 26  |  list index << 32
-    uint64_t *hkey;  // resolved hits waiting for the global append
-    uint32_t *hval;
-    uint32_t ntok, hn, lane;
-    uint32_t thead;  // sliced kernel: ring slot of the oldest pending token
-    unsigned long long res_base;  // this wave's reserved range of the global hit arrays
-    uint32_t res_left;
-    uint32_t cp;     // sliced kernel: the output region the staged hits and the reservation belong to
-    uint4 *parts;    // sliced kernel: {res_base lo, hi, res_left, 0} of the regions this wave is not writing to
-    uint32_t *first; // sliced kernel: first site of every chunk of the current grab (tokens name their chunk by slot)
-};
-
-// Moves the resolved hits of this wave to the global hit arrays.  A single device-wide cursor
-// sustains only ~90 atomics/us (MI355X_MICROARCH.md, "dequeue"), which at 1.6e9 hits and ~200 hits
-// per flush would cost as much as the whole comparison; so a wave reserves a block of a.reserve
-// records per atomic and fills it over several flushes.  What is left of the last block at the end
-// of the kernel is filled with sentinel keys that sort behind every real hit.
-__device__ __forceinline__ void seed_flush_hits(const SeedArgs &a, SeedWave &w)
-{
-    uint32_t done = 0;
-    while (done < w.hn) {
-        if (w.res_left == 0) {
-            const uint32_t want = a.reserve ? a.reserve : w.hn - done;  // reserve == 0: exact appends
-            unsigned long long base = 0;
-            if (w.lane == 0) base = atomicAdd(&a.counters[kCntHits], (unsigned long long)want);
-            base = ((unsigned long long)uniform((uint32_t)(base >> 32)) << 32) | uniform((uint32_t)base);
-            if (base + want > a.hit_cap) {
-                // buffer too small: undo the reservation, count what is lost; the host re-runs with room
-                // for counters[kCntHits] + counters[kCntLost] records (+ one block per wave)
-                if (w.lane == 0) {
-                    atomicAdd(&a.counters[kCntHits], 0ull - (unsigned long long)want);
-                    atomicAdd(&a.counters[kCntLost], (unsigned long long)(w.hn - done));
-                    atomicMax(&a.counters[kCntOverflow], 1ull);
-                }
-                break;
-            }
-            w.res_base = base;
-            w.res_left = want;
-        }
-        const uint32_t take = min(w.hn - done, w.res_left);
-        for (uint32_t i = w.lane; i < take; i += kWave) {
-            a.hit_keys[w.res_base + i] = w.hkey[done + i];
-            a.hit_vals[w.res_base + i] = w.hval[done + i];
-        }
-        w.res_base += take;
-        w.res_left -= take;
-        done += take;
-    }
-    wave_sync();
-    w.hn = 0;
-}
-
-__device__ __forceinline__ void seed_finish_hits(const SeedArgs &a, SeedWave &w)
-{
-    seed_flush_hits(a, w);
-    for (uint32_t i = w.lane; i < w.res_left; i += kWave) a.hit_keys[w.res_base + i] = ~0ull;
-    if (w.lane == 0 && w.res_left) atomicAdd(&a.counters[kCntPad], (unsigned long long)w.res_left);
-    w.res_left = 0;
-}
-
-// Dense second half of the hit path: every lane resolves one pending token of the current chunk.
-__device__ __forceinline__ void seed_resolve(const SeedArgs &a, SeedWave &w, uint32_t chunk_first, uint32_t seg)
-{
-    wave_sync();
-    for (uint32_t base = 0; base < w.ntok; base += kWave) {
-        const uint32_t i = base + w.lane;
-        bool hit = i < w.ntok;
-        uint64_t key = 0;
-        uint32_t val = 0;
-        if (hit) {
-            const uint64_t tk = w.tok[i];
-            const uint32_t lo = (uint32_t)tk;
-            const uint32_t t = lo & kMask23;
-            const uint32_t site = chunk_first + ((lo >> 23) & 7u) * kWave + (lo >> 26);
-            const uint32_t x = a.planes[site].x;
-            const uint32_t pos = a.pos[site];
-            const uint32_t gid = a.list_gid[(uint32_t)(tk >> 32)];
-            const uint32_t strand = (x >> kSiteStrandBit) & 1u;
-            // a pair that also qualifies in an earlier segment was reported there
-            // (straight-line on purpose: as a loop over `seg` the compiler unrolls it eightfold on scalars)
-            static_assert(kSegments == 3, "the duplicate test spells out segments 0 and 1");
-            const uint32_t earlier = seg == 0 ? 0u : (seg == 1 ? 0x7Fu : 0x3FFFu);  // bases of the earlier segments
-            if ((uint32_t)__popc(t & earlier & 0x7Fu) <= a.k_seg && seg >= 1) hit = false;
-            if ((uint32_t)__popc(t & earlier & 0x3F80u) <= a.k_seg && seg >= 2) hit = false;
-            const uint32_t mask = strand ? reverse23(t) : t;
-            // right-edge rule, bidir_mapping.cpp:51-52 (see emit_hits in vsc_kernels.hip)
-            if (hit && ((x >> kSiteEdgeBit) & 1u)) {
-                if ((uint32_t)__popc(mask >> (VSC_READ_LEN / 2)) > a.k_half &&
-                    is_contig_end(a.contig_end, a.n_contigs, pos + VSC_READ_LEN))
-                    hit = false;
-            }
-            key = ((uint64_t)gid << 33) | ((uint64_t)strand << 32) | pos;
-            val = ((uint32_t)__popc(t) << 23) | mask;
-        }
-        const uint64_t b = __ballot(hit);
-        if (hit) {
-            const uint32_t at = lanes_below(b, w.hn);
-            w.hkey[at] = key;
-            w.hval[at] = val;
-        }
-        wave_sync();
-        w.hn += (uint32_t)__popcll(b);
-        if (w.hn > kSeedHitCap - kWave) seed_flush_hits(a, w);
-    }
-    w.ntok = 0;
-}
-
-// One chunk = at most kBatch sites of one bucket, to be compared with that bucket's read list.
-// chunk_tab[c] = {first site, site count, bucket, 0}; the bucket's read list is poff[bucket .. bucket+1).
-typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
-
-__device__ __forceinline__ void seed_load_sites(const SeedArgs &a, uint32_t first, uint32_t count, uint32_t lane,
-                                                uint2 (&v)[kSitesPerLane])
-{
-#pragma unroll
-    for (int j = 0; j < kSitesPerLane; ++j) {
-        const uint32_t idx = j * kWave + lane;
-        v[j] = make_uint2(0xFFFFFFFFu, 0u);  // empty slot: never matches (see process_batch)
-        if (idx < count) v[j] = a.planes[first + idx];
-    }
-}
-
-// kDense = false: one v_min3 tree + one test per four reads, hits (rare) re-derived in a slow path.
-// kDense = true : one test per (read, site slot); hits are appended where they are found.  Chosen by
-//                 the host when most iterations are expected to contain hits (m >= 7).
-template <bool kDense>
-__global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_compare_kernel(const SeedArgs a)
-{
-    __shared__ uint64_t s_tok[kWavesPerGroup][kSeedTokCap];
-    __shared__ uint64_t s_hkey[kWavesPerGroup][kSeedHitCap];
-    __shared__ uint32_t s_hval[kWavesPerGroup][kSeedHitCap];
-
-    const uint32_t wave = threadIdx.x / kWave;
-    SeedWave w;
-    w.lane = threadIdx.x % kWave;
-    w.tok = s_tok[wave];
-    w.hkey = s_hkey[wave];
-    w.hval = s_hval[wave];
-    w.ntok = 0;
-    w.hn = 0;
-    w.res_base = 0;
-    w.res_left = 0;
-
-    const const_v4u_ptr gp = (const_v4u_ptr)(uintptr_t)a.list_planes;
-    const uint32_t m = a.max_mm;
-    uint32_t vm;  // the budget in a VGPR, see the comparison loop
-    asm("v_mov_b32 %0, %1" : "=v"(vm) : "s"(m));
-    const uint32_t lane_bits = w.lane << 26;
-    unsigned long long pairs = 0, visited = 0;
-
-    const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
-    const const_u32_ptr poff = (const_u32_ptr)(uintptr_t)a.poff;
-
-    for (;;) {
-        uint32_t first = 0;
-        if (w.lane == 0) first = (uint32_t)atomicAdd(&a.counters[kCntChunk], (unsigned long long)kSeedGrab);
-        first = uniform(first);
-        if (first >= a.n_chunks) break;
-        const uint32_t last = min(first + (uint32_t)kSeedGrab, a.n_chunks);
-        // Three-stage software pipeline over the chunks of this grab, all stages one chunk apart:
-        //   A  chunk table entry (scalar load)   B  its read-list bounds poff[bucket..] (scalar load)
-        //   C  its sites (vector loads, one HBM round trip per 4 KB)           then the comparison.
-        // Without it a wave idles for three dependent memory latencies per chunk.
-        v4u t0 = ctab[first];                           // chunk c     : A done
-        v4u t1 = ctab[min(first + 1, last - 1)];        // chunk c + 1 : A in flight
-        uint32_t p0a = poff[t0.z], p0b = poff[t0.z + 1];  // chunk c : B done
-        uint2 nv[kSitesPerLane];
-        if (p0a != p0b) seed_load_sites(a, t0.x, t0.y, w.lane, nv);  // chunk c : C in flight
-        uint32_t p1a = poff[t1.z], p1b = poff[t1.z + 1];  // chunk c + 1 : B in flight
-        v4u t2 = ctab[min(first + 2, last - 1)];         // chunk c + 2 : A in flight
-        for (uint32_t c = first; c < last; ++c) {
-            struct {
-                uint32_t first, count, g0, g1, seg;
-            } cur = {t0.x, t0.y, p0a, p0b, t0.z / (uint32_t)kBucketsPerSeg};
-            uint32_t sh[kSitesPerLane], sl[kSitesPerLane];
-#pragma unroll
-            for (int j = 0; j < kSitesPerLane; ++j) {
-                sh[j] = nv[j].x == 0xFFFFFFFFu ? 0xFFFFFFFFu : (nv[j].x & kMask23);
-                sl[j] = nv[j].y;
-            }
-            // advance the pipeline before the comparison so that its loads overlap it
-            t0 = t1;
-            p0a = p1a;
-            p0b = p1b;
-            if (c + 1 < last && p0a != p0b) seed_load_sites(a, t0.x, t0.y, w.lane, nv);
-            t1 = t2;
-            p1a = poff[t1.z];
-            p1b = poff[t1.z + 1];
-            t2 = ctab[min(c + 3, last - 1)];
-            if (cur.g0 == cur.g1) continue;  // no read has this bucket in its neighbourhood
-            pairs += (unsigned long long)cur.count * (cur.g1 - cur.g0);
-            visited += cur.count;
-            v4u na = gp[cur.g0 >> 1], nb = gp[(cur.g0 >> 1) + 1];
-            // Scalar loads return out of order, so a wait for the first read group is a wait for ALL
-            // outstanding scalar loads.  Waiting here, once per chunk, keeps that wait out of the loop:
-            // otherwise it lands behind the prefetch of the next group and exposes its latency every time.
-            asm volatile("; first read group ready" ::"s"(na), "s"(nb));
-            for (uint32_t g = cur.g0; g < cur.g1; g += kGuideUnroll) {
-                const v4u ga = na, gb = nb;
-                na = gp[(g >> 1) + 2];  // the list is allocated with one spare group
-                nb = gp[(g >> 1) + 3];
-                const uint32_t gh[kGuideUnroll] = {ga.x, ga.z, gb.x, gb.z};
-                const uint32_t gl[kGuideUnroll] = {ga.y, ga.w, gb.y, gb.w};
-                if (kDense) {
-#pragma unroll
-                    for (int u = 0; u < kGuideUnroll; ++u) {
-                        // VALU instructions with an SGPR operand issue at about half the rate of all-VGPR
-                        // ones on gfx950 (profiles/r01_valu_rate_microbench.txt): two copies per read buy
-                        // sixteen full-rate instructions.  The asm keeps the compiler from folding them back.
-                        uint32_t vh, vl;
-                        asm("v_mov_b32 %0, %1" : "=v"(vh) : "s"(gh[u]));
-                        asm("v_mov_b32 %0, %1" : "=v"(vl) : "s"(gl[u]));
-#pragma unroll
-                        for (int j = 0; j < kSitesPerLane; ++j) {
-                            const uint32_t t = (sh[j] ^ vh) | (sl[j] ^ vl);
-                            const bool hit = (uint32_t)__popc(t) <= vm;
-                            const uint64_t b = __ballot(hit);
-                            if (b == 0) continue;
-                            if (hit)
-                                w.tok[lanes_below(b, w.ntok)] = ((uint64_t)(g + u) << 32) | lane_bits | ((uint32_t)j << 23) | t;
-                            w.ntok += (uint32_t)__popcll(b);
-                            if (w.ntok > kSeedTokCap - kWave) seed_resolve(a, w, cur.first, cur.seg);
-                        }
-                    }
-                } else {
-                    uint32_t best[kGuideUnroll];
-#pragma unroll
-                    for (int u = 0; u < kGuideUnroll; ++u) {
-                        uint32_t cm = 32;
-#pragma unroll
-                        for (int j = 0; j < kSitesPerLane; ++j) {
-                            const uint32_t t = (sh[j] ^ gh[u]) | (sl[j] ^ gl[u]);
-                            cm = min(cm, (uint32_t)__popc(t));
-                        }
-                        best[u] = cm;
-                    }
-                    const uint32_t any = min(min(best[0], best[1]), min(best[2], best[3]));
-                    if (__ballot(any <= m) != 0) {
-                        // sparse first half of the hit path: one 8-byte token per hit into LDS
-#pragma unroll
-                        for (int u = 0; u < kGuideUnroll; ++u) {
-                            if (__ballot(best[u] <= m) == 0) continue;
-#pragma unroll
-                            for (int j = 0; j < kSitesPerLane; ++j) {
-                                const uint32_t t = (sh[j] ^ gh[u]) | (sl[j] ^ gl[u]);
-                                const bool hit = (uint32_t)__popc(t) <= m;
-                                const uint64_t b = __ballot(hit);
-                                if (b == 0) continue;
-                                if (hit)
-                                    w.tok[lanes_below(b, w.ntok)] = ((uint64_t)(g + u) << 32) | lane_bits | ((uint32_t)j << 23) | t;
-                                w.ntok += (uint32_t)__popcll(b);
-                                if (w.ntok > kSeedTokCap - kWave) seed_resolve(a, w, cur.first, cur.seg);
-                            }
-                        }
-                    }
-                }
-            }
-            if (w.ntok) seed_resolve(a, w, cur.first, cur.seg);
-        }
-    }
-    seed_finish_hits(a, w);
-    if (w.lane == 0 && pairs) {
-        atomicAdd(&a.counters[kCntSites], pairs);
-        atomicAdd(&a.counters[kCntVisited], visited);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // bit-sliced comparison
 // ------------------------------------------------------------------------------------------------
-// The pair kernel above spends 4 VALU instructions per (site, read) pair and lane.  Here a lane holds 32
-// sites "vertically": one word per read position and plane, bit i = site i.  One VALU instruction then
+typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
+
+struct SeedWave {
+    uint4 *tok4;     // pending hit tokens (see sliced_fetch)
+    uint32_t ntok, lane;
+    uint32_t thead;  // ring slot of the oldest pending token
+    uint32_t res_base;  // this wave's open block in region cp: next free record (relative to the region) ...
+    uint32_t res_left;  // ... and records left in it
+    uint32_t cp;     // the output region the open block in registers belongs to
+    uint2 *parts;    // {res_base, res_left} of the regions this wave is not writing to
+    uint32_t *first; // first site of every chunk of the current grab (tokens name their chunk by slot)
+};
+
+// A per-pair comparison (xor, or, popcount, compare) spends 4 VALU instructions per (site, read) pair and lane.
+// Here a lane holds 32 sites "vertically": one word per read position and plane, bit i = site i.  One VALU instruction then
 // works on 32 pairs:  16 positions x 2 (mismatch vector) + a carry-save adder tree (11 full + 4 half
 // adders, 2 instructions each) + a 5-instruction bit-sliced "count <= budget" = ~67 instructions per 32
 // pairs, no popcount, no per-pair branch.  Only the 16 positions OUTSIDE the bucket's seed segment are
@@ -665,15 +380,15 @@ struct SlicedFetch {
     uint4 rec;  // site record of the lowest set bit
 };
 
-// Output of the sliced kernel.  A wave keeps, per output region, an open block of reserved records
-// (w.parts[p] = {next free record lo, hi, records left}).  The hits of a pass go straight from registers to
-// their region's block - no staging in LDS: the hits of consecutive passes belong to different regions
-// often enough (a wave walks through the read ranges once per chunk) that staged batches stayed small.
+// Output of the sliced kernel.  A wave keeps, per output region (128 reads), an open block of reserved
+// records (w.parts[p] = {next free record, records left}, relative to the region).  The hits of a pass go
+// straight from registers to their region's block - no staging in LDS: the hits of consecutive passes
+// belong to different regions often enough (a wave walks through the read ranges once per chunk) that
+// staged batches stayed small.
 //
 // Reserves a new block in region p (wave-uniform).  Returns false when the region is full: the host
 // re-runs with room for reserved + lost records in every region.
-__device__ __forceinline__ bool sliced_reserve(const SeedArgs &a, const SeedWave &w, uint32_t p, uint32_t losing,
-                                               unsigned long long &base)
+__device__ __forceinline__ bool sliced_reserve(const SeedArgs &a, const SeedWave &w, uint32_t p, uint32_t losing, uint32_t &base)
 {
     unsigned long long *const cursor = &a.counters[kCntPart + 4 * p];
     unsigned long long rel = 0;
@@ -687,33 +402,31 @@ __device__ __forceinline__ bool sliced_reserve(const SeedArgs &a, const SeedWave
         }
         return false;
     }
-    base = (unsigned long long)p * a.part_cap + rel;
+    base = (uint32_t)rel;  // part_cap < 2^32
     return true;
 }
 
 // lanes in `mask` (all of region p, wave-uniform) store their record.  The open block of the region in
 // use lives in registers (w.cp, w.res_base, w.res_left); the LDS table is touched on a change of region only.
-__device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, uint32_t p, uint64_t mask, bool mine,
-                                             uint64_t key, uint32_t val)
+__device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, uint32_t p, uint64_t mask, bool mine, uint64_t rec)
 {
     if (p != w.cp) {
-        if (w.lane == 0) w.parts[w.cp] = make_uint4((uint32_t)w.res_base, (uint32_t)(w.res_base >> 32), w.res_left, 0u);
+        if (w.lane == 0) w.parts[w.cp] = make_uint2(w.res_base, w.res_left);
         wave_sync();
-        const uint4 st = w.parts[p];
-        w.res_base = ((unsigned long long)uniform(st.y) << 32) | uniform(st.x);
-        w.res_left = uniform(st.z);
+        const uint2 st = w.parts[p];
+        w.res_base = uniform(st.x);
+        w.res_left = uniform(st.y);
         w.cp = p;
     }
     const uint32_t n = (uint32_t)__popcll(mask);
     const uint32_t rank = lanes_below(mask);
     const uint32_t left = w.res_left;
-    unsigned long long next = w.res_base;
+    uint32_t next = w.res_base;
     bool ok = true;
     if (left < n) ok = sliced_reserve(a, w, p, n - left, next);  // the open block takes `left`, a new one the rest
     if (mine && (rank < left || ok)) {
-        const unsigned long long at = rank < left ? w.res_base + rank : next + (rank - left);
-        a.hit_keys[at] = key;
-        a.hit_vals[at] = val;
+        const uint32_t at = rank < left ? w.res_base + rank : next + (rank - left);
+        a.hit_recs[(unsigned long long)p * a.part_cap + at] = rec;
     }
     if (left < n) {
         w.res_base = ok ? next + (n - left) : w.res_base + left;
@@ -724,16 +437,15 @@ __device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, uin
     }
 }
 
-// end of the kernel: the open blocks are filled up with sentinel keys that sort behind every real hit
+// end of the kernel: the open blocks are filled up with sentinels, which the sort drops
 __device__ __forceinline__ void sliced_finish_hits(const SeedArgs &a, SeedWave &w)
 {
-    if (w.lane == 0) w.parts[w.cp] = make_uint4((uint32_t)w.res_base, (uint32_t)(w.res_base >> 32), w.res_left, 0u);
+    if (w.lane == 0) w.parts[w.cp] = make_uint2(w.res_base, w.res_left);
     wave_sync();
     for (uint32_t q = 0; q < a.n_parts; ++q) {
-        const uint4 st = w.parts[q];
-        const unsigned long long base = ((unsigned long long)uniform(st.y) << 32) | uniform(st.x);
-        const uint32_t left = uniform(st.z);
-        for (uint32_t i = w.lane; i < left; i += kWave) a.hit_keys[base + i] = ~0ull;
+        const uint2 st = w.parts[q];
+        const uint32_t base = uniform(st.x), left = uniform(st.y);
+        for (uint32_t i = w.lane; i < left; i += kWave) a.hit_recs[(unsigned long long)q * a.part_cap + base + i] = kRecSentinel;
         if (w.lane == 0 && left) atomicAdd(&a.counters[kCntPart + 4 * q + 1], (unsigned long long)left);
     }
 }
@@ -794,16 +506,16 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
     if (__ballot(at_edge) != 0) {
         if (at_edge && is_contig_end(a.contig_end, a.n_contigs, pos + VSC_READ_LEN)) hit = false;
     }
-    const uint64_t key = ((uint64_t)gid_of << 33) | ((uint64_t)strand << 32) | pos;
-    const uint32_t val = ((uint32_t)__popc(t) << 23) | mask;
+    const uint64_t rec = ((uint64_t)(gid_of & (uint32_t)(kRegionReads - 1)) << kRecReadShift) | ((uint64_t)strand << kRecStrandShift) |
+                         ((uint64_t)pos << kRecPosShift) | mask;
     // the hits of a pass belong to one output region, two or three when the reads of the batch span region boundaries
-    const uint32_t region = gid_of >> a.part_shift;
+    const uint32_t region = gid_of >> kRegionBits;
     uint64_t todo = __ballot(hit);
     while (todo != 0) {
         const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)region, (int)__builtin_ctzll(todo));
         const bool mine = hit && region == p;
         const uint64_t b = __ballot(mine);
-        sliced_store(a, w, p, b, mine, key, val);
+        sliced_store(a, w, p, b, mine, rec);
         todo &= ~b;
     }
 }
@@ -862,25 +574,21 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
 {
     __shared__ uint4 s_tok[kWavesPerGroup][kSlicedTokCap];
     __shared__ uint4 s_list[kWavesPerGroup][kWave];  // the current tile of 64 read-list entries
-    __shared__ uint4 s_parts[kWavesPerGroup][kParts];
+    __shared__ uint2 s_parts[kWavesPerGroup][kParts];
     __shared__ uint32_t s_first[kWavesPerGroup][kSlicedGrab];
 
     const uint32_t wave = threadIdx.x / kWave;
     SeedWave w;
     w.lane = threadIdx.x % kWave;
-    w.tok = nullptr;
     w.tok4 = s_tok[wave];
-    w.hkey = nullptr;
-    w.hval = nullptr;
     w.ntok = 0;
     w.thead = 0;
-    w.hn = 0;
     w.res_base = 0;
     w.res_left = 0;
     w.cp = 0;
     w.parts = s_parts[wave];
     w.first = s_first[wave];
-    if (w.lane < (uint32_t)kParts) w.parts[w.lane] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t q = w.lane; q < (uint32_t)kParts; q += kWave) w.parts[q] = make_uint2(0u, 0u);
 
     uint4 *const lt = s_list[wave];
     const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
@@ -992,15 +700,6 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
 hipError_t launch_seed_sliced(const SeedArgs &args, int n_groups, hipStream_t stream)
 {
     hipLaunchKernelGGL(seed_sliced_kernel, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
-    return hipGetLastError();
-}
-
-hipError_t launch_seed_compare(const SeedArgs &args, int n_groups, bool dense, hipStream_t stream)
-{
-    if (dense)
-        hipLaunchKernelGGL(seed_compare_kernel<true>, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
-    else
-        hipLaunchKernelGGL(seed_compare_kernel<false>, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
     return hipGetLastError();
 }
 

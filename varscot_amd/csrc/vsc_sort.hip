@@ -1,0 +1,378 @@
+// vsc_sort.hip - puts the hit records of a search in result order and assembles the vsc_hit records:
+// the order of the reference's std::map per read and strand (VARSCOT_pipeline/read_mapping/
+// bidir_mapping.cpp:154, key = (contig, position)) and rID / beginPos of every record (:99-100).
+//
+// The search kernels leave the hits of every region (128 reads) as packed 8-byte records in no particular
+// order (layout: vsc_internal.h); ascending record order inside a region IS the result order.  A
+// comparison-free "bin sort" in the shape of the memory system orders them, every record moving through
+// HBM twice instead of once per 8-bit digit of a library radix sort:
+//
+//   bin_hist_kernel       one streaming read: records per (region, bin), bin = the top <= 11 key bits
+//   bin_scan_kernel       bin starts (exclusive scan per region)
+//   bin_partition_kernel  one read + one write: a workgroup takes a tile of 16 384 records, ranks them per bin
+//                         with LDS atomics, reserves room in every bin with one coalesced returning atomic
+//                         per bin, regroups the tile by bin in LDS and writes each bin's records as one
+//                         contiguous piece.  Pieces of different tiles land in a bin in arbitrary order.
+//   bin_finalize_kernel   one read + the 16-byte result write: a workgroup takes one bin (<= 16 384 records,
+//                         one read's hits on one strand inside a position window), counting-sorts it in LDS
+//                         on the next <= 12 key bits, ranks the handful of records that still agree (keys
+//                         are unique), resolves the contig and writes the vsc_hit records in place.
+//
+// A bin that exceeds the LDS capacity (a read with far more hits than the others - repeats) is listed and
+// goes through another hist / scan / partition level on the following key bits; bins of a level are
+// independent, so the levels are plain relaunches over a list of segments.  The streaming scan, whose hits
+// arrive as (key, value) pairs with the full read index, enters through a level 0 that partitions by region
+// and packs the records.
+#include "vsc_internal.h"
+#include "vsc_device.h"
+
+namespace vsc {
+
+namespace {
+
+// Exclusive scan, in place, of the n (a power of two, <= 4 * kThreads) counters s[0..n); returns the total.
+// Ends with a barrier; s_wave needs kThreads / 64 words.
+template <int kThreads>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t *s, uint32_t n, uint32_t *s_wave)
+{
+    const uint32_t t = threadIdx.x, lane = t % kWave, wave = t / kWave;
+    const uint32_t per = n > (uint32_t)kThreads ? n / kThreads : 1u;  // 1, 2 or 4
+    const bool mine = t * per < n;
+    uint32_t v[4] = {0u, 0u, 0u, 0u};
+    uint32_t sum = 0;
+    if (mine)
+        for (uint32_t i = 0; i < per; ++i) {
+            v[i] = s[t * per + i];
+            sum += v[i];
+        }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, kWave);
+        if (lane >= (uint32_t)d) inc += o;
+    }
+    if (lane == kWave - 1) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / kWave; ++w) {
+        const uint32_t x = s_wave[w];
+        before += (uint32_t)w < wave ? x : 0u;
+        total += x;
+    }
+    uint32_t run = before + inc - sum;
+    if (mine)
+        for (uint32_t i = 0; i < per; ++i) {
+            s[t * per + i] = run;
+            run += v[i];
+        }
+    __syncthreads();
+    return total;
+}
+
+// the segment that holds tile `tile`: last s with seg_tile0[s] <= tile (wave-uniform arguments: scalar loads)
+__device__ __forceinline__ uint32_t segment_of_tile(const uint32_t *seg_tile0, uint32_t n_segs, uint32_t tile)
+{
+    uint32_t lo = 0, hi = n_segs;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (seg_tile0[mid] <= tile) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// level 0: a (key, value) pair of the streaming scan -> packed record (the read's region is the bin, not part of it)
+__device__ __forceinline__ uint64_t pack_pair(uint64_t key, uint32_t val)
+{
+    return ((key & ((1ull << kRecKeyBits) - 1ull)) << kRecPosShift) | (val & kMask23);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// histogram: records per (segment, bin)
+// ------------------------------------------------------------------------------------------------
+template <bool kPairs>
+__global__ __launch_bounds__(kSortThreads) void bin_hist_kernel(const SortArgs a)
+{
+    __shared__ uint32_t s_hist[1 << kSortMaxBinBits];
+    const uint32_t t = threadIdx.x;
+    const uint32_t nbins = 1u << a.bin_bits;
+    for (uint32_t b = t; b < nbins; b += kSortThreads) s_hist[b] = 0;
+    __syncthreads();
+    const uint32_t tile_begin = blockIdx.x * kHistTiles, tile_end = min(tile_begin + (uint32_t)kHistTiles, a.n_tiles);
+    uint32_t seg = segment_of_tile(a.seg_tile0, a.n_segs, tile_begin);
+    for (uint32_t tile = tile_begin; tile < tile_end; ++tile) {
+        if (tile >= a.seg_tile0[seg + 1]) {
+            // the tiles of this block cross into another segment: hand over what was counted so far
+            __syncthreads();
+            for (uint32_t b = t; b < nbins; b += kSortThreads) {
+                const uint32_t c = s_hist[b];
+                if (c) atomicAdd(&a.hist[((size_t)seg << a.bin_bits) + b], c);
+                s_hist[b] = 0;
+            }
+            __syncthreads();
+            seg = segment_of_tile(a.seg_tile0, a.n_segs, tile);
+        }
+        const SortSeg sg = a.segs[seg];
+        const uint32_t first = (tile - a.seg_tile0[seg]) * (uint32_t)kSortTile;
+        const uint32_t n = min(sg.n_in - first, (uint32_t)kSortTile);
+#pragma unroll 4
+        for (int k = 0; k < kSortItems; ++k) {
+            const uint32_t i = k * kSortThreads + t;
+            if (i >= n) break;
+            if (kPairs) {
+                atomicAdd(&s_hist[(uint32_t)(a.pair_keys[sg.in_off + first + i] >> a.bin_shift)], 1u);
+            } else {
+                const uint64_t r = a.in[sg.in_off + first + i];
+                if (!(r >> 63)) atomicAdd(&s_hist[(uint32_t)(r >> a.bin_shift) & (nbins - 1u)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = t; b < nbins; b += kSortThreads) {
+        const uint32_t c = s_hist[b];
+        if (c) atomicAdd(&a.hist[((size_t)seg << a.bin_bits) + b], c);
+    }
+}
+
+hipError_t launch_bin_hist(const SortArgs &args, hipStream_t stream)
+{
+    if (args.n_tiles == 0) return hipSuccess;
+    const unsigned blocks = (args.n_tiles + kHistTiles - 1) / kHistTiles;
+    if (args.pair_keys)
+        hipLaunchKernelGGL(bin_hist_kernel<true>, dim3(blocks), dim3(kSortThreads), 0, stream, args);
+    else
+        hipLaunchKernelGGL(bin_hist_kernel<false>, dim3(blocks), dim3(kSortThreads), 0, stream, args);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// bin starts: one workgroup per segment
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void bin_scan_kernel(const SortArgs a)
+{
+    __shared__ uint32_t s_cnt[1 << kSortMaxBinBits];
+    __shared__ uint32_t s_wave[512 / kWave];
+    const uint32_t nbins = 1u << a.bin_bits;
+    const size_t base = (size_t)blockIdx.x << a.bin_bits;
+    for (uint32_t b = threadIdx.x; b < nbins; b += 512) s_cnt[b] = a.hist[base + b];
+    __syncthreads();
+    block_exclusive_scan<512>(s_cnt, nbins, s_wave);
+    for (uint32_t b = threadIdx.x; b < nbins; b += 512) {
+        a.bin_start[base + b] = s_cnt[b];
+        a.cursor[base + b] = s_cnt[b];
+    }
+}
+
+hipError_t launch_bin_scan(const SortArgs &args, hipStream_t stream)
+{
+    if (args.n_segs == 0) return hipSuccess;
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(args.n_segs), dim3(512), 0, stream, args);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// partition: one tile of kSortTile records per workgroup
+// ------------------------------------------------------------------------------------------------
+template <bool kPairs>
+__global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortArgs a)
+{
+    __shared__ uint64_t s_rec[kSortTile];
+    __shared__ uint32_t s_cnt[(1 << kSortMaxBinBits) + 1];  // records per bin, then their first slot in s_rec (+ a spare)
+    __shared__ uint32_t s_gbase[1 << kSortMaxBinBits];  // where this tile's records of a bin go in the bin
+    __shared__ uint32_t s_wave[kSortThreads / kWave];
+    const uint32_t t = threadIdx.x;
+    const uint32_t nbins = 1u << a.bin_bits;
+    const uint32_t seg = segment_of_tile(a.seg_tile0, a.n_segs, blockIdx.x);
+    const SortSeg sg = a.segs[seg];
+    const uint32_t first = (blockIdx.x - a.seg_tile0[seg]) * (uint32_t)kSortTile;
+    const uint32_t n = min(sg.n_in - first, (uint32_t)kSortTile);
+    for (uint32_t b = t; b <= nbins; b += kSortThreads) s_cnt[b] = 0;
+    __syncthreads();
+    // records of the tile in registers; sentinels (and the slots past the tile) take no part.  Branch-free on
+    // purpose (clamped loads + selects): with conditional stores into r[] / bin[] the compiler keeps the arrays
+    // as 16-wide vectors, copies them at every branch and spills.
+    uint64_t r[kSortItems];
+    uint32_t bin[kSortItems];  // bin | rank inside (tile, bin) << 16
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = k * kSortThreads + t;
+        const bool in_tile = i < n;
+        const uint64_t at = sg.in_off + first + (in_tile ? i : 0u);
+        if (kPairs) {
+            const uint64_t key = a.pair_keys[at];
+            r[k] = in_tile ? pack_pair(key, a.pair_vals[at]) : kRecSentinel;
+            bin[k] = in_tile ? (uint32_t)(key >> a.bin_shift) : 0u;
+        } else {
+            const uint64_t v = a.in[at];
+            r[k] = in_tile ? v : kRecSentinel;
+            bin[k] = (uint32_t)(r[k] >> a.bin_shift) & (nbins - 1u);
+        }
+    }
+    // rank inside (tile, bin) = what the LDS atomic returns; sentinels add nothing to a spare counter
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const bool real = !(r[k] >> 63);
+        const uint32_t rank = atomicAdd(&s_cnt[real ? bin[k] : nbins], real ? 1u : 0u);
+        bin[k] |= rank << 16;  // a tile has <= 16 384 records: the rank fits 16 bits
+    }
+    __syncthreads();
+    // room in the bins: consecutive lanes take consecutive bins (one coalesced returning atomic per 64 bins)
+    for (uint32_t b = t; b < nbins; b += kSortThreads) {
+        const uint32_t c = s_cnt[b];
+        s_gbase[b] = c ? atomicAdd(&a.cursor[((size_t)seg << a.bin_bits) + b], c) : 0u;
+    }
+    const uint32_t total = block_exclusive_scan<kSortThreads>(s_cnt, nbins, s_wave);  // barriers inside
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k)
+        if (!(r[k] >> 63)) s_rec[s_cnt[bin[k] & 0xFFFFu] + (bin[k] >> 16)] = r[k];
+    __syncthreads();
+    // the tile, grouped by bin: neighbouring lanes write neighbouring records of a bin
+    for (uint32_t i = t; i < total; i += kSortThreads) {
+        const uint64_t x = s_rec[i];
+        // level 0 dropped the region from the record: find the bin of slot i in the scanned counters instead
+        uint32_t b;
+        if (kPairs) {
+            uint32_t lo = 0, hi = nbins;  // last bin whose first slot is <= i (empty bins share a slot with their successor)
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_cnt[mid] <= i) lo = mid; else hi = mid;
+            }
+            b = lo;
+        } else {
+            b = (uint32_t)(x >> a.bin_shift) & (nbins - 1u);
+        }
+        a.out[sg.out_off + s_gbase[b] + (i - s_cnt[b])] = x;
+    }
+}
+
+hipError_t launch_bin_partition(const SortArgs &args, hipStream_t stream)
+{
+    if (args.n_tiles == 0) return hipSuccess;
+    if (args.pair_keys)
+        hipLaunchKernelGGL(bin_partition_kernel<true>, dim3(args.n_tiles), dim3(kSortThreads), 0, stream, args);
+    else
+        hipLaunchKernelGGL(bin_partition_kernel<false>, dim3(args.n_tiles), dim3(kSortThreads), 0, stream, args);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: one bin per workgroup -> vsc_hit records in result order
+// ------------------------------------------------------------------------------------------------
+// kStaged: the contig table fits the LDS copy (a genome has a few dozen contigs, a variant genome millions)
+template <bool kStaged>
+__global__ __launch_bounds__(kSortThreads) void bin_finalize_kernel(const FinArgs a)
+{
+    __shared__ uint64_t s_rec[kSortCap];
+    __shared__ uint32_t s_sub[(1 << kSortSubBits) + 1];
+    __shared__ uint32_t s_contig[kStaged ? kFinalizeContigs : 1];
+    __shared__ uint32_t s_wave[kSortThreads / kWave];
+    const uint32_t t = threadIdx.x;
+    const uint32_t seg = blockIdx.x >> a.bin_bits, bin = blockIdx.x & ((1u << a.bin_bits) - 1u);
+    const SortSeg sg = a.segs[seg];
+    uint64_t src = sg.in_off, dst = sg.final_off;
+    uint32_t n_src = sg.n_in;
+    if (a.hist) {
+        const size_t idx = ((size_t)seg << a.bin_bits) + bin;
+        n_src = a.hist[idx];
+        const uint32_t st = a.bin_start[idx];
+        src = sg.out_off + st;
+        dst = sg.final_off + st;
+    }
+    if (n_src == 0) return;
+    if (n_src > a.cap) {
+        // too large to order in LDS: another partition level takes it (source and destination swap roles)
+        if (t == 0) {
+            const uint32_t slot = atomicAdd(a.n_over, 1u);
+            if (slot < a.over_cap) {
+                SortSeg o;
+                o.in_off = src;
+                o.out_off = src;
+                o.final_off = dst;
+                o.n_in = n_src;
+                o.guide_base = sg.guide_base;
+                a.over[slot] = o;
+            }
+        }
+        return;
+    }
+    const uint32_t nsub = 1u << a.sub_bits;
+    for (uint32_t i = t; i <= nsub; i += kSortThreads) s_sub[i] = 0;
+    if (kStaged)
+        for (uint32_t i = t; i < a.n_contigs; i += kSortThreads) s_contig[i] = a.contig_off[i];
+    __syncthreads();
+    uint64_t r[kSortItems];
+    uint32_t rk[kSortItems];
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {  // branch-free: see bin_partition_kernel
+        const uint32_t i = k * kSortThreads + t;
+        const uint64_t v = a.src[src + (i < n_src ? i : 0u)];
+        r[k] = i < n_src ? v : kRecSentinel;
+    }
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const bool real = !(r[k] >> 63);
+        rk[k] = atomicAdd(&s_sub[real ? (uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u) : nsub], real ? 1u : 0u);
+    }
+    __syncthreads();
+    const uint32_t n = block_exclusive_scan<kSortThreads>(s_sub, nsub, s_wave);  // s_sub[b] = first slot of sub-bin b
+    if (t == 0) s_sub[nsub] = n;
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k)
+        if (!(r[k] >> 63)) s_rec[s_sub[(uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u)] + rk[k]] = r[k];
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += kSortThreads) {
+        const uint32_t i = base + t;
+        const bool live = i < n;
+        const uint64_t x = live ? s_rec[i] : 0ull;
+        const uint32_t sb = (uint32_t)(x >> a.sub_shift) & (nsub - 1u);
+        const uint32_t s = s_sub[sb], e = live ? s_sub[sb + 1] : s;
+        // rank among the records of the sub-bin (a handful: 2-3 on average); keys are unique.  Wave-uniform
+        // trip count, predicated body: per-lane loops cost more in execution-mask bookkeeping than they save.
+        uint32_t smaller = 0;
+        if (a.low_bits) {
+            for (uint32_t d = 0;; ++d) {
+                const uint32_t j = s + d;
+                const bool act = j < e;
+                if (__ballot(act) == 0) break;
+                if (act) smaller += s_rec[j] < x;
+            }
+        }
+        if (!live) continue;
+        const uint32_t pos = (uint32_t)(x >> kRecPosShift);
+        uint32_t c, start;
+        {
+            uint32_t lo = 0, hi = a.n_contigs;  // last contig whose start is <= pos
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((kStaged ? s_contig[mid] : a.contig_off[mid]) <= pos) lo = mid; else hi = mid;
+            }
+            c = lo;
+            start = kStaged ? s_contig[c] : a.contig_off[c];
+        }
+        const uint32_t mask = (uint32_t)x & kMask23;
+        uint4 h;
+        h.x = sg.guide_base + ((uint32_t)(x >> kRecReadShift) & (uint32_t)(kRegionReads - 1));  // vsc_hit.guide
+        h.y = c;                                                                           // .contig
+        h.z = pos - start;                                                                 // .pos
+        h.w = ((uint32_t)(x >> kRecStrandShift) & 1u) << 31 | (uint32_t)__popc(mask) << 23 | mask;  // .info
+        ((uint4 *)a.out)[dst + s + smaller] = h;
+    }
+}
+
+hipError_t launch_bin_finalize(const FinArgs &args, hipStream_t stream)
+{
+    if (args.n_segs == 0) return hipSuccess;
+    const uint64_t blocks = (uint64_t)args.n_segs << args.bin_bits;
+    if (blocks >= (1ull << 31) || args.sub_bits > (uint32_t)kSortSubBits || args.bin_bits > (uint32_t)kSortMaxBinBits ||
+        args.cap > (uint32_t)kSortCap)
+        return hipErrorInvalidValue;
+    if (args.n_contigs <= (uint32_t)kFinalizeContigs)
+        hipLaunchKernelGGL(bin_finalize_kernel<true>, dim3((unsigned)blocks), dim3(kSortThreads), 0, stream, args);
+    else
+        hipLaunchKernelGGL(bin_finalize_kernel<false>, dim3((unsigned)blocks), dim3(kSortThreads), 0, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace vsc
