@@ -610,6 +610,9 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             while (bits > 1 && ((uint64_t)segs.size() << bits) > (1ull << 22)) --bits;  // bounded bin tables
         }
         const size_t n_segs = segs.size();
+        if (std::getenv("VSC_DEBUG_SORT"))
+            std::fprintf(stderr, "[vsc sort] level %u: %zu segments, %llu records, largest %llu, %u bits (of %u left), cap %llu\n", level,
+                         n_segs, (unsigned long long)n_all, (unsigned long long)n_max, bits, rem, (unsigned long long)sort_cap);
         std::vector<uint32_t> tile0(n_segs + 1, 0);
         uint64_t tiles = 0;
         for (size_t i = 0; i < n_segs; ++i) {
@@ -649,6 +652,27 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             VSC_TRY(hipMemsetAsync(a.hist, 0, n_bins * sizeof(uint32_t), st));
             VSC_TRY(launch_bin_hist(a, st));
             VSC_TRY(launch_bin_scan(a, st));
+            if (const char *dbg = std::getenv("VSC_DEBUG_SORT"); dbg && dbg[0] == '2') {
+                // recount every bin on the host and compare with the device histogram
+                std::vector<uint32_t> h(n_bins);
+                VSC_TRY(hipMemcpyAsync(h.data(), a.hist, n_bins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                VSC_TRY(hipStreamSynchronize(st));
+                for (size_t i = 0; i < n_segs; ++i) {
+                    std::vector<uint64_t> recs(segs[i].n_in);
+                    VSC_TRY(hipMemcpy(recs.data(), src + segs[i].in_off, recs.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                    std::vector<uint32_t> want((size_t)1 << bits, 0);
+                    unsigned odd = 0;
+                    for (uint64_t r : recs) {
+                        if (r >> 63) continue;
+                        want[(r >> a.bin_shift) & (((uint64_t)1 << bits) - 1)]++;
+                        if ((r >> kRecPosShift & 0xFFFFFFFFu) > 100000u) odd++;
+                    }
+                    for (size_t b = 0; b < want.size(); ++b)
+                        if (want[b] != h[(i << bits) + b] || odd)
+                            std::fprintf(stderr, "[vsc sort]   seg %zu (in_off %llu n %u) bin %zu: device %u host %u, odd records %u\n", i,
+                                         (unsigned long long)segs[i].in_off, segs[i].n_in, b, h[(i << bits) + b], want[b], odd);
+                }
+            }
             VSC_TRY(launch_bin_partition(a, st));
             rem -= bits;
             f.src = other;

@@ -25,6 +25,16 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Workgroup barrier that also orders LDS accesses.  hipcc (ROCm 7.2, gfx950) leaves out the wait for outstanding
+// LDS operations in front of s_barrier on some paths (seen in bin_hist_kernel, a loop back-edge into a barrier:
+// one wave's ds_add landed after another wave had read and cleared the counter behind the barrier - 64 records
+// missing from a histogram).  With the explicit wait every barrier is safe; use this instead of __syncthreads().
+__device__ __forceinline__ void block_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // reverse complement of a 23-base plane: reverse the bit order, complement (A<->T, C<->G = NOT both planes)

@@ -333,12 +333,12 @@ __global__ __launch_bounds__(1024) void merge_scan_kernel(const uint64_t *bound,
     for (uint32_t k = k0; k < k1; ++k)
         for (uint32_t s = 0; s < n_shards; ++s) sum += bound[(uint64_t)s * (K + 1) + k + 1] - bound[(uint64_t)s * (K + 1) + k];
     partial[t] = sum;
-    __syncthreads();
+    block_sync();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
         const uint64_t v = t >= d ? partial[t - d] : 0;
-        __syncthreads();
+        block_sync();
         partial[t] += v;
-        __syncthreads();
+        block_sync();
     }
     uint64_t run = partial[t] - sum;
     for (uint32_t k = k0; k < k1; ++k) {

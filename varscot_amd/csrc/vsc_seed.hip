@@ -146,12 +146,12 @@ __global__ __launch_bounds__(1024) void seed_pad_scan_kernel(const uint32_t *off
         sum += (off[b + 1] - off[b] + (kGuideUnroll - 1)) & ~(uint32_t)(kGuideUnroll - 1);
     }
     partial[t] = sum;
-    __syncthreads();
+    block_sync();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
         uint32_t v = t >= d ? partial[t - d] : 0;
-        __syncthreads();
+        block_sync();
         partial[t] += v;
-        __syncthreads();
+        block_sync();
     }
     uint32_t run = partial[t] - sum;  // exclusive prefix of this thread's range
     for (uint32_t i = 0; i < per; ++i) {

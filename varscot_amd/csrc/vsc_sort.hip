@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t *s, uint32_t n
         if (lane >= (uint32_t)d) inc += o;
     }
     if (lane == kWave - 1) s_wave[wave] = inc;
-    __syncthreads();
+    block_sync();
     uint32_t before = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < kThreads / kWave; ++w) {
@@ -66,7 +66,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t *s, uint32_t n
             s[t * per + i] = run;
             run += v[i];
         }
-    __syncthreads();
+    block_sync();
     return total;
 }
 
@@ -99,19 +99,19 @@ __global__ __launch_bounds__(kSortThreads) void bin_hist_kernel(const SortArgs a
     const uint32_t t = threadIdx.x;
     const uint32_t nbins = 1u << a.bin_bits;
     for (uint32_t b = t; b < nbins; b += kSortThreads) s_hist[b] = 0;
-    __syncthreads();
+    block_sync();
     const uint32_t tile_begin = blockIdx.x * kHistTiles, tile_end = min(tile_begin + (uint32_t)kHistTiles, a.n_tiles);
     uint32_t seg = segment_of_tile(a.seg_tile0, a.n_segs, tile_begin);
     for (uint32_t tile = tile_begin; tile < tile_end; ++tile) {
         if (tile >= a.seg_tile0[seg + 1]) {
             // the tiles of this block cross into another segment: hand over what was counted so far
-            __syncthreads();
+            block_sync();
             for (uint32_t b = t; b < nbins; b += kSortThreads) {
                 const uint32_t c = s_hist[b];
                 if (c) atomicAdd(&a.hist[((size_t)seg << a.bin_bits) + b], c);
                 s_hist[b] = 0;
             }
-            __syncthreads();
+            block_sync();
             seg = segment_of_tile(a.seg_tile0, a.n_segs, tile);
         }
         const SortSeg sg = a.segs[seg];
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_hist_kernel(const SortArgs a
             }
         }
     }
-    __syncthreads();
+    block_sync();
     for (uint32_t b = t; b < nbins; b += kSortThreads) {
         const uint32_t c = s_hist[b];
         if (c) atomicAdd(&a.hist[((size_t)seg << a.bin_bits) + b], c);
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512) void bin_scan_kernel(const SortArgs a)
     const uint32_t nbins = 1u << a.bin_bits;
     const size_t base = (size_t)blockIdx.x << a.bin_bits;
     for (uint32_t b = threadIdx.x; b < nbins; b += 512) s_cnt[b] = a.hist[base + b];
-    __syncthreads();
+    block_sync();
     block_exclusive_scan<512>(s_cnt, nbins, s_wave);
     for (uint32_t b = threadIdx.x; b < nbins; b += 512) {
         a.bin_start[base + b] = s_cnt[b];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
     const uint32_t first = (blockIdx.x - a.seg_tile0[seg]) * (uint32_t)kSortTile;
     const uint32_t n = min(sg.n_in - first, (uint32_t)kSortTile);
     for (uint32_t b = t; b <= nbins; b += kSortThreads) s_cnt[b] = 0;
-    __syncthreads();
+    block_sync();
     // records of the tile in registers; sentinels (and the slots past the tile) take no part.  Branch-free on
     // purpose (clamped loads + selects): with conditional stores into r[] / bin[] the compiler keeps the arrays
     // as 16-wide vectors, copies them at every branch and spills.
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
         const uint32_t rank = atomicAdd(&s_cnt[real ? bin[k] : nbins], real ? 1u : 0u);
         bin[k] |= rank << 16;  // a tile has <= 16 384 records: the rank fits 16 bits
     }
-    __syncthreads();
+    block_sync();
     // room in the bins: consecutive lanes take consecutive bins (one coalesced returning atomic per 64 bins)
     for (uint32_t b = t; b < nbins; b += kSortThreads) {
         const uint32_t c = s_cnt[b];
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k)
         if (!(r[k] >> 63)) s_rec[s_cnt[bin[k] & 0xFFFFu] + (bin[k] >> 16)] = r[k];
-    __syncthreads();
+    block_sync();
     // the tile, grouped by bin: neighbouring lanes write neighbouring records of a bin
     for (uint32_t i = t; i < total; i += kSortThreads) {
         const uint64_t x = s_rec[i];
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_finalize_kernel(const FinArg
     for (uint32_t i = t; i <= nsub; i += kSortThreads) s_sub[i] = 0;
     if (kStaged)
         for (uint32_t i = t; i < a.n_contigs; i += kSortThreads) s_contig[i] = a.contig_off[i];
-    __syncthreads();
+    block_sync();
     uint64_t r[kSortItems];
     uint32_t rk[kSortItems];
 #pragma unroll
@@ -315,13 +315,13 @@ __global__ __launch_bounds__(kSortThreads) void bin_finalize_kernel(const FinArg
         const bool real = !(r[k] >> 63);
         rk[k] = atomicAdd(&s_sub[real ? (uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u) : nsub], real ? 1u : 0u);
     }
-    __syncthreads();
+    block_sync();
     const uint32_t n = block_exclusive_scan<kSortThreads>(s_sub, nsub, s_wave);  // s_sub[b] = first slot of sub-bin b
     if (t == 0) s_sub[nsub] = n;
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k)
         if (!(r[k] >> 63)) s_rec[s_sub[(uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u)] + rk[k]] = r[k];
-    __syncthreads();
+    block_sync();
     for (uint32_t base = 0; base < n; base += kSortThreads) {
         const uint32_t i = base + t;
         const bool live = i < n;
