@@ -649,6 +649,7 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             a.bin_start = a.cursor + n_bins;
             a.bin_bits = bits;
             a.bin_shift = kRecPosShift + rem - bits;
+            if (tiles >= 64 && !(std::getenv("VSC_SORT_XCD") && std::getenv("VSC_SORT_XCD")[0] == '0')) a.xcd_tiles = (uint32_t)((tiles + 7) / 8);
             VSC_TRY(hipMemsetAsync(a.hist, 0, n_bins * sizeof(uint32_t), st));
             VSC_TRY(launch_bin_hist(a, st));
             VSC_TRY(launch_bin_scan(a, st));

@@ -76,12 +76,12 @@ constexpr uint64_t kRecSentinel = ~0ull;
 // ---- bin sort (vsc_sort.hip) -------------------------------------------------------------------------
 constexpr int kSortThreads = 1024;
 constexpr int kSortItems = 16;
-constexpr int kSortTile = kSortThreads * kSortItems;  // records per partition tile; also the largest bin the
-constexpr int kSortCap = kSortTile;                   // finalize kernel orders in LDS
+constexpr int kSortTile = kSortThreads * kSortItems;  // records per partition tile
+constexpr int kSortCap = kSortTile - 128;             // the largest bin the finalize kernel orders in LDS (records + sub-bin
+                                                      // table fill the CU's 160 KiB)
 constexpr int kSortMaxBinBits = 11;                   // <= 2048 bins per partition level
-constexpr int kSortSubBits = 12;                      // <= 4096 sub-bins inside the finalize kernel
+constexpr int kSortSubBits = 14;                      // <= 16 384 sub-bins inside the finalize kernel
 constexpr int kHistTiles = 8;                         // tiles a block of the histogram kernel walks through
-constexpr int kFinalizeContigs = 1024;                // contig table entries the finalize kernel stages in LDS
 
 // Required plane bits of the two PAM letters, expanded to all-ones / all-zero words.
 struct PamMasks {
@@ -132,6 +132,7 @@ struct SortArgs {
     uint32_t *cursor;              // [n_segs << bin_bits] next free record of every bin (relative to the segment)
     uint32_t *bin_start;           // [n_segs << bin_bits] first record of every bin (relative to the segment)
     uint32_t bin_bits, bin_shift;  // bin = (record >> bin_shift) & ((1 << bin_bits) - 1)
+    uint32_t xcd_tiles;            // partition: tiles per XCD (0: workgroup b takes tile b)
 };
 
 struct FinArgs {

@@ -184,9 +184,17 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
     __shared__ uint32_t s_wave[kSortThreads / kWave];
     const uint32_t t = threadIdx.x;
     const uint32_t nbins = 1u << a.bin_bits;
-    const uint32_t seg = segment_of_tile(a.seg_tile0, a.n_segs, blockIdx.x);
+    // Workgroups are dealt round-robin over the 8 XCDs (workgroup b runs on XCD b % 8).  Each XCD takes a contiguous
+    // eighth of the tiles, i.e. whole regions: the pieces different tiles append to one bin then meet in ONE L2,
+    // which merges them into full lines before they leave for HBM.  (Speed only: nothing depends on the placement.)
+    uint32_t tile = blockIdx.x;
+    if (a.xcd_tiles) {
+        tile = (blockIdx.x & 7u) * a.xcd_tiles + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= a.xcd_tiles || tile >= a.n_tiles) return;
+    }
+    const uint32_t seg = segment_of_tile(a.seg_tile0, a.n_segs, tile);
     const SortSeg sg = a.segs[seg];
-    const uint32_t first = (blockIdx.x - a.seg_tile0[seg]) * (uint32_t)kSortTile;
+    const uint32_t first = (tile - a.seg_tile0[seg]) * (uint32_t)kSortTile;
     const uint32_t n = min(sg.n_in - first, (uint32_t)kSortTile);
     for (uint32_t b = t; b <= nbins; b += kSortThreads) s_cnt[b] = 0;
     block_sync();
@@ -250,24 +258,35 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
 hipError_t launch_bin_partition(const SortArgs &args, hipStream_t stream)
 {
     if (args.n_tiles == 0) return hipSuccess;
+    const unsigned blocks = args.xcd_tiles ? 8u * args.xcd_tiles : args.n_tiles;
     if (args.pair_keys)
-        hipLaunchKernelGGL(bin_partition_kernel<true>, dim3(args.n_tiles), dim3(kSortThreads), 0, stream, args);
+        hipLaunchKernelGGL(bin_partition_kernel<true>, dim3(blocks), dim3(kSortThreads), 0, stream, args);
     else
-        hipLaunchKernelGGL(bin_partition_kernel<false>, dim3(args.n_tiles), dim3(kSortThreads), 0, stream, args);
+        hipLaunchKernelGGL(bin_partition_kernel<false>, dim3(blocks), dim3(kSortThreads), 0, stream, args);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
 // finalize: one bin per workgroup -> vsc_hit records in result order
 // ------------------------------------------------------------------------------------------------
-// kStaged: the contig table fits the LDS copy (a genome has a few dozen contigs, a variant genome millions)
-template <bool kStaged>
+// Sub-bin counters / first slots are 16-bit (a bin has < 2^16 records), two to a word, so that 16 384
+// sub-bins fit beside the records: the finer the sub-bins, the fewer records share one and have to be
+// ranked against each other (at 10 000 records per bin: 0.6 per sub-bin on average instead of 2.5 with
+// 4 096 sub-bins, which made that ranking loop the largest item of the kernel).
+__device__ __forceinline__ uint32_t sub_slot(const uint32_t *s_sub, uint32_t sb)
+{
+    return (s_sub[sb >> 1] >> ((sb & 1u) * 16u)) & 0xFFFFu;
+}
+
+constexpr int kFinalizeNear = 4;    // contigs a bin's position range may touch for the straight-line contig lookup
+constexpr int kFinalizeRange = 64;  // ... for a binary search in LDS (more: in global memory - variant genomes)
+
 __global__ __launch_bounds__(kSortThreads) void bin_finalize_kernel(const FinArgs a)
 {
     __shared__ uint64_t s_rec[kSortCap];
-    __shared__ uint32_t s_sub[(1 << kSortSubBits) + 1];
-    __shared__ uint32_t s_contig[kStaged ? kFinalizeContigs : 1];
+    __shared__ uint32_t s_sub[(1 << kSortSubBits) / 2 + 1];  // packed pairs of 16-bit counters, then first slots
     __shared__ uint32_t s_wave[kSortThreads / kWave];
+    __shared__ uint32_t s_range[2 + kFinalizeRange];  // first contig of the bin's position range, contigs in it, their starts
     const uint32_t t = threadIdx.x;
     const uint32_t seg = blockIdx.x >> a.bin_bits, bin = blockIdx.x & ((1u << a.bin_bits) - 1u);
     const SortSeg sg = a.segs[seg];
@@ -298,38 +317,109 @@ __global__ __launch_bounds__(kSortThreads) void bin_finalize_kernel(const FinArg
         return;
     }
     const uint32_t nsub = 1u << a.sub_bits;
-    for (uint32_t i = t; i <= nsub; i += kSortThreads) s_sub[i] = 0;
-    if (kStaged)
-        for (uint32_t i = t; i < a.n_contigs; i += kSortThreads) s_contig[i] = a.contig_off[i];
+    const uint32_t nwords = nsub > 1u ? nsub / 2u : 1u;
+    for (uint32_t i = t; i <= nwords; i += kSortThreads) s_sub[i] = 0;
     block_sync();
+    const uint64_t *const in = a.src + src;
     uint64_t r[kSortItems];
     uint32_t rk[kSortItems];
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {  // branch-free: see bin_partition_kernel
         const uint32_t i = k * kSortThreads + t;
-        const uint64_t v = a.src[src + (i < n_src ? i : 0u)];
+        const uint64_t v = in[i < n_src ? i : 0u];
         r[k] = i < n_src ? v : kRecSentinel;
     }
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         const bool real = !(r[k] >> 63);
-        rk[k] = atomicAdd(&s_sub[real ? (uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u) : nsub], real ? 1u : 0u);
+        const uint32_t sb = (uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u);
+        const uint32_t sh = (sb & 1u) * 16u;
+        // sentinels (and the slots past the bin) add nothing to the spare word
+        rk[k] = (atomicAdd(&s_sub[real ? sb >> 1 : nwords], real ? 1u << sh : 0u) >> sh) & 0xFFFFu;
     }
     block_sync();
-    const uint32_t n = block_exclusive_scan<kSortThreads>(s_sub, nsub, s_wave);  // s_sub[b] = first slot of sub-bin b
-    if (t == 0) s_sub[nsub] = n;
+    // exclusive scan of the packed counters: a thread owns `per` consecutive words
+    uint32_t n;
+    {
+        const uint32_t per = nwords > (uint32_t)kSortThreads ? nwords / kSortThreads : 1u;  // 1, 2, 4 or 8
+        const bool mine = t * per < nwords;
+        uint32_t w[8];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            w[i] = (mine && (uint32_t)i < per) ? s_sub[t * per + i] : 0u;
+            sum += (w[i] & 0xFFFFu) + (w[i] >> 16);
+        }
+        const uint32_t lane = t % kWave, wave = t / kWave;
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, kWave);
+            if (lane >= (uint32_t)d) inc += o;
+        }
+        if (lane == kWave - 1) s_wave[wave] = inc;
+        block_sync();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < kSortThreads / kWave; ++q) {
+            const uint32_t x = s_wave[q];
+            before += (uint32_t)q < wave ? x : 0u;
+            total += x;
+        }
+        n = total;
+        uint32_t run = before + inc - sum;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t lo = run;
+            run += w[i] & 0xFFFFu;
+            const uint32_t hi = run;
+            run += w[i] >> 16;
+            if (mine && (uint32_t)i < per) s_sub[t * per + i] = lo | (hi << 16);
+        }
+        if (t == 0) {
+            // the end of the last sub-bin (slot nsub: the low half of the spare word, or the high half of the only word)
+            if (nsub > 1u) s_sub[nwords] = n;
+            // contigs the bin's position range touches: keys agree in all bits above the sub-bin and rank fields
+            const uint32_t free_bits = a.sub_bits + a.low_bits;
+            const uint32_t any = (uint32_t)(in[0] >> kRecPosShift);  // sentinels (level 1 without partition) have all bits set: range = everything
+            const uint32_t p_lo = free_bits >= 32u ? 0u : (any >> free_bits) << free_bits;
+            const uint32_t p_hi = free_bits >= 32u ? 0xFFFFFFFFu : p_lo | ((1u << free_bits) - 1u);
+            uint32_t c_lo, c_hi;
+            {
+                uint32_t lo = 0, hi = a.n_contigs;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (a.contig_off[mid] <= p_lo) lo = mid; else hi = mid;
+                }
+                c_lo = lo;
+                hi = a.n_contigs;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (a.contig_off[mid] <= p_hi) lo = mid; else hi = mid;
+                }
+                c_hi = lo;
+            }
+            s_range[0] = c_lo;
+            s_range[1] = c_hi - c_lo + 1u;
+        }
+        block_sync();
+        // their starts (absent: a position no window has)
+        if (t < (uint32_t)kFinalizeRange) s_range[2 + t] = t < s_range[1] ? a.contig_off[s_range[0] + t] : 0xFFFFFFFFu;
+    }
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k)
-        if (!(r[k] >> 63)) s_rec[s_sub[(uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u)] + rk[k]] = r[k];
+        if (!(r[k] >> 63)) s_rec[sub_slot(s_sub, (uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u)) + rk[k]] = r[k];
     block_sync();
+    const uint32_t c_lo = s_range[0], c_n = s_range[1];
+    const uint32_t st0 = s_range[2], st1 = s_range[3], st2 = s_range[4], st3 = s_range[5];
     for (uint32_t base = 0; base < n; base += kSortThreads) {
         const uint32_t i = base + t;
         const bool live = i < n;
         const uint64_t x = live ? s_rec[i] : 0ull;
         const uint32_t sb = (uint32_t)(x >> a.sub_shift) & (nsub - 1u);
-        const uint32_t s = s_sub[sb], e = live ? s_sub[sb + 1] : s;
-        // rank among the records of the sub-bin (a handful: 2-3 on average); keys are unique.  Wave-uniform
-        // trip count, predicated body: per-lane loops cost more in execution-mask bookkeeping than they save.
+        const uint32_t s = sub_slot(s_sub, sb), e = live ? sub_slot(s_sub, sb + 1u) : s;
+        // rank among the records of the sub-bin (keys are unique).  Wave-uniform trip count, predicated body:
+        // per-lane loops cost more in execution-mask bookkeeping than they save.
         uint32_t smaller = 0;
         if (a.low_bits) {
             for (uint32_t d = 0;; ++d) {
@@ -342,14 +432,27 @@ __global__ __launch_bounds__(kSortThreads) void bin_finalize_kernel(const FinArg
         if (!live) continue;
         const uint32_t pos = (uint32_t)(x >> kRecPosShift);
         uint32_t c, start;
-        {
-            uint32_t lo = 0, hi = a.n_contigs;  // last contig whose start is <= pos
+        if (c_n <= (uint32_t)kFinalizeNear) {
+            // the usual case: the bin's positions lie in at most four contigs - three comparisons
+            const uint32_t k = (uint32_t)(pos >= st1) + (uint32_t)(pos >= st2) + (uint32_t)(pos >= st3);
+            c = c_lo + k;
+            start = k == 0 ? st0 : (k == 1 ? st1 : (k == 2 ? st2 : st3));
+        } else if (c_n <= (uint32_t)kFinalizeRange) {
+            uint32_t lo = 0, hi = c_n;  // last contig of the staged range whose start is <= pos
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if ((kStaged ? s_contig[mid] : a.contig_off[mid]) <= pos) lo = mid; else hi = mid;
+                if (s_range[2 + mid] <= pos) lo = mid; else hi = mid;
+            }
+            c = c_lo + lo;
+            start = s_range[2 + lo];
+        } else {
+            uint32_t lo = c_lo, hi = c_lo + c_n;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (a.contig_off[mid] <= pos) lo = mid; else hi = mid;
             }
             c = lo;
-            start = kStaged ? s_contig[c] : a.contig_off[c];
+            start = a.contig_off[c];
         }
         const uint32_t mask = (uint32_t)x & kMask23;
         uint4 h;
@@ -368,10 +471,7 @@ hipError_t launch_bin_finalize(const FinArgs &args, hipStream_t stream)
     if (blocks >= (1ull << 31) || args.sub_bits > (uint32_t)kSortSubBits || args.bin_bits > (uint32_t)kSortMaxBinBits ||
         args.cap > (uint32_t)kSortCap)
         return hipErrorInvalidValue;
-    if (args.n_contigs <= (uint32_t)kFinalizeContigs)
-        hipLaunchKernelGGL(bin_finalize_kernel<true>, dim3((unsigned)blocks), dim3(kSortThreads), 0, stream, args);
-    else
-        hipLaunchKernelGGL(bin_finalize_kernel<false>, dim3((unsigned)blocks), dim3(kSortThreads), 0, stream, args);
+    hipLaunchKernelGGL(bin_finalize_kernel, dim3((unsigned)blocks), dim3(kSortThreads), 0, stream, args);
     return hipGetLastError();
 }
 
