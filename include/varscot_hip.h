@@ -225,6 +225,8 @@ int vsc_hits_free(vsc_hits *hits);
  *   features  : count * 442 bytes = featureMatrixRecord (variant_processing/feature_matrix.h:25-126)
  *               of (guide, off-target in guide orientation), as merge_output_bam.h:696 calls it
  * Any of the three output pointers may be NULL.  guides must be the array passed to vsc_search.
+ * A row range whose scores do not fit the free device memory at once is scored in several passes over
+ * the same scratch buffers (VSC_ERR_NOMEM only if not even 65 536 rows fit).
  */
 int vsc_score_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, const uint64_t *guides,
                    uint32_t n_guides, uint64_t first, uint64_t count, double *mit, uint8_t *mit_flags,
@@ -237,8 +239,10 @@ int vsc_score_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits,
  *   w2..w4  A1..T20, PAMA..PAMT one-hots (bit 4 i + base)
  *   w5..w14 AA1..TT19 one-hots (bit 16 i + pair); the 16 dinucleotide counts are their column sums
  *   w15     0
- * The rows are written to packed_dev (device memory, count * 64 bytes; NULL = library scratch) and,
- * if packed_host is not NULL, copied to the host; mit_host (optional) receives the MIT scores.
+ * The rows are written to packed_dev (device memory, count * 64 bytes) or, if that is NULL, to library
+ * scratch - as many rows per pass as fit the free device memory (a 10 000-read result at 8 mismatches is
+ * 1.6e9 rows = 104 GB) - and, if packed_host is not NULL, copied to the host pass by pass; with neither
+ * destination the rows are computed and dropped (timing runs).  mit_host (optional) receives the MIT scores.
  * vsc_unpack_features expands rows to the dense 442-byte form of vsc_score_hits.
  */
 int vsc_score_hits_packed(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, const uint64_t *guides,
@@ -255,6 +259,35 @@ void vsc_unpack_features(const uint32_t *packed, uint64_t n, uint8_t *features);
  */
 int vsc_score_pairs(vsc_ctx *ctx, const uint64_t *on_targets, const uint64_t *off_targets, const uint32_t *masks,
                     uint64_t n, double *mit, uint8_t *mit_flags, uint8_t *features);
+
+/* ---- variant windows (row R8) ------------------------------------------------------------------- */
+/*
+ * The alt-allele windows of one sample column of a VCF ("SNP genome"), built straight into packed planes:
+ * what `vcf_loader FILE.vcf SNP.fa GENOME.fa SAMPLE SEQLENGTH THREADS` followed by `bidir_index -G SNP.fa`
+ * produce (variant_processing/vcf_loader.cpp:40-68, process_vcf.h:54-269, overlap_sequences.h:35-240,
+ * write_fasta.h:30-470; VARSCOT:296-307) - same windows, same order, same ids, planes byte-identical -
+ * without the FASTA text in between.  Reference segments are copied bit-wise from the reference planes
+ * hi / lo / nmask (whole genome, host memory; contigs / contig_names describe it, a chromosome is found by
+ * the first word of its name as with an FAI index) instead of per-segment FAI reads (write_fasta.h:245-271);
+ * parsing, sweep and window assembly run on `threads` host threads (0 = all).  Host-only, no device needed.
+ * The result is a genome like any other: vsc_genome_load(planes, contigs) + vsc_search.  One call per sample
+ * column replaces one run of the reference pipeline per sample (parallel.py:49-63); the reference genome and
+ * its search are shared between the samples.
+ * err (optional, err_len bytes) receives the text of a failure.
+ */
+typedef struct vsc_windows vsc_windows;
+int vsc_windows_build(const char *vcf_path, uint32_t sample, uint32_t seq_len, uint32_t threads, const uint32_t *hi,
+                      const uint32_t *lo, const uint32_t *nmask, const vsc_contig *contigs, const char *const *contig_names,
+                      uint32_t n_contigs, vsc_windows **out, char *err, size_t err_len);
+uint32_t vsc_windows_count(const vsc_windows *w);            /* windows = contigs of the SNP genome */
+uint64_t vsc_windows_words(const vsc_windows *w);            /* 32-bit words per plane */
+const uint32_t *vsc_windows_plane(const vsc_windows *w, int which); /* 0 hi, 1 lo, 2 nmask */
+const vsc_contig *vsc_windows_contigs(const vsc_windows *w);
+/* id of window i (chr_start_REF / chr_start_ALT_pos_ref_alt..., write_fasta.h:30-65); not NUL-terminated */
+const char *vsc_windows_name(const vsc_windows *w, uint32_t i, uint32_t *len);
+/* count + 1 offsets into the id pool that starts at vsc_windows_name(w, 0, NULL); every id is followed by '\n' */
+const uint64_t *vsc_windows_name_offsets(const vsc_windows *w);
+void vsc_windows_free(vsc_windows *w);
 
 /* ---- classifier ---------------------------------------------------------------------------------- */
 /*

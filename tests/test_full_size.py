@@ -102,3 +102,99 @@ def test_c3_scan_and_seed_agree_on_the_device(big):
     assert bool((seed_mid == _device_records(h_scan)[mid:mid + 1_000_000]).all())
     h_scan.close()
     torch.cuda.empty_cache()
+
+
+def test_c5_streamed_batches_with_packed_scoring(big):
+    """BASELINE.json configs[4] in the shape one GPU runs it: the reads streamed in batches of 5 000 at <= 8
+    mismatches through vsc_search_stream, every batch scored (packed feature rows) from the callback and
+    dropped.  Two batches = the c3 read set, so the batches' digests must add up to the digest of the one
+    c3 search; the packed rows carry totalMismatches = the popcount of the record's mask over read
+    positions 0..20, every row."""
+    ctx, packed, genome, guides, planted = big
+    whole = genome.search(guides, 8, algorithm="seed")
+    want = _digest(whole)
+    whole.close()
+    torch.cuda.empty_cache()
+    seen = []
+
+    def on_batch(h, first, count):
+        n, ascending, max_nm, sums = _digest(h)
+        rec = _device_records(h)
+        assert int(rec[:, 0].min()) >= first and int(rec[:, 0].max()) < first + count
+        rows = torch.empty((n, 16), dtype=torch.int32, device="cuda:0")
+        h.packed_features(to_host=False, dev_ptr=rows.data_ptr())
+        ok = True
+        for b in range(0, n, 1 << 27):
+            info = rec[b:b + (1 << 27), 3]
+            mask = info & 0x7FFFFF
+            strand = (info >> 31) & 1
+            # read positions 0..20 are window positions 0..20 on '+', 2..22 on '-'
+            nonpam = torch.where(strand == 1, mask >> 2, mask & 0x1FFFFF)
+            pop = torch.zeros_like(nonpam)
+            for bit in range(21):
+                pop += (nonpam >> bit) & 1
+            w0 = rows[b:b + (1 << 27), 0]
+            ok = ok and bool((((w0 >> 21) & 31) == pop).all()) and bool(((w0 & 0x1FFFFF).to(torch.int64).ne(0) == pop.ne(0)).all())
+            del info, mask, strand, nonpam, pop, w0
+        seen.append((first, count, n, ascending, max_nm, sums, ok))
+        del rows
+        torch.cuda.empty_cache()
+
+    genome.search_streamed(guides, 8, on_batch, batch=5000, algorithm="seed")
+    assert [(f, c) for f, c, *_ in seen] == [(0, 5000), (5000, 5000)]
+    assert all(asc and nm <= 8 and ok for _, _, _, asc, nm, _, ok in seen)
+    assert sum(s[2] for s in seen) == want[0]
+    assert [sum(s[5][k] for s in seen) for k in range(3)] == want[3]
+    t = ctx.timing()
+    assert t["read_passes"] == 2 and t["hits"] == want[0] and t["score_ms"] > 0
+
+
+def test_c4_variant_windows_at_full_size(big, tmp_path):
+    """BASELINE.json configs[3]: ~5 M SNPs on the 3 Gbp genome -> 8.9 M alt-allele windows built straight from
+    the packed planes (vsc_windows_build) and searched as a second genome with millions of contigs (contig ids
+    beyond 2^23, the finalize kernel's contig lookup in global memory).  Properties: scan == seed on the SNP
+    genome; sorted, unique, NM <= 6; a site that exists only with the ALT allele is found in the ALT window of
+    its SNP and not in the REF window; window bases equal the reference around the SNP."""
+    ctx, packed, genome, guides, planted = big
+    vcf = str(tmp_path / "c4.vcf")
+    n_snps = synth.synthetic_vcf(packed, 5_000_000, vcf)
+    assert n_snps > 4_900_000
+    snp = va.variant_windows(packed, vcf, sample=0)
+    assert len(snp.contigs) > 8_500_000 and int(snp.contigs["length"].max()) < 400
+    # an isolated heterozygous SNP: windows <chr>_<start>_REF and <chr>_<start>_ALT_<pos>_<ref>_<alt>, 45 bases each
+    k = next(i for i in range(4_000_000, 4_100_000)
+             if snp.names[i].endswith("_REF") and int(snp.contigs["length"][i]) == 45 and "_ALT_" in snp.names[i + 1]
+             and int(snp.contigs["length"][i + 1]) == 45 and snp.names[i + 1].count("_") == 6)
+    chrom, start = snp.names[k].split("_")[0], int(snp.names[k].split("_")[1])
+    c_ref = packed.names.index(chrom)
+    ref_seq = packed.decode(int(packed.contigs[c_ref]["offset"]) + start, 45)
+    alt_name = snp.names[k + 1].split("_")
+    assert snp.contig_sequence(k) == ref_seq
+    pos, ref_base, alt_base = int(alt_name[3]), alt_name[4], alt_name[5]
+    assert ref_seq[pos - start] == ref_base
+    assert snp.contig_sequence(k + 1) == ref_seq[:pos - start] + alt_base + ref_seq[pos - start + 1:]
+    # a read that matches the ALT window exactly around the SNP (+ a valid PAM is not guaranteed: take the window's
+    # own 23-mer and let the search decide through the extra-PAM option)
+    alt_seq = snp.contig_sequence(k + 1)
+    off = pos - start - 10  # the SNP sits at read position 10
+    probe = alt_seq[off:off + 23]
+    assert "N" not in probe
+    reads = guides[:999] + [probe]
+    snp_gen = ctx.load_genome(snp)
+    h_seed = snp_gen.search(reads, 6, extra_pam=probe[21:], algorithm="seed")
+    a = h_seed.to_numpy().copy()
+    h_seed.close()
+    h_scan = snp_gen.search(reads, 6, extra_pam=probe[21:], algorithm="scan")
+    b = h_scan.to_numpy().copy()
+    h_scan.close()
+    snp_gen.close()
+    assert len(a) > 100_000 and a.tobytes() == b.tobytes()
+    key = ((a["guide"].astype(np.int64) << 1 | (a["info"] >> 31)) << 24 | a["contig"]) << 9 | a["pos"]
+    assert np.all(np.diff(key) > 0)
+    assert ((a["info"] >> 23) & 31).max() <= 6
+    assert a["contig"].max() > (1 << 23)
+    mine = a[(a["guide"] == 999) & ((a["info"] >> 31) == 0)]
+    exact = mine[((mine["info"] >> 23) & 31) == 0]
+    assert (k + 1, off) in set(zip(exact["contig"].tolist(), exact["pos"].tolist()))
+    one_off = mine[(mine["contig"] == k) & (mine["pos"] == off)]
+    assert len(one_off) == 1 and int(one_off["info"][0]) & 0x7FFFFF == 1 << 10  # REF window: the SNP position mismatches

@@ -606,3 +606,35 @@ def test_streamed_search_equals_one_search(ctx, oracle):
     assert np.array_equal(np.concatenate(rows), want_rows)
     ref = oracle.search_fast(contigs, guides, 6)
     assert hits_as_tuples(got) == hits_as_tuples(ref)
+
+
+def test_scoring_in_several_passes(ctx, oracle, monkeypatch):
+    """vsc_score_hits / vsc_score_hits_packed score a result that does not fit their scratch buffers in several
+    passes (a c3-sized result is 104 GB of packed rows): forced here with passes of 777 rows; scores, flags,
+    dense and packed rows equal the one-pass ones and the oracle's."""
+    rng = np.random.default_rng(1234)
+    guides = random_guides(rng, 30)
+    contigs = make_genome(1234, [90000, 30000], guides, 6, n_plant=400, n_runs=3)
+    gen = ctx.load_genome(va.PackedGenome.from_sequences(contigs))
+    h = gen.search(guides, 6)
+    rec = h.to_numpy()
+    assert len(rec) > 3000
+    one = h.scores(mit=True, features=True)
+    one_rows, one_mit = h.packed_features(mit=True)
+    monkeypatch.setenv("VSC_SCORE_CHUNK", "777")
+    many = h.scores(mit=True, features=True)
+    many_rows, many_mit = h.packed_features(mit=True)
+    sub = h.scores(first=1000, count=1700, mit=True, features=True)
+    h.close()
+    gen.close()
+    for a, b in zip(one, many):
+        assert np.array_equal(a, b)
+    assert np.array_equal(one_rows, many_rows) and np.array_equal(one_mit, many_mit)
+    assert np.array_equal(sub[0], one[0][1000:2700]) and np.array_equal(sub[2], one[2][1000:2700])
+    assert np.array_equal(va.unpack_features(many_rows), one[2])
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    for i in range(0, len(rec), 97):
+        off = contigs[rec["contig"][i]][rec["pos"][i]:rec["pos"][i] + 23]
+        if rec["info"][i] >> 31:
+            off = "".join(comp[c] for c in reversed(off))
+        assert np.array_equal(one[2][i].astype(np.uint32), oracle.feature_row(guides[rec["guide"][i]], off))

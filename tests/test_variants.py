@@ -119,3 +119,57 @@ def test_cli_errors(tmp_path):
     r = subprocess.run([BIN, str(tmp_path / "missing.vcf"), str(tmp_path / "o.fa"), str(tmp_path / "g.fa"), "0", "23", "1"],
                        capture_output=True, text=True)
     assert r.returncode == 1
+
+
+def _fasta_route(tmp_path, vcf, genome, sample):
+    """vcf_loader -> FASTA -> packed planes: the route the windows-from-planes builder must reproduce."""
+    import varscot_amd as va
+    r, text = run_tool(tmp_path, vcf, genome, sample)
+    assert r.returncode == 0, r.stdout + r.stderr
+    names, seqs = [], []
+    for block in text.split(">")[1:]:
+        head, _, body = block.partition("\n")
+        names.append(head)
+        seqs.append(body.replace("\n", ""))
+    return va.PackedGenome.from_sequences(seqs, names)
+
+
+@pytest.mark.parametrize("seed,sample,indel_rate,threads", [(1, 0, 0.0, 1), (2, 1, 0.0, 3), (3, 0, 0.3, 2), (4, 1, 0.5, 8),
+                                                           (5, 0, 0.8, 5), (6, 0, 0.3, 0)])
+def test_windows_from_planes_equal_the_fasta_route(tmp_path, seed, sample, indel_rate, threads):
+    """vsc_windows_build (reference segments copied bit-wise from the packed reference planes, parsing and
+    assembly on several threads) gives the planes, contig table and ids of vcf_loader + bidir_index, byte for
+    byte: SNPs, indels, multi-allelic and unphased records, N runs, variants near contig ends."""
+    import varscot_amd as va
+    rng = np.random.default_rng(1000 + seed)
+    genome = {"chr1": random_seq(rng, 4000), "chr2": random_seq(rng, 2500), "chrUn_x": random_seq(rng, 600)}
+    genome["chr2"] = genome["chr2"][:700] + "N" * 40 + genome["chr2"][740:]
+    vcf = synth_vcf(seed, genome, 260, header_contigs=["chr2", "chr1"] if seed % 2 else None, indel_rate=indel_rate)
+    want = _fasta_route(tmp_path, vcf, genome, sample)
+    ref = va.PackedGenome.from_sequences(list(genome.values()), [n + " some description" for n in genome])
+    got = va.variant_windows(ref, tmp_path / "in.vcf", sample=sample, threads=threads)
+    assert len(got.contigs) == len(want.contigs) > 100
+    assert got.contigs.tobytes() == want.contigs.tobytes()
+    assert list(got.names) == want.names
+    for a, b in ((got.hi, want.hi), (got.lo, want.lo), (got.nmask, want.nmask)):
+        assert a.tobytes() == b.tobytes()
+
+
+def test_windows_from_planes_many_blocks(tmp_path):
+    """More ranges than one work unit takes (4 096), so that the units' bit streams are stitched at arbitrary
+    bit offsets by several threads; plus a chromosome the genome does not have (an error, as in the tool)."""
+    import varscot_amd as va
+    rng = np.random.default_rng(77)
+    genome = {"chrA": random_seq(rng, 900_000), "chrB": random_seq(rng, 300_000)}
+    vcf = synth_vcf(11, genome, 30_000, n_samples=1, indel_rate=0.1, cluster=False)
+    want = _fasta_route(tmp_path, vcf, genome, 0)
+    ref = va.PackedGenome.from_sequences(list(genome.values()), list(genome))
+    got = va.variant_windows(ref, tmp_path / "in.vcf", sample=0, threads=4)
+    assert len(got.contigs) == len(want.contigs) > 20_000
+    assert got.contigs.tobytes() == want.contigs.tobytes()
+    assert got.hi.tobytes() == want.hi.tobytes() and got.lo.tobytes() == want.lo.tobytes() and got.nmask.tobytes() == want.nmask.tobytes()
+    assert got.names[0] == want.names[0] and got.names[len(want.names) - 1] == want.names[-1]
+    assert got.names[12345] == want.names[12345]
+    small = va.PackedGenome.from_sequences([genome["chrA"]], ["chrA"])
+    with pytest.raises(va.VarscotError):
+        va.variant_windows(small, tmp_path / "in.vcf", sample=0)

@@ -81,6 +81,15 @@ SYMBOLS = [
     ("vsc_score_hits_packed", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
     ("vsc_unpack_features", None, [_vp, C.c_uint64, _vp]),
     ("vsc_score_pairs", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    ("vsc_windows_build", C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, C.c_uint32,
+                                    C.POINTER(_vp), C.c_char_p, C.c_size_t]),
+    ("vsc_windows_count", C.c_uint32, [_vp]),
+    ("vsc_windows_words", C.c_uint64, [_vp]),
+    ("vsc_windows_plane", _vp, [_vp, C.c_int]),
+    ("vsc_windows_contigs", _vp, [_vp]),
+    ("vsc_windows_name", _vp, [_vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("vsc_windows_name_offsets", _vp, [_vp]),
+    ("vsc_windows_free", None, [_vp]),
     ("vsc_rf_predict", C.c_int, [_vp, C.POINTER(RfModel), _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     ("vsc_sam_order", None, [_vp, C.c_uint64, _vp, _vp]),
 ]

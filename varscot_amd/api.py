@@ -287,14 +287,16 @@ class Hits:
                                    first, count, ptr(m), ptr(fl), ptr(ft)), self.genome.ctx._h)
         return m, fl, ft
 
-    def packed_features(self, first=0, count=None, to_host=True, mit=False):
+    def packed_features(self, first=0, count=None, to_host=True, mit=False, dev_ptr=None):
         """vsc_score_hits_packed: 64-byte feature rows (uint32[count, 16]) and optionally MIT scores.
-        With to_host=False the rows stay in library scratch on the device (timing / streaming runs)."""
+        dev_ptr: device memory for count * 64 bytes (e.g. a torch tensor's data_ptr()) that receives the rows;
+        without it they pass through library scratch (to_host=False: computed and dropped - timing runs)."""
         count = len(self) - first if count is None else count
         rows = np.empty((count, 16), dtype=np.uint32) if to_host else None
         m = np.empty(count, dtype=np.float64) if mit else None
         check(lib().vsc_score_hits_packed(self.genome.ctx._h, self.genome._h, self._h, ptr(self.codes), len(self.codes),
-                                          first, count, None, ptr(rows), ptr(m)), self.genome.ctx._h)
+                                          first, count, C.c_void_p(dev_ptr) if dev_ptr else None, ptr(rows), ptr(m)),
+              self.genome.ctx._h)
         return rows, m
 
     def close(self):
@@ -337,6 +339,82 @@ def merge_shard_records(ctx, records_ptr, on_device, shard_counts, n_guides):
     check(lib().vsc_hits_merge(ctx._h, C.c_void_p(records_ptr), int(bool(on_device)), ptr(counts), len(counts), n_guides,
                                C.byref(h)), ctx._h)
     return MergedHits(ctx, h)
+
+
+class LazyNames:
+    """The ids of a variant-window genome (millions of them), decoded from the library's name pool on demand."""
+
+    def __init__(self, pool, offsets):
+        self._pool, self._off = pool, offsets
+
+    def __len__(self):
+        return len(self._off) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        return self._pool[int(self._off[i]):int(self._off[i + 1]) - 1].tobytes().decode()
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+def variant_windows(reference, vcf_path, sample=0, seq_len=23, threads=0):
+    """vsc_windows_build: the alt-allele windows of one VCF sample column as a PackedGenome (the "SNP genome"
+    of VARSCOT:296-307), built straight from the reference's packed planes - no FASTA in between."""
+    L = lib()
+    names = (C.c_char_p * len(reference.names))(*[n.encode() for n in reference.names])
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    code = L.vsc_windows_build(str(vcf_path).encode(), sample, seq_len, threads, ptr(reference.hi), ptr(reference.lo),
+                               ptr(reference.nmask), ptr(reference.contigs), names, len(reference.contigs), C.byref(h), err, 512)
+    if code != 0:
+        raise _lib.VarscotError(code, err.value.decode(errors="replace"))
+    owner = _WindowsOwner(h)  # the arrays below are views of the library's memory: it lives as long as they do
+    n, nw = int(L.vsc_windows_count(h)), int(L.vsc_windows_words(h))
+
+    def view(address, ctype, count, dtype):
+        a = np.ctypeslib.as_array(C.cast(address, C.POINTER(ctype)), shape=(count,)).view(dtype)
+        return _OwnedArray.wrap(a, owner)
+
+    out = PackedGenome.__new__(PackedGenome)
+    out.hi, out.lo, out.nmask = (view(L.vsc_windows_plane(h, k), C.c_uint32, nw, np.uint32) for k in range(3))
+    if n:
+        out.contigs = view(L.vsc_windows_contigs(h), C.c_uint8, n * CONTIG_DTYPE.itemsize, CONTIG_DTYPE)
+        offsets = view(L.vsc_windows_name_offsets(h), C.c_uint64, n + 1, np.uint64)
+        pool = view(L.vsc_windows_name(h, 0, None), C.c_uint8, int(offsets[n]), np.uint8)
+        out.names = LazyNames(pool, offsets)
+    else:
+        out.contigs, out.names = np.zeros(0, dtype=CONTIG_DTYPE), []
+    return out
+
+
+class _WindowsOwner:
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().vsc_windows_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class _OwnedArray(np.ndarray):
+    """ndarray view that keeps the owner of its memory alive."""
+
+    @classmethod
+    def wrap(cls, a, owner):
+        v = a.view(cls)
+        v._owner = owner
+        return v
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
 
 
 def unpack_features(rows):

@@ -67,29 +67,91 @@ inline std::vector<std::string> split(const std::string &s, char sep)
     return out;
 }
 
-// One VCF data line -> the record's variants (empty = the sample carries no alternative here).
-inline Record parse_record(const std::vector<std::string> &f, unsigned sample)
+// What `std::istringstream is(text); is >> int; is >> char >> int;` does for a GT field, without the stream
+// (constructing one per line was the largest single cost of parsing a 5-million-record VCF): leading white
+// space skipped, optional sign, decimal digits; no digits = failure, after which every later read fails too.
+struct GtScanner {
+    const char *p, *e;
+    bool ok = true;
+    explicit GtScanner(const std::string &s) : p(s.data()), e(s.data() + s.size()) {}
+    void skip_space()
+    {
+        while (p < e && (*p == ' ' || (*p >= '\t' && *p <= '\r'))) ++p;
+    }
+    bool read_int(int &v)
+    {
+        if (!ok) return false;
+        skip_space();
+        const char *q = p;
+        bool neg = false;
+        if (q < e && (*q == '+' || *q == '-')) neg = *q++ == '-';
+        if (q >= e || *q < '0' || *q > '9') return ok = false;
+        long long x = 0;
+        while (q < e && *q >= '0' && *q <= '9') {
+            if (x < (1ll << 40)) x = x * 10 + (*q - '0');
+            ++q;
+        }
+        p = q;
+        if (x > 2147483647ll) {  // out of range: the stream stores the limit and sets failbit
+            v = neg ? -2147483647 - 1 : 2147483647;
+            return ok = false;
+        }
+        v = (int)(neg ? -x : x);
+        return true;
+    }
+    bool read_char(char &c)
+    {
+        if (!ok) return false;
+        skip_space();
+        if (p >= e) return ok = false;
+        c = *p++;
+        return true;
+    }
+};
+
+// The five columns of a VCF data line that matter (POS, REF, ALT, FORMAT, the sample's column) -> the record's
+// variants (empty = the sample carries no alternative here).
+inline Record parse_columns(const std::string &pos_col, const std::string &ref_col, const std::string &alt_col,
+                            const std::string &format_col, const std::string &sample_col)
 {
     Record out;
-    if (f.size() < 10 || sample >= f.size() - 9) throw std::out_of_range("ERROR: Sample index out of range.");
     Variant base;
-    base.pos = (uint32_t)(std::strtoul(f[1].c_str(), nullptr, 10) - 1);
-    base.ref = dna5(f[3]);
-    const auto fmt = split(f[8], ':');
+    base.pos = (uint32_t)(std::strtoul(pos_col.c_str(), nullptr, 10) - 1);
+    base.ref = dna5(ref_col);
+    // index of GT among the FORMAT keys (0 when absent), then that field of the sample's column
     size_t gt_at = 0;
-    for (size_t i = 0; i < fmt.size(); ++i)
-        if (fmt[i] == "GT") {
-            gt_at = i;
-            break;
+    {
+        size_t i = 0, b = 0;
+        for (;; ++i) {
+            const size_t e = format_col.find(':', b);
+            if (format_col.compare(b, (e == std::string::npos ? format_col.size() : e) - b, "GT") == 0) {
+                gt_at = i;
+                break;
+            }
+            if (e == std::string::npos) break;
+            b = e + 1;
         }
-    const auto geno = split(f[9 + sample], ':');
-    const auto alts = split(f[4], ',');
-    std::istringstream is(gt_at < geno.size() ? geno[gt_at] : std::string());
+    }
+    std::string gt_text;
+    {
+        size_t i = 0, b = 0;
+        for (;; ++i) {
+            const size_t e = sample_col.find(':', b);
+            if (i == gt_at) {
+                gt_text = sample_col.substr(b, e == std::string::npos ? std::string::npos : e - b);
+                break;
+            }
+            if (e == std::string::npos) break;
+            b = e + 1;
+        }
+    }
+    const auto alts = split(alt_col, ',');
+    GtScanner is(gt_text);
     int first = -1, second = -1;
     char sep = 0;
     bool phased = true;
-    if (!(is >> first) || first < 0 || (size_t)first > alts.size()) return out;
-    if ((is >> sep >> second) && second >= 0 && (size_t)second <= alts.size()) {
+    if (!is.read_int(first) || first < 0 || (size_t)first > alts.size()) return out;
+    if ((is.read_char(sep) && is.read_int(second)) && second >= 0 && (size_t)second <= alts.size()) {
         if (sep == '/') phased = false;
     } else {
         second = first;  // haploid call (process_vcf.h:104-108)
@@ -127,6 +189,13 @@ inline Record parse_record(const std::vector<std::string> &f, unsigned sample)
         v.type = v.ref.size() > v.alt.size() ? 2 : (v.ref.size() == v.alt.size() ? 0 : 1);
     }
     return out;
+}
+
+// One VCF data line, split at tabs -> the record's variants.
+inline Record parse_record(const std::vector<std::string> &f, unsigned sample)
+{
+    if (f.size() < 10 || sample >= f.size() - 9) throw std::out_of_range("ERROR: Sample index out of range.");
+    return parse_columns(f[1], f[3], f[4], f[8], f[9 + sample]);
 }
 
 // Reads a VCF.  Chromosome order = ##contig header order, then order of first appearance.

@@ -1196,6 +1196,57 @@ int vsc_hits_free(vsc_hits *hits)
 }
 
 // ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// Rows of scratch a scoring call gets: as many as fit.  Halves the request until the device has room (down
+// to 64 Ki rows), so that a result larger than the free memory is scored in several passes over the same
+// scratch buffers.  VSC_SCORE_CHUNK=n (tests) forces passes of at most n rows.
+hipError_t score_scratch(vsc_ctx *ctx, uint64_t count, size_t mit_bytes, size_t flag_bytes, size_t feat_bytes, uint64_t *rows_out)
+{
+    uint64_t rows = count;
+    if (const char *o = std::getenv("VSC_SCORE_CHUNK")) rows = std::min<uint64_t>(rows, (uint64_t)std::max(1, std::atoi(o)));
+    for (;;) {
+        hipError_t e = hipSuccess;
+        if (mit_bytes) e = ctx->score_mit.ensure(rows * mit_bytes);
+        if (e == hipSuccess && flag_bytes) e = ctx->score_flags.ensure(rows * flag_bytes);
+        if (e == hipSuccess && feat_bytes) e = ctx->score_feat.ensure(rows * feat_bytes);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory || rows <= (1u << 16)) return e;
+        // give back what this attempt got before asking for less
+        ctx->score_mit.release();
+        ctx->score_flags.release();
+        ctx->score_feat.release();
+        rows = (rows + 1) / 2;
+    }
+    *rows_out = rows;
+    return hipSuccess;
+}
+
+hipError_t upload_read_planes(vsc_ctx *ctx, const uint64_t *guides, uint32_t n_guides)
+{
+    std::vector<uint32_t> gp((size_t)std::max<uint32_t>(n_guides, 1) * 2, 0);
+    for (uint32_t i = 0; i < n_guides; ++i) guide_planes(guides[i], &gp[2 * (size_t)i], &gp[2 * (size_t)i + 1]);
+    VSC_TRY(ctx->guides.ensure(gp.size() * sizeof(uint32_t)));
+    VSC_TRY(hipMemcpyAsync(ctx->guides.p, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    return hipStreamSynchronize(ctx->stream);  // gp goes out of scope
+}
+
+void fill_score_args(ScoreArgs &s, vsc_ctx *ctx, const vsc_genome *genome)
+{
+    s.hl = genome->d_hl;
+    s.first_pos = (uint32_t)(genome->first_word * 32);
+    s.n_plane_words = genome->dev_words;
+    s.contig_off = genome->d_contig_off;
+    s.guides = (const uint2 *)ctx->guides.p;
+}
+
+}  // namespace
+
+extern "C" {
+
 int vsc_score_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, const uint64_t *guides,
                    uint32_t n_guides, uint64_t first, uint64_t count, double *mit, uint8_t *mit_flags,
                    uint8_t *features)
@@ -1207,42 +1258,33 @@ int vsc_score_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits,
     ctx->timing.score_ms = 0;
     if (count == 0 || (!mit && !mit_flags && !features)) return VSC_OK;
     VSC_HIP(ctx, hipSetDevice(ctx->device));
-    std::vector<uint32_t> gp((size_t)std::max<uint32_t>(n_guides, 1) * 2, 0);
-    for (uint32_t i = 0; i < n_guides; ++i) guide_planes(guides[i], &gp[2 * (size_t)i], &gp[2 * (size_t)i + 1]);
-    VSC_HIP(ctx, ctx->guides.ensure(gp.size() * sizeof(uint32_t)));
-    VSC_HIP(ctx, hipMemcpyAsync(ctx->guides.p, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    ScoreArgs s{};
-    s.hits = hits->d_records + first;
-    s.n = count;
+    VSC_HIP(ctx, upload_read_planes(ctx, guides, n_guides));
     VSC_HIP(ctx, ensure_hl(ctx, genome));
-    s.hl = genome->d_hl;
-    s.first_pos = (uint32_t)(genome->first_word * 32);
-    s.n_plane_words = genome->dev_words;
-    s.contig_off = genome->d_contig_off;
-    s.guides = (const uint2 *)ctx->guides.p;
-    if (mit) {
-        VSC_HIP(ctx, ctx->score_mit.ensure(count * sizeof(double)));
-        s.mit = (double *)ctx->score_mit.p;
+    uint64_t rows = 0;
+    VSC_HIP(ctx, score_scratch(ctx, count, mit ? sizeof(double) : 0, mit_flags ? 1 : 0, features ? VSC_N_FEATURES : 0, &rows));
+    double total_ms = 0;
+    for (uint64_t done = 0; done < count; done += rows) {  // one pass unless the scratch buffers had to be smaller than the result
+        const uint64_t m = std::min(rows, count - done);
+        ScoreArgs s{};
+        fill_score_args(s, ctx, genome);
+        s.hits = hits->d_records + first + done;
+        s.n = m;
+        if (mit) s.mit = (double *)ctx->score_mit.p;
+        if (mit_flags) s.mit_flags = (uint8_t *)ctx->score_flags.p;
+        if (features) s.features = (uint8_t *)ctx->score_feat.p;
+        VSC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+        VSC_HIP(ctx, launch_score(s, ctx->stream));
+        VSC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+        if (mit) VSC_HIP(ctx, hipMemcpyAsync(mit + done, s.mit, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (mit_flags) VSC_HIP(ctx, hipMemcpyAsync(mit_flags + done, s.mit_flags, m, hipMemcpyDeviceToHost, ctx->stream));
+        if (features)
+            VSC_HIP(ctx, hipMemcpyAsync(features + done * VSC_N_FEATURES, s.features, m * VSC_N_FEATURES, hipMemcpyDeviceToHost, ctx->stream));
+        VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        float ms = 0;
+        VSC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        total_ms += ms;
     }
-    if (mit_flags) {
-        VSC_HIP(ctx, ctx->score_flags.ensure(count));
-        s.mit_flags = (uint8_t *)ctx->score_flags.p;
-    }
-    if (features) {
-        VSC_HIP(ctx, ctx->score_feat.ensure(count * VSC_N_FEATURES));
-        s.features = (uint8_t *)ctx->score_feat.p;
-    }
-    VSC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    VSC_HIP(ctx, launch_score(s, ctx->stream));
-    VSC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    if (mit) VSC_HIP(ctx, hipMemcpyAsync(mit, s.mit, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (mit_flags) VSC_HIP(ctx, hipMemcpyAsync(mit_flags, s.mit_flags, count, hipMemcpyDeviceToHost, ctx->stream));
-    if (features)
-        VSC_HIP(ctx, hipMemcpyAsync(features, s.features, count * VSC_N_FEATURES, hipMemcpyDeviceToHost, ctx->stream));
-    VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    float ms = 0;
-    VSC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-    ctx->timing.score_ms = ms;
+    ctx->timing.score_ms = total_ms;
     return VSC_OK;
 }
 
@@ -1304,37 +1346,33 @@ int vsc_score_hits_packed(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits
     ctx->timing.score_ms = 0;
     if (count == 0) return VSC_OK;
     VSC_HIP(ctx, hipSetDevice(ctx->device));
-    std::vector<uint32_t> gp((size_t)std::max<uint32_t>(n_guides, 1) * 2, 0);
-    for (uint32_t i = 0; i < n_guides; ++i) guide_planes(guides[i], &gp[2 * (size_t)i], &gp[2 * (size_t)i + 1]);
-    VSC_HIP(ctx, ctx->guides.ensure(gp.size() * sizeof(uint32_t)));
-    VSC_HIP(ctx, hipMemcpyAsync(ctx->guides.p, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    ScoreArgs s{};
-    s.hits = hits->d_records + first;
-    s.n = count;
+    VSC_HIP(ctx, upload_read_planes(ctx, guides, n_guides));
     VSC_HIP(ctx, ensure_hl(ctx, genome));
-    s.hl = genome->d_hl;
-    s.first_pos = (uint32_t)(genome->first_word * 32);
-    s.n_plane_words = genome->dev_words;
-    s.contig_off = genome->d_contig_off;
-    s.guides = (const uint2 *)ctx->guides.p;
-    if (mit_host) {
-        VSC_HIP(ctx, ctx->score_mit.ensure(count * sizeof(double)));
-        s.mit = (double *)ctx->score_mit.p;
+    // rows go to the caller's device buffer (whole result, one pass unless the MIT scratch is short) or through
+    // library scratch, as many rows per pass as fit (c3's 1.6e9 rows are 104 GB: several passes)
+    uint64_t rows = 0;
+    VSC_HIP(ctx, score_scratch(ctx, count, mit_host ? sizeof(double) : 0, 0, packed_dev ? 0 : VSC_PACKED_FEATURE_BYTES, &rows));
+    double total_ms = 0;
+    for (uint64_t done = 0; done < count; done += rows) {
+        const uint64_t m = std::min(rows, count - done);
+        ScoreArgs s{};
+        fill_score_args(s, ctx, genome);
+        s.hits = hits->d_records + first + done;
+        s.n = m;
+        if (mit_host) s.mit = (double *)ctx->score_mit.p;
+        uint4 *dst = packed_dev ? (uint4 *)packed_dev + done * 4 : (uint4 *)ctx->score_feat.p;
+        VSC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+        VSC_HIP(ctx, launch_score_packed(s, dst, ctx->stream));
+        VSC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+        if (packed_host)
+            VSC_HIP(ctx, hipMemcpyAsync(packed_host + done * 16, dst, m * VSC_PACKED_FEATURE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+        if (mit_host) VSC_HIP(ctx, hipMemcpyAsync(mit_host + done, s.mit, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        float ms = 0;
+        VSC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        total_ms += ms;
     }
-    uint4 *dst = (uint4 *)packed_dev;
-    if (!dst) {
-        VSC_HIP(ctx, ctx->score_feat.ensure(count * 64));
-        dst = (uint4 *)ctx->score_feat.p;
-    }
-    VSC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    VSC_HIP(ctx, launch_score_packed(s, dst, ctx->stream));
-    VSC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    if (packed_host) VSC_HIP(ctx, hipMemcpyAsync(packed_host, dst, count * 64, hipMemcpyDeviceToHost, ctx->stream));
-    if (mit_host) VSC_HIP(ctx, hipMemcpyAsync(mit_host, s.mit, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    float ms = 0;
-    VSC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-    ctx->timing.score_ms = ms;
+    ctx->timing.score_ms = total_ms;
     return VSC_OK;
 }
 
