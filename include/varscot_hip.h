@@ -260,6 +260,50 @@ void vsc_unpack_features(const uint32_t *packed, uint64_t n, uint8_t *features);
 int vsc_score_pairs(vsc_ctx *ctx, const uint64_t *on_targets, const uint64_t *off_targets, const uint32_t *masks,
                     uint64_t n, double *mit, uint8_t *mit_flags, uint8_t *features);
 
+/* ---- several devices of one node ----------------------------------------------------------------------- */
+/*
+ * The genome-sharded search of one host process over n devices (BASELINE north star: "partitioned across
+ * the 8 GPUs of one node by genome shard with a single RCCL gather of candidate hits"): one vsc_ctx per
+ * entry of device_ids, the planes cut into n tile-aligned position ranges (+ a one-word halo; a window
+ * belongs to the shard that holds its first base), every device searching ALL reads on its shard from its own
+ * host thread, then one exchange - the hit counts by ncclAllGather, the records by one grouped
+ * ncclSend / ncclRecv per shard to the first device, over xGMI - and vsc_hits_merge there.  The result is an
+ * ordinary vsc_hits of the first context (vsc_multi_ctx(m, 0)): same records, same order as one device gives.
+ * This replaces, inside the bidir_mapping process, the OpenMP loop over reads and the concatenation of the
+ * per-thread output buffers (read_mapping/bidir_mapping.cpp:285-295,307-308): the parallel axis is the genome.
+ * RCCL is bound at run time (dlopen) and used when n > 1 distinct devices are given; device ids may repeat
+ * (several contexts on one GPU: tests and rehearsals on a one-GPU box) - the exchange then is device copies.
+ * Environment: VSC_MULTI_RCCL=0 forces copies, =1 insists on RCCL (also for n = 1: a one-rank communicator).
+ */
+typedef struct vsc_multi vsc_multi;
+typedef struct vsc_multi_genome vsc_multi_genome;
+typedef struct {
+    double search_wall_ms;   /* host wall time until the slowest shard's search had returned */
+    double search_ms_max;    /* largest vsc_timing.total_ms among the shards */
+    double exchange_ms;      /* counts + records to the first device (host wall) */
+    double merge_ms;         /* vsc_hits_merge on the first device (host wall) */
+    double total_ms;
+    uint64_t hits;
+    uint64_t exchanged_bytes; /* record bytes that crossed between devices */
+    uint32_t n_devices;
+    uint32_t used_rccl;      /* 1: RCCL carried the exchange, 0: device copies */
+} vsc_multi_timing;
+int vsc_multi_create(const int *device_ids, int n, vsc_multi **out);
+int vsc_multi_destroy(vsc_multi *m);
+int vsc_multi_size(const vsc_multi *m);
+vsc_ctx *vsc_multi_ctx(vsc_multi *m, int i);  /* the i-th context, e.g. for scoring the merged result on context 0 */
+const char *vsc_multi_last_error(const vsc_multi *m);
+int vsc_multi_uses_rccl(const vsc_multi *m);
+int vsc_multi_get_timing(const vsc_multi *m, vsc_multi_timing *out);
+/* hi / lo / nmask: the WHOLE genome's planes (n_words words each); every device receives its shard. */
+int vsc_multi_genome_load(vsc_multi *m, const uint32_t *hi, const uint32_t *lo, const uint32_t *nmask, uint64_t n_words,
+                          const vsc_contig *contigs, uint32_t n_contigs, vsc_multi_genome **out);
+int vsc_multi_genome_free(vsc_multi_genome *g);
+int vsc_multi_genome_build_index(vsc_multi *m, vsc_multi_genome *g, const vsc_search_params *params);
+/* as vsc_search; *out belongs to the first context and is released with vsc_hits_free */
+int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides, uint32_t n_guides,
+                     const vsc_search_params *params, vsc_hits **out);
+
 /* ---- variant windows (row R8) ------------------------------------------------------------------- */
 /*
  * The alt-allele windows of one sample column of a VCF ("SNP genome"), built straight into packed planes:

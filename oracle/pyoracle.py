@@ -55,6 +55,12 @@ def lib():
         L.orc_mit_score.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
         L.orc_feature_row.argtypes = [C.c_char_p, C.c_char_p, u32p]
         L.orc_max_threads.restype = C.c_int
+        L.orc_pigeon_build.restype = C.c_void_p
+        L.orc_pigeon_build.argtypes = [pp, u32p, C.c_uint32]
+        L.orc_pigeon_free.argtypes = [C.c_void_p]
+        L.orc_pigeon_search.restype = C.c_long
+        L.orc_pigeon_search.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_int, C.c_void_p,
+                                        C.c_long, C.POINTER(C.c_long)]
         _lib = L
     return _lib
 
@@ -118,6 +124,46 @@ def count_fast(contigs, guides, max_mm, extra_pam=None, threads=0):
     n = lib().orc_count_fast(arr, lens, len(bufs), g, len(guides), max_mm, _pam(extra_pam), threads,
                              C.byref(sites))
     return n, sites.value
+
+
+class PigeonIndex:
+    """The k-mer tables of vsc_pigeon.c over a text (built once, searched many times)."""
+
+    def __init__(self, contigs):
+        self._bufs, arr, lens = _genome_args(contigs)
+        self._h = lib().orc_pigeon_build(arr, lens, len(self._bufs))
+        if not self._h:
+            raise MemoryError("orc_pigeon_build failed")
+
+    def search(self, guides, max_mm, extra_pam=None, threads=0):
+        """Hits sorted by (guide, strand, contig, pos), and the number of delegate calls."""
+        g = _guides_arg(guides)
+        cand = C.c_long(0)
+        n = lib().orc_pigeon_search(self._h, g, len(guides), max_mm, _pam(extra_pam), threads, None, 0, C.byref(cand))
+        if n < 0:
+            raise ValueError("orc_pigeon_search failed")
+        out = np.zeros(n, dtype=HIT_DTYPE)
+        if n:
+            lib().orc_pigeon_search(self._h, g, len(guides), max_mm, _pam(extra_pam), threads,
+                                    out.ctypes.data_as(C.c_void_p), n, C.byref(cand))
+        return out, cand.value
+
+    def count(self, guides, max_mm, extra_pam=None, threads=0):
+        g = _guides_arg(guides)
+        cand = C.c_long(0)
+        n = lib().orc_pigeon_search(self._h, g, len(guides), max_mm, _pam(extra_pam), threads, None, 0, C.byref(cand))
+        return n, cand.value
+
+    def close(self):
+        if self._h:
+            lib().orc_pigeon_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def search_sam(contigs, contig_names, guides, guide_names, max_mm, extra_pam=None, md_style=0):

@@ -100,6 +100,17 @@ long orc_count_fast(const char *const *contigs, const uint32_t *contig_len, uint
                     int threads, long *sites);
 int orc_max_threads(void);
 
+/* The same search in the reference's algorithmic shape (vsc_pigeon.c): pigeonhole halves with floor(m/2)
+ * substitutions each (read_mapping/bidir_mapping.cpp:129-146,157-162) through a k-mer table of the text,
+ * every occurrence verified by the delegate (:39-126), reads under OpenMP (:285-295).  Build once per text. */
+typedef struct orc_pigeon orc_pigeon;
+orc_pigeon *orc_pigeon_build(const char *const *contigs, const uint32_t *contig_len, uint32_t n_contigs);
+void orc_pigeon_free(orc_pigeon *ix);
+/* Returns the number of hits (stores the first cap, sorted by (guide, strand, contig, pos), when out != NULL);
+ * *candidates = occurrences the delegate was called on. */
+long orc_pigeon_search(const orc_pigeon *ix, const char *reads, uint32_t n_reads, uint32_t max_mm, const char *extra_pam,
+                       int threads, orc_hit *out, long cap, long *candidates);
+
 #ifdef __cplusplus
 }
 #endif

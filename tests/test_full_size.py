@@ -164,7 +164,7 @@ def test_c4_variant_windows_at_full_size(big, tmp_path):
     # an isolated heterozygous SNP: windows <chr>_<start>_REF and <chr>_<start>_ALT_<pos>_<ref>_<alt>, 45 bases each
     k = next(i for i in range(4_000_000, 4_100_000)
              if snp.names[i].endswith("_REF") and int(snp.contigs["length"][i]) == 45 and "_ALT_" in snp.names[i + 1]
-             and int(snp.contigs["length"][i + 1]) == 45 and snp.names[i + 1].count("_") == 6)
+             and int(snp.contigs["length"][i + 1]) == 45 and snp.names[i + 1].count("_") == 5)
     chrom, start = snp.names[k].split("_")[0], int(snp.names[k].split("_")[1])
     c_ref = packed.names.index(chrom)
     ref_seq = packed.decode(int(packed.contigs[c_ref]["offset"]) + start, 45)

@@ -638,3 +638,69 @@ def test_scoring_in_several_passes(ctx, oracle, monkeypatch):
         if rec["info"][i] >> 31:
             off = "".join(comp[c] for c in reversed(off))
         assert np.array_equal(one[2][i].astype(np.uint32), oracle.feature_row(guides[rec["guide"][i]], off))
+
+
+@pytest.mark.parametrize("devices,algo", [([0, 0], "seed"), ([0, 0, 0], "scan"), ([0, 0, 0, 0, 0, 0, 0, 0], "seed")])
+def test_multi_device_search_behind_the_abi(oracle, devices, algo):
+    """vsc_multi_*: N contexts in one process (here all on device 0), genome shards + halo word, concurrent
+    per-shard searches from host threads, one exchange to the first context and the segment merge - the records
+    of one context and of the oracle, including windows that straddle shard boundaries, reads without hits and
+    shards without hits."""
+    rng = np.random.default_rng(700 + len(devices))
+    guides = random_guides(rng, 150)
+    contigs = make_genome(700 + len(devices), [70000, 30000, 33, 9000], guides[:40], 6, n_plant=500, n_runs=4)
+    packed = va.PackedGenome.from_sequences(contigs)
+    # a site across every shard boundary: tile-aligned word ranges
+    for r in range(1, len(devices)):
+        b, _ = packed.shard_words(r, len(devices))
+        at = b * 32 - 11
+        c = int(np.searchsorted(packed.contigs["offset"].astype(np.int64), at, side="right") - 1)
+        local = at - int(packed.contigs[c]["offset"])
+        if 0 <= local <= int(packed.contigs[c]["length"]) - 23:
+            s = contigs[c]
+            contigs[c] = s[:local] + mutate(rng, guides[r], 2, 0, 20) + s[local + 23:]
+    packed = va.PackedGenome.from_sequences(contigs)
+    want = oracle.search_fast(contigs, guides, 6)
+    m = va.MultiContext(devices)
+    try:
+        assert not m.uses_rccl  # repeated device ids: device copies carry the exchange
+        g = m.load_genome(packed)
+        if algo == "seed":
+            g.build_index()
+        h = g.search(guides, 6, algorithm=algo)
+        got = h.to_numpy()
+        t = m.timing()
+        assert t["n_devices"] == len(devices) and t["hits"] == len(want)
+        h.close()
+        h2 = g.search(guides[:10], 3, algorithm=algo)  # a second search on the same objects
+        got2 = h2.to_numpy()
+        h2.close()
+        g.close()
+    finally:
+        m.close()
+    assert len(want) > 500
+    assert got.tobytes() == want.tobytes()
+    assert got2.tobytes() == oracle.search_fast(contigs, guides[:10], 3).tobytes()
+
+
+def test_multi_device_exchange_over_rccl_with_one_rank(oracle, monkeypatch):
+    """The RCCL leg of vsc_multi_search on the one GPU of this box: VSC_MULTI_RCCL=1 sets up a one-rank
+    communicator (ncclCommInitAll), the hit counts go through ncclAllGather and the records through a grouped
+    ncclSend / ncclRecv to the rank itself; the result is the single-context one."""
+    monkeypatch.setenv("VSC_MULTI_RCCL", "1")
+    rng = np.random.default_rng(808)
+    guides = random_guides(rng, 40)
+    contigs = make_genome(808, [50000, 20000], guides, 5, n_plant=300, n_runs=2)
+    want = oracle.search_fast(contigs, guides, 5)
+    m = va.MultiContext([0])
+    try:
+        assert m.uses_rccl
+        g = m.load_genome(va.PackedGenome.from_sequences(contigs))
+        h = g.search(guides, 5, algorithm="seed")
+        got = h.to_numpy()
+        assert m.timing()["used_rccl"] == 1
+        h.close()
+        g.close()
+    finally:
+        m.close()
+    assert len(want) > 200 and got.tobytes() == want.tobytes()

@@ -206,6 +206,28 @@ def test_fast_port_equals_restatement(oracle, seed, max_mm, extra_pam):
     assert n == len(a) and sites > 0
 
 
+# ---------------------------------------------------------------- pigeonhole port == restatement
+@pytest.mark.parametrize("seed,max_mm,extra_pam", [(31, 0, None), (32, 1, None), (33, 3, "AG"), (34, 4, None), (35, 6, None),
+                                                    (36, 7, "TT"), (37, 8, None)])
+def test_pigeonhole_port_equals_restatement(oracle, seed, max_mm, extra_pam):
+    """vsc_pigeon.c - halves with floor(m/2) substitutions through a k-mer table, then the delegate - returns
+    the records of the character-level restatement (both of its formulations), including contig-end windows
+    only the second-half route may report, contigs shorter than a read and N runs."""
+    rng = np.random.default_rng(seed)
+    guides = random_guides(rng, 8) + [random_seq(rng, 23)]
+    contigs = make_genome(seed, [5000, 23, 22, 1200, 64, 2500, 11, 12], guides, max_mm)
+    a = oracle.search(contigs, guides, max_mm, extra_pam)
+    b = oracle.search(contigs, guides, max_mm, extra_pam, mode=oracle.MODE_REFERENCE_FLOW)
+    ix = oracle.PigeonIndex(contigs)
+    for threads in (1, 4):
+        got, candidates = ix.search(guides, max_mm, extra_pam, threads=threads)
+        assert hits_as_tuples(got) == hits_as_tuples(a)
+        assert candidates >= len(a)
+    n, _ = ix.count(guides, max_mm, extra_pam)
+    assert n == len(a) and sorted(hits_as_tuples(b)) == hits_as_tuples(a)
+    ix.close()
+
+
 def test_sam_text(oracle):
     g = "ACGTTGCATGCAAGTCCTAGTGG"
     site = "ACGTTGCATGCAAGTCCTAGTGA"  # GA PAM, 1 mismatch at 22

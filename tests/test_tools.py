@@ -78,6 +78,23 @@ def test_bidir_mapping_sam_equals_oracle(workdir, oracle, md_style, pam):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0"])
+def test_bidir_mapping_over_several_device_contexts(workdir, oracle, devices):
+    """-D with a device list: the genome sharded over that many contexts inside the bidir_mapping process
+    (vsc_multi: per-shard searches on host threads, one gather to the first context, segment merge) - the SAM
+    text is the single-device one, byte for byte.  One GPU here, so the ids repeat; the 12 kb + 5 kb genome leaves
+    the later shards of five without words."""
+    d, names, contigs, gnames, guides = workdir
+    assert run("bidir_index", "-G", str(d / "genome.fa"), "-I", str(d / "idx")).returncode == 0
+    args = ["-G", str(d / "genome.fa"), "-I", str(d / "idx"), "-R", str(d / "reads.fa"), "-M", "6", "-O", str(d / "out.sam"),
+            "-D", devices]
+    r = run("bidir_mapping", *args)
+    assert r.returncode == 0, r.stderr
+    assert open(d / "out.sam").read() == oracle.search_sam(contigs, names, guides, gnames, 6, None, 0)
+    assert run("bidir_mapping", *args[:-1], "0,x").returncode == 1
+
+
+@pytest.mark.gpu
 def test_bidir_mapping_unwritable_output(workdir):
     d, *_ = workdir
     run("bidir_index", "-G", str(d / "genome.fa"), "-I", str(d / "idx"))

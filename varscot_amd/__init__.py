@@ -5,7 +5,7 @@ include/varscot_hip.h); this package is the thin host-side mirror used by tests,
 Python entry points.  There is no CPU fallback: without the built library importing fails.
 """
 from ._lib import HIT_DTYPE, CONTIG_DTYPE, N_FEATURES, LIB_PATH, VarscotError, lib  # noqa: F401
-from .api import (Context, Genome, Hits, PackedGenome, device_count, pack_guides, sam_order,  # noqa: F401
+from .api import (Context, Genome, Hits, MultiContext, PackedGenome, device_count, pack_guides, sam_order,  # noqa: F401
                   unpack_features, variant_windows)
 
 lib()  # fail loudly at import time if the HIP extension is missing

@@ -46,6 +46,15 @@ class Timing(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
+class MultiTiming(C.Structure):
+    _fields_ = [("search_wall_ms", C.c_double), ("search_ms_max", C.c_double), ("exchange_ms", C.c_double),
+                ("merge_ms", C.c_double), ("total_ms", C.c_double), ("hits", C.c_uint64), ("exchanged_bytes", C.c_uint64),
+                ("n_devices", C.c_uint32), ("used_rccl", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32)  # vsc_batch_fn
 
 # every symbol include/varscot_hip.h declares: (name, restype, argtypes)
@@ -81,6 +90,17 @@ SYMBOLS = [
     ("vsc_score_hits_packed", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
     ("vsc_unpack_features", None, [_vp, C.c_uint64, _vp]),
     ("vsc_score_pairs", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    ("vsc_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
+    ("vsc_multi_destroy", C.c_int, [_vp]),
+    ("vsc_multi_size", C.c_int, [_vp]),
+    ("vsc_multi_ctx", _vp, [_vp, C.c_int]),
+    ("vsc_multi_last_error", C.c_char_p, [_vp]),
+    ("vsc_multi_uses_rccl", C.c_int, [_vp]),
+    ("vsc_multi_get_timing", C.c_int, [_vp, C.POINTER(MultiTiming)]),
+    ("vsc_multi_genome_load", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32, C.POINTER(_vp)]),
+    ("vsc_multi_genome_free", C.c_int, [_vp]),
+    ("vsc_multi_genome_build_index", C.c_int, [_vp, _vp, C.POINTER(SearchParams)]),
+    ("vsc_multi_search", C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(SearchParams), C.POINTER(_vp)]),
     ("vsc_windows_build", C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, C.c_uint32,
                                     C.POINTER(_vp), C.c_char_p, C.c_size_t]),
     ("vsc_windows_count", C.c_uint32, [_vp]),

@@ -341,6 +341,96 @@ def merge_shard_records(ctx, records_ptr, on_device, shard_counts, n_guides):
     return MergedHits(ctx, h)
 
 
+class MultiContext:
+    """vsc_multi: the genome-sharded search of ONE process over several devices behind the C ABI (one context per
+    entry of `devices`; ids may repeat - several contexts on one GPU).  search() returns the merged records on
+    the first context."""
+
+    def __init__(self, devices):
+        ids = (C.c_int * len(devices))(*devices)
+        self._h = C.c_void_p()
+        check(lib().vsc_multi_create(ids, len(devices), C.byref(self._h)))
+        self.devices = list(devices)
+        self._genomes = weakref.WeakSet()
+        self._results = weakref.WeakSet()
+
+    def _check(self, code):
+        if code != 0:
+            raise _lib.VarscotError(code, lib().vsc_multi_last_error(self._h).decode(errors="replace"))
+
+    @property
+    def uses_rccl(self):
+        return bool(lib().vsc_multi_uses_rccl(self._h))
+
+    def timing(self):
+        t = _lib.MultiTiming()
+        self._check(lib().vsc_multi_get_timing(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def load_genome(self, packed):
+        g = MultiGenome(self, packed)
+        self._genomes.add(g)
+        return g
+
+    def close(self):
+        if self._h:
+            for r in list(self._results):
+                r.close()
+            for g in list(self._genomes):
+                g.close()
+            lib().vsc_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _BorrowedContext:
+    """The first context of a MultiContext as far as a result object needs it (owned by the vsc_multi)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._children = weakref.WeakSet()
+
+
+class MultiGenome:
+    def __init__(self, multi, packed):
+        self.multi, self.packed = multi, packed
+        self._h = C.c_void_p()
+        hi, lo, nm = (np.ascontiguousarray(a, dtype=np.uint32) for a in (packed.hi, packed.lo, packed.nmask))
+        contigs = np.ascontiguousarray(packed.contigs, dtype=CONTIG_DTYPE)
+        multi._check(lib().vsc_multi_genome_load(multi._h, ptr(hi), ptr(lo), ptr(nm), len(hi), ptr(contigs), len(contigs),
+                                                 C.byref(self._h)))
+
+    def build_index(self, extra_pam=None):
+        p = Genome._params(0, extra_pam, ALGO_SEED)
+        self.multi._check(lib().vsc_multi_genome_build_index(self.multi._h, self._h, C.byref(p)))
+
+    def search(self, guides, max_mismatches, extra_pam=None, algorithm="auto"):
+        codes = guides if isinstance(guides, np.ndarray) else pack_guides(guides)
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        p = Genome._params(max_mismatches, extra_pam, algorithm)
+        h = C.c_void_p()
+        self.multi._check(lib().vsc_multi_search(self.multi._h, self._h, ptr(codes), len(codes), C.byref(p), C.byref(h)))
+        res = MergedHits(_BorrowedContext(C.c_void_p(lib().vsc_multi_ctx(self.multi._h, 0))), h)
+        self.multi._results.add(res)
+        return res
+
+    def close(self):
+        if self._h:
+            lib().vsc_multi_genome_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class LazyNames:
     """The ids of a variant-window genome (millions of them), decoded from the library's name pool on demand."""
 

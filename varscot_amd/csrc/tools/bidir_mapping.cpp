@@ -21,7 +21,8 @@ int main(int argc, char **argv)
         {'T', "threads", "Number of threads (accepted for compatibility; the GPU replaces the OpenMP loop)", false},
         {'O', "output", "Path to output SAM file", false},
         {'P', "pam", "Additional non-canonical PAM that should be allowed for off-target search besides (N)GG and (N)GA (default).", false},
-        {'D', "device", "HIP device index (default 0)", false},
+        {'D', "device", "HIP device index (default 0), or a comma-separated list (0,1,2,...): the genome is sharded over these "
+                        "devices, each searches all reads, one RCCL gather brings the hits to the first", false},
         {'S', "md-style", "0 = SAM-spec MD strings (default), 1 = no zeros between adjacent mismatches", false},
     };
     const int pr = parse_args(argc, argv, opts, "Read mapping",
@@ -45,11 +46,30 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "Error: Maximum number of mismatches must lie between 0 and 8.\n");
         return 1;
     }
-    const int device = opts[7].set ? std::atoi(opts[7].value.c_str()) : 0;
+    std::vector<int> devices;  // -D 0 | -D 0,1,2,3 (an id may repeat: several shards on one device)
+    {
+        const std::string d = opts[7].set ? opts[7].value : "0";
+        size_t b = 0;
+        for (;;) {
+            const size_t e = d.find(',', b);
+            const std::string item = d.substr(b, e == std::string::npos ? std::string::npos : e - b);
+            char *iend = nullptr;
+            const long v = std::strtol(item.c_str(), &iend, 10);
+            if (item.empty() || *iend || v < 0) {
+                std::fprintf(stderr, "%s: bad device list '%s'\n", argv[0], d.c_str());
+                return 1;
+            }
+            devices.push_back((int)v);
+            if (e == std::string::npos) break;
+            b = e + 1;
+        }
+    }
     const int md_style = opts[8].set ? std::atoi(opts[8].value.c_str()) : 0;
 
     vsc_ctx *ctx = nullptr;
     vsc_genome *genome = nullptr;
+    vsc_multi *multi = nullptr;
+    vsc_multi_genome *mgenome = nullptr;
     vsc_hits *hits = nullptr;
     int rc = 1;
     try {
@@ -62,11 +82,21 @@ int main(int argc, char **argv)
             codes[i] = vsc_pack_guide(reads[i].seq.c_str());
         }
         const PackedIndex ix = read_index(index_prefix);
-        int st = vsc_ctx_create(device, &ctx);
-        if (st != VSC_OK) throw std::runtime_error(st == VSC_ERR_NODEVICE ? "no HIP device available (there is no CPU fallback)" : "could not create the device context");
-        st = vsc_genome_load(ctx, ix.hi.data(), ix.lo.data(), ix.nm.data(), 0, ix.hi.size(), ix.hi.size(), ix.contigs.data(),
-                             (uint32_t)ix.contigs.size(), &genome);
-        if (st != VSC_OK) throw std::runtime_error(vsc_last_error(ctx));
+        int st;
+        if (devices.size() == 1) {
+            st = vsc_ctx_create(devices[0], &ctx);
+            if (st != VSC_OK) throw std::runtime_error(st == VSC_ERR_NODEVICE ? "no HIP device available (there is no CPU fallback)" : "could not create the device context");
+            st = vsc_genome_load(ctx, ix.hi.data(), ix.lo.data(), ix.nm.data(), 0, ix.hi.size(), ix.hi.size(), ix.contigs.data(),
+                                 (uint32_t)ix.contigs.size(), &genome);
+            if (st != VSC_OK) throw std::runtime_error(vsc_last_error(ctx));
+        } else {
+            st = vsc_multi_create(devices.data(), (int)devices.size(), &multi);
+            if (st != VSC_OK) throw std::runtime_error(st == VSC_ERR_NODEVICE ? "no HIP device available (there is no CPU fallback)" : "could not create the device contexts");
+            st = vsc_multi_genome_load(multi, ix.hi.data(), ix.lo.data(), ix.nm.data(), ix.hi.size(), ix.contigs.data(),
+                                       (uint32_t)ix.contigs.size(), &mgenome);
+            if (st != VSC_OK) throw std::runtime_error(vsc_multi_last_error(multi));
+            ctx = vsc_multi_ctx(multi, 0);  // owns the merged result
+        }
         std::printf("Index loaded.\n");
 
         vsc_search_params p{};
@@ -76,8 +106,13 @@ int main(int argc, char **argv)
             p.extra_pam[0] = pam[0];
             p.extra_pam[1] = pam[1];
         }
-        st = vsc_search(ctx, genome, codes.data(), (uint32_t)codes.size(), &p, &hits);
-        if (st != VSC_OK) throw std::runtime_error(vsc_last_error(ctx));
+        if (multi) {
+            st = vsc_multi_search(multi, mgenome, codes.data(), (uint32_t)codes.size(), &p, &hits);
+            if (st != VSC_OK) throw std::runtime_error(vsc_multi_last_error(multi));
+        } else {
+            st = vsc_search(ctx, genome, codes.data(), (uint32_t)codes.size(), &p, &hits);
+            if (st != VSC_OK) throw std::runtime_error(vsc_last_error(ctx));
+        }
         const uint64_t n = vsc_hits_count(hits);
         const vsc_hit *h = nullptr;
         st = vsc_hits_data(hits, &h);
@@ -114,7 +149,12 @@ int main(int argc, char **argv)
         rc = 1;
     }
     vsc_hits_free(hits);
-    vsc_genome_free(genome);
-    vsc_ctx_destroy(ctx);
+    if (multi) {
+        vsc_multi_genome_free(mgenome);
+        vsc_multi_destroy(multi);
+    } else {
+        vsc_genome_free(genome);
+        vsc_ctx_destroy(ctx);
+    }
     return rc;
 }

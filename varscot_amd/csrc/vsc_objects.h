@@ -1,0 +1,91 @@
+// vsc_objects.h - the objects behind the opaque handles of include/varscot_hip.h, shared by the host-side
+// translation units of the library (vsc_api.cpp, vsc_multi.cpp).  Not installed.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "vsc_internal.h"
+
+namespace vsc {
+
+struct DeviceBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    // hipMalloc / hipFree of multi-GB buffers cost hundreds of milliseconds: grow with 1/8 headroom so
+    // that result sizes that wobble from search to search do not reallocate every time
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess && want != bytes) {
+            (void)hipGetLastError();
+            want = bytes;
+            e = hipMalloc(&p, want);
+        }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace vsc
+
+struct vsc_ctx {
+    int device = 0;
+    int n_cus = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::string err;
+    vsc_timing timing{};
+    // keys_a / keys_b: the two record buffers the bin sort alternates between (keys_a + vals_a: the scan's (key, value) pairs)
+    vsc::DeviceBuf counters, guides, keys_a, keys_b, vals_a, sort_temp, score_mit, score_flags, score_feat;
+    vsc::DeviceBuf sort_segs, sort_tabs, sort_over;  // bin sort: segment table + tile starts, per-bin tables, oversize list + counter
+    vsc::DeviceBuf seed_k1, seed_k2, seed_v1, seed_v2, seed_off, seed_poff, seed_lrest;  // per-search read lists
+    // record buffers of freed results, kept for the next search: hipMalloc / hipFree of tens of GB
+    // cost hundreds of milliseconds each
+    std::vector<vsc::DeviceBuf> spare_records;
+};
+
+struct vsc_genome {
+    vsc_ctx *ctx = nullptr;
+    uint32_t *d_hi = nullptr, *d_lo = nullptr, *d_nm = nullptr;
+    uint32_t *d_contig_off = nullptr, *d_contig_end = nullptr;
+    uint2 *d_hl = nullptr;  // interleaved planes, built on first scoring call
+    uint64_t first_word = 0, own_words = 0, dev_words = 0;
+    uint32_t n_tiles = 0, n_contigs = 0;
+    uint64_t device_bytes = 0;
+    uint64_t sites = 0;  // PAM-valid windows seen by the last scan (sizes the next hit buffer)
+    // seed index (vsc_seed.hip): the PAM-valid sites filed once per segment, sorted by bucket
+    bool has_index = false;
+    uint8_t index_has_extra_pam = 0;
+    char index_extra_pam[2] = {0, 0};
+    uint64_t index_sites = 0;  // S
+    uint32_t *d_ix_bucket_start = nullptr;
+    uint4 *d_ix_chunk_tab = nullptr;
+    uint32_t *d_ix_vert = nullptr;  // bit-sliced blocks of 32 sites
+    uint4 *d_ix_sites = nullptr;    // 16-byte site records
+    uint32_t ix_chunks = 0;
+    uint64_t index_bytes = 0;
+    double index_ms = 0;
+};
+
+struct vsc_hits {
+    vsc_ctx *ctx = nullptr;
+    vsc_hit *d_records = nullptr;
+    vsc::DeviceBuf storage;  // owns d_records
+    uint64_t n = 0;
+    std::vector<vsc_hit> host;
+    bool host_valid = false;
+};
+
