@@ -144,7 +144,8 @@ def test_c5_streamed_batches_with_packed_scoring(big):
     assert [(f, c) for f, c, *_ in seen] == [(0, 5000), (5000, 5000)]
     assert all(asc and nm <= 8 and ok for _, _, _, asc, nm, _, ok in seen)
     assert sum(s[2] for s in seen) == want[0]
-    assert [sum(s[5][k] for s in seen) for k in range(3)] == want[3]
+    # (the checksums are sums of 64-bit integers that wrap inside torch: equal modulo 2^64 however they are chunked)
+    assert [sum(s[5][k] for s in seen) % (1 << 64) for k in range(3)] == [x % (1 << 64) for x in want[3]]
     t = ctx.timing()
     assert t["read_passes"] == 2 and t["hits"] == want[0] and t["score_ms"] > 0
 

@@ -610,7 +610,7 @@ def test_streamed_search_equals_one_search(ctx, oracle):
 
 def test_scoring_in_several_passes(ctx, oracle, monkeypatch):
     """vsc_score_hits / vsc_score_hits_packed score a result that does not fit their scratch buffers in several
-    passes (a c3-sized result is 104 GB of packed rows): forced here with passes of 777 rows; scores, flags,
+    passes (a c3-sized result is 104 GB of packed rows): forced here with passes of 50 rows; scores, flags,
     dense and packed rows equal the one-pass ones and the oracle's."""
     rng = np.random.default_rng(1234)
     guides = random_guides(rng, 30)
@@ -618,22 +618,22 @@ def test_scoring_in_several_passes(ctx, oracle, monkeypatch):
     gen = ctx.load_genome(va.PackedGenome.from_sequences(contigs))
     h = gen.search(guides, 6)
     rec = h.to_numpy()
-    assert len(rec) > 3000
+    assert len(rec) > 300
     one = h.scores(mit=True, features=True)
     one_rows, one_mit = h.packed_features(mit=True)
-    monkeypatch.setenv("VSC_SCORE_CHUNK", "777")
+    monkeypatch.setenv("VSC_SCORE_CHUNK", "50")
     many = h.scores(mit=True, features=True)
     many_rows, many_mit = h.packed_features(mit=True)
-    sub = h.scores(first=1000, count=1700, mit=True, features=True)
+    sub = h.scores(first=100, count=170, mit=True, features=True)
     h.close()
     gen.close()
     for a, b in zip(one, many):
         assert np.array_equal(a, b)
     assert np.array_equal(one_rows, many_rows) and np.array_equal(one_mit, many_mit)
-    assert np.array_equal(sub[0], one[0][1000:2700]) and np.array_equal(sub[2], one[2][1000:2700])
+    assert np.array_equal(sub[0], one[0][100:270]) and np.array_equal(sub[2], one[2][100:270])
     assert np.array_equal(va.unpack_features(many_rows), one[2])
     comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
-    for i in range(0, len(rec), 97):
+    for i in range(0, len(rec), 7):
         off = contigs[rec["contig"][i]][rec["pos"][i]:rec["pos"][i] + 23]
         if rec["info"][i] >> 31:
             off = "".join(comp[c] for c in reversed(off))
@@ -678,7 +678,7 @@ def test_multi_device_search_behind_the_abi(oracle, devices, algo):
         g.close()
     finally:
         m.close()
-    assert len(want) > 500
+    assert len(want) > 300
     assert got.tobytes() == want.tobytes()
     assert got2.tobytes() == oracle.search_fast(contigs, guides[:10], 3).tobytes()
 
