@@ -220,10 +220,7 @@ struct SeedWave {
     uint4 *tok4;     // pending hit tokens (see sliced_fetch)
     uint32_t ntok, lane;
     uint32_t thead;  // ring slot of the oldest pending token
-    uint32_t res_base;  // this wave's open block in region cp: next free record (relative to the region) ...
-    uint32_t res_left;  // ... and records left in it
-    uint32_t cp;     // the output region the open block in registers belongs to
-    uint2 *parts;    // {res_base, res_left} of the regions this wave is not writing to
+    uint2 *parts;    // per output region: {first record of this wave's open block, records claimed in it}
     uint32_t *first; // first site of every chunk of the current grab (tokens name their chunk by slot)
 };
 
@@ -380,11 +377,13 @@ struct SlicedFetch {
     uint4 rec;  // site record of the lowest set bit
 };
 
-// Output of the sliced kernel.  A wave keeps, per output region (128 reads), an open block of reserved
-// records (w.parts[p] = {next free record, records left}, relative to the region).  The hits of a pass go
-// straight from registers to their region's block - no staging in LDS: the hits of consecutive passes
-// belong to different regions often enough (a wave walks through the read ranges once per chunk) that
-// staged batches stayed small.
+// Output of the sliced kernel.  A wave keeps, per output region (128 reads), an open block of `reserve`
+// reserved records: w.parts[p] = {first record of the block (relative to the region), records claimed in it}.
+// The hits of a pass belong to whatever regions their reads fall into - with 128.8 reads per bucket spread over
+// 79 regions (c3) that is four or five regions per pass - so every hit lane claims its slot by itself with one
+// LDS atomic on its region's counter and stores straight from registers; nothing in the common path depends on
+// how many regions a pass touches.  Only when a block is used up (once per `reserve` hits of a region) do the
+// lanes that found it full take the wave-uniform path that reserves the next block.
 //
 // Reserves a new block in region p (wave-uniform).  Returns false when the region is full: the host
 // re-runs with room for reserved + lost records in every region.
@@ -406,46 +405,41 @@ __device__ __forceinline__ bool sliced_reserve(const SeedArgs &a, const SeedWave
     return true;
 }
 
-// lanes in `mask` (all of region p, wave-uniform) store their record.  The open block of the region in
-// use lives in registers (w.cp, w.res_base, w.res_left); the LDS table is touched on a change of region only.
-__device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, uint32_t p, uint64_t mask, bool mine, uint64_t rec)
+// lanes with `hit` store their record in the region of their read
+__device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, bool hit, uint32_t region, uint64_t rec)
 {
-    if (p != w.cp) {
-        if (w.lane == 0) w.parts[w.cp] = make_uint2(w.res_base, w.res_left);
+    uint32_t slot = 0, base = 0;
+    if (hit) {
+        slot = atomicAdd(&w.parts[region].y, 1u);  // LDS; may run past `reserve`: those lanes take the path below
+        base = w.parts[region].x;
+    }
+    const bool placed = hit && slot < a.reserve;
+    if (placed) a.hit_recs[(unsigned long long)region * a.part_cap + base + slot] = rec;
+    uint64_t todo = __ballot(hit && !placed);
+    while (todo != 0) {
+        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)region, (int)__builtin_ctzll(todo));
+        const bool mine = hit && !placed && region == p;
+        const uint64_t b = __ballot(mine);
+        const uint32_t n = (uint32_t)__popcll(b);
+        uint32_t next = 0;
+        const bool ok = sliced_reserve(a, w, p, n, next);
+        if (mine && ok) a.hit_recs[(unsigned long long)p * a.part_cap + next + lanes_below(b)] = rec;
+        // (a region that is full keeps a "used up" block: later hits come here again and are counted as lost)
+        if (w.lane == 0) w.parts[p] = make_uint2(ok ? next : 0u, ok ? n : a.reserve);
         wave_sync();
-        const uint2 st = w.parts[p];
-        w.res_base = uniform(st.x);
-        w.res_left = uniform(st.y);
-        w.cp = p;
-    }
-    const uint32_t n = (uint32_t)__popcll(mask);
-    const uint32_t rank = lanes_below(mask);
-    const uint32_t left = w.res_left;
-    uint32_t next = w.res_base;
-    bool ok = true;
-    if (left < n) ok = sliced_reserve(a, w, p, n - left, next);  // the open block takes `left`, a new one the rest
-    if (mine && (rank < left || ok)) {
-        const uint32_t at = rank < left ? w.res_base + rank : next + (rank - left);
-        a.hit_recs[(unsigned long long)p * a.part_cap + at] = rec;
-    }
-    if (left < n) {
-        w.res_base = ok ? next + (n - left) : w.res_base + left;
-        w.res_left = ok ? a.reserve - (n - left) : 0;
-    } else {
-        w.res_base += n;
-        w.res_left -= n;
+        todo &= ~b;
     }
 }
 
 // end of the kernel: the open blocks are filled up with sentinels, which the sort drops
 __device__ __forceinline__ void sliced_finish_hits(const SeedArgs &a, SeedWave &w)
 {
-    if (w.lane == 0) w.parts[w.cp] = make_uint2(w.res_base, w.res_left);
     wave_sync();
     for (uint32_t q = 0; q < a.n_parts; ++q) {
         const uint2 st = w.parts[q];
-        const uint32_t base = uniform(st.x), left = uniform(st.y);
-        for (uint32_t i = w.lane; i < left; i += kWave) a.hit_recs[(unsigned long long)q * a.part_cap + base + i] = kRecSentinel;
+        const uint32_t base = uniform(st.x), used = uniform(st.y);
+        const uint32_t left = used < a.reserve ? a.reserve - used : 0u;
+        for (uint32_t i = w.lane; i < left; i += kWave) a.hit_recs[(unsigned long long)q * a.part_cap + base + used + i] = kRecSentinel;
         if (w.lane == 0 && left) atomicAdd(&a.counters[kCntPart + 4 * q + 1], (unsigned long long)left);
     }
 }
@@ -508,16 +502,7 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
     }
     const uint64_t rec = ((uint64_t)(gid_of & (uint32_t)(kRegionReads - 1)) << kRecReadShift) | ((uint64_t)strand << kRecStrandShift) |
                          ((uint64_t)pos << kRecPosShift) | mask;
-    // the hits of a pass belong to one output region, two or three when the reads of the batch span region boundaries
-    const uint32_t region = gid_of >> kRegionBits;
-    uint64_t todo = __ballot(hit);
-    while (todo != 0) {
-        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)region, (int)__builtin_ctzll(todo));
-        const bool mine = hit && region == p;
-        const uint64_t b = __ballot(mine);
-        sliced_store(a, w, p, b, mine, rec);
-        todo &= ~b;
-    }
+    sliced_store(a, w, hit, gid_of >> kRegionBits, rec);
 }
 
 // Resolves tokens in passes of 64.  drain = false: full passes only - what is left (< 64 tokens) waits
@@ -583,12 +568,9 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     w.tok4 = s_tok[wave];
     w.ntok = 0;
     w.thead = 0;
-    w.res_base = 0;
-    w.res_left = 0;
-    w.cp = 0;
     w.parts = s_parts[wave];
     w.first = s_first[wave];
-    for (uint32_t q = w.lane; q < (uint32_t)kParts; q += kWave) w.parts[q] = make_uint2(0u, 0u);
+    for (uint32_t q = w.lane; q < (uint32_t)kParts; q += kWave) w.parts[q] = make_uint2(0u, a.reserve);  // no block yet = a used-up one
 
     uint4 *const lt = s_list[wave];
     const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
