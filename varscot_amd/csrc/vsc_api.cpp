@@ -695,7 +695,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
     const double sites_est = genome->sites ? (double)genome->sites : own_bases / 4;
     uint64_t cap = (uint64_t)(1.5 * sites_est * n_guides * hit_probability(params->max_mismatches)) + (1u << 20);
     unsigned long long cnt[kCntPart + 4 * kParts] = {};
-    const int n_parts = (int)((n_guides + kRegionReads - 1) / kRegionReads);  // output regions of 128 reads
+    const int n_parts = (int)((n_guides + kRegionReads - 1) / kRegionReads);  // output regions of 64 reads
 
     ScanArgs a{};
     SeedArgs sa{};
@@ -752,12 +752,15 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         const uint32_t n_waves_max = (uint32_t)ctx->n_cus * groups_per_cu * kWavesPerGroup;
         const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, (sa.n_chunks + kSlicedGrab - 1) / kSlicedGrab));
         n_groups = (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
-        // block of records a wave reserves per atomic and region: large when many hits are expected, small
-        // otherwise (the unused tail of every wave's last block is written as sentinels and read by the sort)
+        // block of records a wave reserves per atomic and region (a power of two, 64 .. 1024): large when many hits
+        // are expected, small otherwise (the unused tail of every wave's last block is written as sentinels
+        // and read by the sort)
         const uint64_t per_wave = cap / ((uint64_t)n_groups * kWavesPerGroup * 8 * n_parts);
-        sa.reserve = (uint32_t)std::min<uint64_t>(n_parts > 8 ? 256 : 1024, std::max<uint64_t>(kWave, per_wave / kWave * kWave));
-        if (const char *o = std::getenv("VSC_SEED_RESERVE"))  // experiments; a block must take the <= 64 hits of a pass
-            sa.reserve = (uint32_t)std::min(4096, std::max((int)kWave, std::atoi(o) / kWave * kWave));
+        uint32_t want_reserve = (uint32_t)std::min<uint64_t>(n_parts > 8 ? 128 : 1024, std::max<uint64_t>(kWave, per_wave));
+        if (const char *o = std::getenv("VSC_SEED_RESERVE")) want_reserve = (uint32_t)std::min(1024, std::max((int)kWave, std::atoi(o)));
+        sa.reserve_log2 = 6;
+        while ((2u << sa.reserve_log2) <= want_reserve) ++sa.reserve_log2;
+        sa.reserve = 1u << sa.reserve_log2;
         sa.n_parts = (uint32_t)n_parts;
         // a region gets its share of the expected hits + 15 % (read ranges differ) + the open blocks
         part_cap = cap / n_parts + cap / n_parts / 7 + 4096 + (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
@@ -766,8 +769,9 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
 
     ht.lap("prep enqueue");
     for (unsigned tries = 0;; ++tries) {
-        if (algo == VSC_ALGO_SEED && part_cap >= (1ull << 32) - (1u << 20))
-            return fail(ctx, VSC_ERR_RANGE, "vsc_search: more than 2^32 hits in a block of 128 reads");
+        // (the kernel keeps a block number in 21 bits: part_cap / reserve < 2^21)
+        if (algo == VSC_ALGO_SEED && (part_cap >= (1ull << 32) - (1u << 20) || part_cap >= ((uint64_t)sa.reserve << 21)))
+            return fail(ctx, VSC_ERR_RANGE, "vsc_search: more than 2^32 hits in a block of 64 reads");
         VSC_HIP_H(ctx->keys_a.ensure(cap * sizeof(uint64_t)));
         VSC_HIP_H(hipMemsetAsync(ctx->counters.p, 0, kCounterWords * sizeof(unsigned long long), ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -839,7 +843,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
             l0.cursor = l0.hist + n_bins;
             l0.bin_start = l0.cursor + n_bins;
             l0.bin_bits = bits0;
-            l0.bin_shift = kRecKeyBits;  // key >> 40 = read index >> 7 = region
+            l0.bin_shift = kRecKeyBits;  // key >> 39 = read index >> 6 = region
             VSC_HIP_H(hipMemsetAsync(l0.hist, 0, n_bins * sizeof(uint32_t), ctx->stream));
             VSC_HIP_H(launch_bin_hist(l0, ctx->stream));
             VSC_HIP_H(launch_bin_scan(l0, ctx->stream));
@@ -953,7 +957,7 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     vsc_hits *hits = new (std::nothrow) vsc_hits();
     if (!hits) return fail(ctx, VSC_ERR_NOMEM, "vsc_search: out of host memory");
     hits->ctx = ctx;
-    // a pass takes at most kMaxPassReads reads (128 output regions of 128 reads); larger sets are searched
+    // a pass takes at most kMaxPassReads reads (128 output regions of 64 reads); larger sets are searched
     // pass by pass - the read index is the major sort key, so the passes' results simply follow each other
     uint64_t used = 0;
     for (uint32_t first = 0; first < n_guides; first += kMaxPassReads) {

@@ -47,12 +47,12 @@ enum { kCntHits = 0, kCntChunk = 1, kCntSites = 2, kCntOverflow = 3, kCntVisited
 // bytes apart behind the counters: one device-wide cursor sustains only ~90 atomics/us
 // (MI355X_MICROARCH.md), which for 270 000 grabs is 3 ms - as long as a whole 1 000-read search.
 // The sliced kernel writes its hits into up to kParts regions by read range (region = read index >>
-// kRegionBits, 128 reads): inside a region a hit is one packed 8-byte record (below), and the regions
+// kRegionBits, 64 reads): inside a region a hit is one packed 8-byte record (below), and the regions
 // are ordered independently by the bin sort of vsc_sort.hip; their concatenation is the result.
 // Per region: counters[kCntPart + 4 p + {0, 1, 2}] = records reserved, sentinels among them, records lost.
-constexpr int kRegionBits = 7;
+constexpr int kRegionBits = 6;
 constexpr int kRegionReads = 1 << kRegionBits;
-constexpr int kParts = 128;
+constexpr int kParts = 256;
 constexpr int kMaxPassReads = kParts * kRegionReads;  // reads one search pass can take (vsc_search splits larger sets)
 constexpr int kCntPart = 8;
 constexpr int kCursors = 32;
@@ -64,8 +64,8 @@ constexpr int kCounterWords = kCursorBase + kCursors * kCursorStride;
 //   bits  0..22  mismatch mask in forward-genome window coordinates (NM is its popcount)
 //   bits 23..54  global position of the window start
 //   bit  55      strand (1 = '-')
-//   bits 56..62  read index inside its region (read & 127)
-//   bit  63      0; the all-ones word is the sentinel that pads reserved-but-unused record slots
+//   bits 56..61  read index inside its region (read & 63)
+//   bits 62, 63  0; the all-ones word is the sentinel that pads reserved-but-unused record slots
 // Ascending order of the records of one region = the result order (read, strand, position).
 constexpr int kRecPosShift = 23;
 constexpr int kRecStrandShift = 55;
@@ -77,10 +77,13 @@ constexpr uint64_t kRecSentinel = ~0ull;
 constexpr int kSortThreads = 1024;
 constexpr int kSortItems = 16;
 constexpr int kSortTile = kSortThreads * kSortItems;  // records per partition tile
-constexpr int kSortCap = kSortTile - 128;             // the largest bin the finalize kernel orders in LDS (records + sub-bin
-                                                      // table fill the CU's 160 KiB)
+constexpr int kFinThreads = 512;                      // finalize kernel: 512 threads x 16 records, two workgroups per CU
+constexpr int kFinItems = 16;
+constexpr int kSortCap = kFinThreads * kFinItems - 128;  // the largest bin it orders in LDS (records + sub-bin table = half
+                                                      // of the CU's 160 KiB, so that one workgroup computes while the other
+                                                      // waits for memory)
 constexpr int kSortMaxBinBits = 11;                   // <= 2048 bins per partition level
-constexpr int kSortSubBits = 14;                      // <= 16 384 sub-bins inside the finalize kernel
+constexpr int kSortSubBits = 13;                      // <= 8 192 sub-bins inside the finalize kernel
 constexpr int kHistTiles = 8;                         // tiles a block of the histogram kernel walks through
 
 // Required plane bits of the two PAM letters, expanded to all-ones / all-zero words.
@@ -179,7 +182,8 @@ struct SeedArgs {
     const uint32_t *contig_end;
     uint32_t n_contigs;
     uint64_t *hit_recs;            // out: packed records (layout above), region p = [p * part_cap, (p + 1) * part_cap)
-    uint32_t reserve;              // records a wave reserves per atomic on its region's cursor
+    uint32_t reserve;              // records a wave reserves per atomic on its region's cursor: a power of two, 64 .. 1024
+    uint32_t reserve_log2;
     uint32_t n_parts;              // regions in use (region of a hit = read index >> kRegionBits)
     unsigned long long part_cap;   // records per region
     unsigned long long *counters;  // kCntPart + 4 p + {0,1,2}, kCntSites (= pairs compared), kCntVisited, kCntOverflow, cursors

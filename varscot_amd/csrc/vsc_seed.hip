@@ -17,7 +17,7 @@
 // seed_sliced_kernel compares bit-sliced: 32 sites per lane and instruction, only the 16 positions outside
 // the bucket's segment are counted, the segment adds the list entry's known distance; hits are resolved
 // from the site records and leave the kernel as packed 8-byte records (vsc_internal.h), one output region
-// per 128 reads.
+// per 64 reads.
 #include "vsc_internal.h"
 #include "vsc_device.h"
 
@@ -220,7 +220,7 @@ struct SeedWave {
     uint4 *tok4;     // pending hit tokens (see sliced_fetch)
     uint32_t ntok, lane;
     uint32_t thead;  // ring slot of the oldest pending token
-    uint2 *parts;    // per output region: {first record of this wave's open block, records claimed in it}
+    uint32_t *parts; // per output region: this wave's open block, block number << 11 | records claimed in it
     uint32_t *first; // first site of every chunk of the current grab (tokens name their chunk by slot)
 };
 
@@ -377,14 +377,17 @@ struct SlicedFetch {
     uint4 rec;  // site record of the lowest set bit
 };
 
-// Output of the sliced kernel.  A wave keeps, per output region (128 reads), an open block of `reserve`
-// reserved records: w.parts[p] = {first record of the block (relative to the region), records claimed in it}.
+// Output of the sliced kernel.  A wave keeps, per output region (64 reads), an open block of `reserve`
+// (a power of two, <= 1024) reserved records, one 32-bit word of LDS per region: block number << 11 | records
+// claimed in it (the block starts at record block number x reserve of the region).
 // The hits of a pass belong to whatever regions their reads fall into - with 128.8 reads per bucket spread over
-// 79 regions (c3) that is four or five regions per pass - so every hit lane claims its slot by itself with one
-// LDS atomic on its region's counter and stores straight from registers; nothing in the common path depends on
+// 157 regions (c3) that is five or six regions per pass - so every hit lane claims its slot by itself with ONE
+// LDS atomic on its region's word and stores straight from registers; nothing in the common path depends on
 // how many regions a pass touches.  Only when a block is used up (once per `reserve` hits of a region) do the
 // lanes that found it full take the wave-uniform path that reserves the next block.
-//
+constexpr uint32_t kPartUsedBits = 11;
+constexpr uint32_t kPartUsedMask = (1u << kPartUsedBits) - 1u;
+
 // Reserves a new block in region p (wave-uniform).  Returns false when the region is full: the host
 // re-runs with room for reserved + lost records in every region.
 __device__ __forceinline__ bool sliced_reserve(const SeedArgs &a, const SeedWave &w, uint32_t p, uint32_t losing, uint32_t &base)
@@ -401,20 +404,18 @@ __device__ __forceinline__ bool sliced_reserve(const SeedArgs &a, const SeedWave
         }
         return false;
     }
-    base = (uint32_t)rel;  // part_cap < 2^32
+    base = (uint32_t)rel;  // part_cap < 2^32; a multiple of `reserve` (every reservation is)
     return true;
 }
 
 // lanes with `hit` store their record in the region of their read
 __device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, bool hit, uint32_t region, uint64_t rec)
 {
-    uint32_t slot = 0, base = 0;
-    if (hit) {
-        slot = atomicAdd(&w.parts[region].y, 1u);  // LDS; may run past `reserve`: those lanes take the path below
-        base = w.parts[region].x;
-    }
+    uint32_t state = kPartUsedMask;
+    if (hit) state = atomicAdd(&w.parts[region], 1u);  // LDS; the count may run past `reserve`: those lanes take the path below
+    const uint32_t slot = state & kPartUsedMask;
     const bool placed = hit && slot < a.reserve;
-    if (placed) a.hit_recs[(unsigned long long)region * a.part_cap + base + slot] = rec;
+    if (placed) a.hit_recs[(unsigned long long)region * a.part_cap + ((state >> kPartUsedBits) << a.reserve_log2) + slot] = rec;
     uint64_t todo = __ballot(hit && !placed);
     while (todo != 0) {
         const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)region, (int)__builtin_ctzll(todo));
@@ -425,7 +426,7 @@ __device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, boo
         const bool ok = sliced_reserve(a, w, p, n, next);
         if (mine && ok) a.hit_recs[(unsigned long long)p * a.part_cap + next + lanes_below(b)] = rec;
         // (a region that is full keeps a "used up" block: later hits come here again and are counted as lost)
-        if (w.lane == 0) w.parts[p] = make_uint2(ok ? next : 0u, ok ? n : a.reserve);
+        if (w.lane == 0) w.parts[p] = ok ? ((next >> a.reserve_log2) << kPartUsedBits) | n : a.reserve;
         wave_sync();
         todo &= ~b;
     }
@@ -436,8 +437,8 @@ __device__ __forceinline__ void sliced_finish_hits(const SeedArgs &a, SeedWave &
 {
     wave_sync();
     for (uint32_t q = 0; q < a.n_parts; ++q) {
-        const uint2 st = w.parts[q];
-        const uint32_t base = uniform(st.x), used = uniform(st.y);
+        const uint32_t state = uniform(w.parts[q]);
+        const uint32_t base = (state >> kPartUsedBits) << a.reserve_log2, used = state & kPartUsedMask;
         const uint32_t left = used < a.reserve ? a.reserve - used : 0u;
         for (uint32_t i = w.lane; i < left; i += kWave) a.hit_recs[(unsigned long long)q * a.part_cap + base + used + i] = kRecSentinel;
         if (w.lane == 0 && left) atomicAdd(&a.counters[kCntPart + 4 * q + 1], (unsigned long long)left);
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
 {
     __shared__ uint4 s_tok[kWavesPerGroup][kSlicedTokCap];
     __shared__ uint4 s_list[kWavesPerGroup][kWave];  // the current tile of 64 read-list entries
-    __shared__ uint2 s_parts[kWavesPerGroup][kParts];
+    __shared__ uint32_t s_parts[kWavesPerGroup][kParts];
     __shared__ uint32_t s_first[kWavesPerGroup][kSlicedGrab];
 
     const uint32_t wave = threadIdx.x / kWave;
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     w.thead = 0;
     w.parts = s_parts[wave];
     w.first = s_first[wave];
-    for (uint32_t q = w.lane; q < (uint32_t)kParts; q += kWave) w.parts[q] = make_uint2(0u, a.reserve);  // no block yet = a used-up one
+    for (uint32_t q = w.lane; q < (uint32_t)kParts; q += kWave) w.parts[q] = a.reserve;  // no block yet = a used-up one
 
     uint4 *const lt = s_list[wave];
     const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;

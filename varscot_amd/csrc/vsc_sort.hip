@@ -2,7 +2,7 @@
 // the order of the reference's std::map per read and strand (VARSCOT_pipeline/read_mapping/
 // bidir_mapping.cpp:154, key = (contig, position)) and rID / beginPos of every record (:99-100).
 //
-// The search kernels leave the hits of every region (128 reads) as packed 8-byte records in no particular
+// The search kernels leave the hits of every region (64 reads) as packed 8-byte records in no particular
 // order (layout: vsc_internal.h); ascending record order inside a region IS the result order.  A
 // comparison-free "bin sort" in the shape of the memory system orders them, every record moving through
 // HBM twice instead of once per 8-bit digit of a library radix sort:
@@ -13,9 +13,9 @@
 //                         with LDS atomics, reserves room in every bin with one coalesced returning atomic
 //                         per bin, regroups the tile by bin in LDS and writes each bin's records as one
 //                         contiguous piece.  Pieces of different tiles land in a bin in arbitrary order.
-//   bin_finalize_kernel   one read + the 16-byte result write: a workgroup takes one bin (<= 16 384 records,
+//   bin_finalize_kernel   one read + the 16-byte result write: a workgroup takes one bin (<= 8 064 records,
 //                         one read's hits on one strand inside a position window), counting-sorts it in LDS
-//                         on the next <= 12 key bits, ranks the handful of records that still agree (keys
+//                         on the next <= 13 key bits, ranks the handful of records that still agree (keys
 //                         are unique), resolves the contig and writes the vsc_hit records in place.
 //
 // A bin that exceeds the LDS capacity (a read with far more hits than the others - repeats) is listed and
@@ -269,10 +269,10 @@ hipError_t launch_bin_partition(const SortArgs &args, hipStream_t stream)
 // ------------------------------------------------------------------------------------------------
 // finalize: one bin per workgroup -> vsc_hit records in result order
 // ------------------------------------------------------------------------------------------------
-// Sub-bin counters / first slots are 16-bit (a bin has < 2^16 records), two to a word, so that 16 384
-// sub-bins fit beside the records: the finer the sub-bins, the fewer records share one and have to be
-// ranked against each other (at 10 000 records per bin: 0.6 per sub-bin on average instead of 2.5 with
-// 4 096 sub-bins, which made that ranking loop the largest item of the kernel).
+// Sub-bin counters / first slots are 16-bit (a bin has < 2^16 records), two to a word, so that 8 192
+// sub-bins fit beside 8 000 records in HALF of the CU's LDS: the finer the sub-bins, the fewer records share
+// one and have to be ranked against each other (0.6 per sub-bin on average at 5 000 records per bin), and with
+// two workgroups per CU one computes while the other waits for its loads or drains its stores.
 __device__ __forceinline__ uint32_t sub_slot(const uint32_t *s_sub, uint32_t sb)
 {
     return (s_sub[sb >> 1] >> ((sb & 1u) * 16u)) & 0xFFFFu;
@@ -281,11 +281,11 @@ __device__ __forceinline__ uint32_t sub_slot(const uint32_t *s_sub, uint32_t sb)
 constexpr int kFinalizeNear = 4;    // contigs a bin's position range may touch for the straight-line contig lookup
 constexpr int kFinalizeRange = 64;  // ... for a binary search in LDS (more: in global memory - variant genomes)
 
-__global__ __launch_bounds__(kSortThreads) void bin_finalize_kernel(const FinArgs a)
+__global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs a)
 {
     __shared__ uint64_t s_rec[kSortCap];
     __shared__ uint32_t s_sub[(1 << kSortSubBits) / 2 + 1];  // packed pairs of 16-bit counters, then first slots
-    __shared__ uint32_t s_wave[kSortThreads / kWave];
+    __shared__ uint32_t s_wave[kFinThreads / kWave];
     __shared__ uint32_t s_range[2 + kFinalizeRange];  // first contig of the bin's position range, contigs in it, their starts
     const uint32_t t = threadIdx.x;
     const uint32_t seg = blockIdx.x >> a.bin_bits, bin = blockIdx.x & ((1u << a.bin_bits) - 1u);
@@ -318,19 +318,19 @@ __global__ __launch_bounds__(kSortThreads) void bin_finalize_kernel(const FinArg
     }
     const uint32_t nsub = 1u << a.sub_bits;
     const uint32_t nwords = nsub > 1u ? nsub / 2u : 1u;
-    for (uint32_t i = t; i <= nwords; i += kSortThreads) s_sub[i] = 0;
+    for (uint32_t i = t; i <= nwords; i += kFinThreads) s_sub[i] = 0;
     block_sync();
     const uint64_t *const in = a.src + src;
-    uint64_t r[kSortItems];
-    uint32_t rk[kSortItems];
+    uint64_t r[kFinItems];
+    uint32_t rk[kFinItems];
 #pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {  // branch-free: see bin_partition_kernel
-        const uint32_t i = k * kSortThreads + t;
+    for (int k = 0; k < kFinItems; ++k) {  // branch-free: see bin_partition_kernel
+        const uint32_t i = k * kFinThreads + t;
         const uint64_t v = in[i < n_src ? i : 0u];
         r[k] = i < n_src ? v : kRecSentinel;
     }
 #pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
+    for (int k = 0; k < kFinItems; ++k) {
         const bool real = !(r[k] >> 63);
         const uint32_t sb = (uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u);
         const uint32_t sh = (sb & 1u) * 16u;
@@ -341,7 +341,8 @@ __global__ __launch_bounds__(kSortThreads) void bin_finalize_kernel(const FinArg
     // exclusive scan of the packed counters: a thread owns `per` consecutive words
     uint32_t n;
     {
-        const uint32_t per = nwords > (uint32_t)kSortThreads ? nwords / kSortThreads : 1u;  // 1, 2, 4 or 8
+        const uint32_t per = nwords > (uint32_t)kFinThreads ? nwords / kFinThreads : 1u;  // 1, 2, 4 or 8
+        static_assert((1 << kSortSubBits) / 2 <= 8 * kFinThreads, "a thread scans at most 8 words of the sub-bin table");
         const bool mine = t * per < nwords;
         uint32_t w[8];
         uint32_t sum = 0;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_finalize_kernel(const FinArg
         block_sync();
         uint32_t before = 0, total = 0;
 #pragma unroll
-        for (int q = 0; q < kSortThreads / kWave; ++q) {
+        for (int q = 0; q < kFinThreads / kWave; ++q) {
             const uint32_t x = s_wave[q];
             before += (uint32_t)q < wave ? x : 0u;
             total += x;
@@ -407,12 +408,12 @@ __global__ __launch_bounds__(kSortThreads) void bin_finalize_kernel(const FinArg
         if (t < (uint32_t)kFinalizeRange) s_range[2 + t] = t < s_range[1] ? a.contig_off[s_range[0] + t] : 0xFFFFFFFFu;
     }
 #pragma unroll
-    for (int k = 0; k < kSortItems; ++k)
+    for (int k = 0; k < kFinItems; ++k)
         if (!(r[k] >> 63)) s_rec[sub_slot(s_sub, (uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u)) + rk[k]] = r[k];
     block_sync();
     const uint32_t c_lo = s_range[0], c_n = s_range[1];
     const uint32_t st0 = s_range[2], st1 = s_range[3], st2 = s_range[4], st3 = s_range[5];
-    for (uint32_t base = 0; base < n; base += kSortThreads) {
+    for (uint32_t base = 0; base < n; base += kFinThreads) {
         const uint32_t i = base + t;
         const bool live = i < n;
         const uint64_t x = live ? s_rec[i] : 0ull;
@@ -471,7 +472,7 @@ hipError_t launch_bin_finalize(const FinArgs &args, hipStream_t stream)
     if (blocks >= (1ull << 31) || args.sub_bits > (uint32_t)kSortSubBits || args.bin_bits > (uint32_t)kSortMaxBinBits ||
         args.cap > (uint32_t)kSortCap)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bin_finalize_kernel, dim3((unsigned)blocks), dim3(kSortThreads), 0, stream, args);
+    hipLaunchKernelGGL(bin_finalize_kernel, dim3((unsigned)blocks), dim3(kFinThreads), 0, stream, args);
     return hipGetLastError();
 }
 
