@@ -356,6 +356,11 @@ typedef struct {
  */
 int vsc_rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *features, const double *activity, uint64_t n,
                    double *prob, uint8_t *cls, uint8_t *tie);
+/* The same for rows in the packed 64-byte form of vsc_score_hits_packed (host memory, or device memory when
+ * rows_on_device != 0 - e.g. the buffer vsc_score_hits_packed has just filled): the columns the forest tests
+ * are decoded on the device, the 442-byte rows never exist. */
+int vsc_rf_predict_packed(vsc_ctx *ctx, const vsc_rf_model *model, const void *packed_rows, int rows_on_device,
+                          const double *activity, uint64_t n, double *prob, uint8_t *cls, uint8_t *tie);
 
 /* ---- host-side formatting helpers (no device needed) ------------------------------------------ */
 /*

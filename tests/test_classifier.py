@@ -49,6 +49,42 @@ def test_rf_predict_matches_restatement_and_training_labels(golden_dir):
 
 
 @pytest.mark.gpu
+def test_rf_predict_from_packed_rows_on_host_and_device():
+    """vsc_rf_predict_packed decodes the columns the forest tests straight from the 64-byte packed rows - no
+    442-byte expansion: same votes as the dense entry point, for rows passed from the host and for rows left in
+    device memory by vsc_score_hits_packed; few rows (the trees are split over workgroups, votes meet in an
+    atomic) and many rows (one workgroup walks all trees of its 256 rows)."""
+    import torch
+    from helpers import make_genome, random_guides
+    rng = np.random.default_rng(77)
+    guides = random_guides(rng, 20)
+    contigs = make_genome(77, [60000, 20000], guides, 6, n_plant=300, n_runs=2)
+    ctx = va.Context(0)
+    gen = ctx.load_genome(va.PackedGenome.from_sequences(contigs))
+    h = gen.search(guides, 6)
+    n = len(h)
+    assert n > 200
+    _, _, dense = h.scores(mit=False, features=True)
+    rows, _ = h.packed_features()
+    dev = torch.empty((n, 16), dtype=torch.int32, device="cuda:0")
+    h.packed_features(to_host=False, dev_ptr=dev.data_ptr())
+    act = rng.random(n) * 0.9 + 0.05
+    forest = Forest(MODEL)
+    want = forest.predict(ctx, dense, act)
+    for got in (forest.predict_packed(ctx, rows, act), forest.predict_packed(ctx, n, act, dev_ptr=dev.data_ptr()),
+                forest.predict_packed(ctx, rows[:3], act[:3])):
+        m = len(got[0])
+        assert all(np.array_equal(a[:m], b) for a, b in zip(want, got))
+    assert 0 < want[1].mean() < 1 or n < 50  # both classes occur among a few hundred real hits
+    big = 300_000 // n + 1  # many rows: every workgroup walks the whole forest
+    many = forest.predict_packed(ctx, np.tile(rows, (big, 1)), np.tile(act, big))
+    assert all(np.array_equal(np.tile(a, big), b) for a, b in zip(want, many))
+    h.close()
+    gen.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_classification_pipeline_tool(tmp_path, golden_dir):
     """TSV + feature file in, TSV with the Score column replaced out (classificationPipeline.R:36-48)."""
     from oracle.rf_oracle import Forest as OracleForest

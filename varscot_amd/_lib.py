@@ -111,6 +111,7 @@ SYMBOLS = [
     ("vsc_windows_name_offsets", _vp, [_vp]),
     ("vsc_windows_free", None, [_vp]),
     ("vsc_rf_predict", C.c_int, [_vp, C.POINTER(RfModel), _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    ("vsc_rf_predict_packed", C.c_int, [_vp, C.POINTER(RfModel), _vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),
     ("vsc_sam_order", None, [_vp, C.c_uint64, _vp, _vp]),
 ]
 

@@ -59,3 +59,21 @@ class Forest:
         tie = np.empty(n, dtype=np.uint8)
         check(lib().vsc_rf_predict(ctx._h, C.byref(m), ptr(features), ptr(activity), n, ptr(prob), ptr(cls), ptr(tie)), ctx._h)
         return prob, cls, tie
+
+    def predict_packed(self, ctx, rows, activity, dev_ptr=None):
+        """The same from packed 64-byte rows: uint32[n, 16] on the host, or (dev_ptr: device address, rows = row
+        count) in device memory as vsc_score_hits_packed left them.  Returns (prob, class, tie)."""
+        activity = np.ascontiguousarray(activity, dtype=np.float64)
+        n = len(activity)
+        if dev_ptr is None:
+            rows = np.ascontiguousarray(rows, dtype=np.uint32).reshape(-1, 16)
+            assert len(rows) == n
+        m = RfModel(self.n_trees, self.n_nodes, ptr(self.status), ptr(self.feature), ptr(self.left), ptr(self.right),
+                    ptr(self.split), ptr(self.node_class))
+        prob = np.empty(n, dtype=np.float64)
+        cls = np.empty(n, dtype=np.uint8)
+        tie = np.empty(n, dtype=np.uint8)
+        src = C.c_void_p(dev_ptr) if dev_ptr is not None else ptr(rows)
+        check(lib().vsc_rf_predict_packed(ctx._h, C.byref(m), src, int(dev_ptr is not None), ptr(activity), n, ptr(prob),
+                                          ptr(cls), ptr(tie)), ctx._h)
+        return prob, cls, tie

@@ -1303,44 +1303,90 @@ int vsc_score_hits_packed(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits
     return VSC_OK;
 }
 
-int vsc_rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *features, const double *activity, uint64_t n,
-                   double *prob, uint8_t *cls, uint8_t *tie)
+}  // extern "C"
+
+namespace {
+
+// vsc_rf_predict / vsc_rf_predict_packed: the forest as 16-byte nodes over its own (compact) column numbering,
+// the rows from the host (dense) or from host / device memory (packed)
+int rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *dense, const void *packed, int packed_on_device,
+               const double *activity, uint64_t n, double *prob, uint8_t *cls, uint8_t *tie, const char *who)
 {
-    if (!ctx) return VSC_ERR_INVALID;
     ctx->err.clear();
     if (!model || !model->node_status || !model->feature || !model->left || !model->right || !model->split ||
-        !model->node_class || model->n_trees == 0 || model->n_nodes == 0 || (n && (!features || !activity)))
-        return fail(ctx, VSC_ERR_INVALID, "vsc_rf_predict: null or empty argument");
+        !model->node_class || model->n_trees == 0 || model->n_nodes == 0 || (n && ((!dense && !packed) || !activity)))
+        return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": null or empty argument").c_str());
     if (n == 0) return VSC_OK;
     const size_t nn = (size_t)model->n_trees * model->n_nodes;
+    if ((size_t)model->n_nodes * sizeof(RfNode) > (size_t)kRfTileBytes)
+        return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": a tree has more nodes than the kernel stages at once").c_str());
     std::vector<RfNode> nodes(nn);
+    std::vector<int> slot(VSC_N_FEATURES, -1);
+    std::vector<uint16_t> columns;
     for (size_t i = 0; i < nn; ++i) {
         RfNode &d = nodes[i];
         d.split = model->split[i];
-        d.feature = model->feature[i];
         d.left = model->left[i];
         d.right = model->right[i];
-        d.status = model->node_status[i];
+        d.status = model->node_status[i] == 1 ? 1 : -1;  // unused slots behind a tree's last node are never reached
         d.node_class = model->node_class[i];
-        if (d.status != 1) d.status = -1;  // unused slots behind a tree's last node are never reached
-        if (d.status == 1 && (d.feature > VSC_N_FEATURES || d.left == 0 || d.right == 0 || d.left > model->n_nodes ||
-                               d.right > model->n_nodes))
-            return fail(ctx, VSC_ERR_INVALID, "vsc_rf_predict: malformed forest (feature or daughter index out of range)");
+        d.pad = 0;
+        d.column = 0;
+        if (d.status != 1) continue;
+        const uint16_t f = model->feature[i];
+        if (f > VSC_N_FEATURES || d.left == 0 || d.right == 0 || d.left > model->n_nodes || d.right > model->n_nodes)
+            return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": malformed forest (feature or daughter index out of range)").c_str());
+        if (f == VSC_N_FEATURES) {
+            d.column = kRfActivity;
+        } else {
+            if (slot[f] < 0) {
+                if (columns.size() == (size_t)kRfMaxColumns)
+                    return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": the forest tests more than 128 distinct feature columns").c_str());
+                slot[f] = (int)columns.size();
+                columns.push_back(f);
+            }
+            d.column = (uint8_t)slot[f];
+        }
     }
     VSC_HIP(ctx, hipSetDevice(ctx->device));
-    VSC_HIP(ctx, ctx->score_feat.ensure(n * VSC_N_FEATURES));
+    const size_t node_bytes = (nn * sizeof(RfNode) + 255) / 256 * 256;
+    VSC_HIP(ctx, ctx->guides.ensure(node_bytes + std::max<size_t>(columns.size(), 1) * sizeof(uint16_t)));
+    VSC_HIP(ctx, hipMemcpyAsync(ctx->guides.p, nodes.data(), nn * sizeof(RfNode), hipMemcpyHostToDevice, ctx->stream));
+    uint16_t *d_columns = (uint16_t *)((char *)ctx->guides.p + node_bytes);
+    if (!columns.empty())
+        VSC_HIP(ctx, hipMemcpyAsync(d_columns, columns.data(), columns.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
     VSC_HIP(ctx, ctx->score_mit.ensure(n * sizeof(double)));
     VSC_HIP(ctx, ctx->score_flags.ensure(n * sizeof(uint32_t)));
-    VSC_HIP(ctx, ctx->guides.ensure(nn * sizeof(RfNode)));
-    VSC_HIP(ctx, hipMemcpyAsync(ctx->guides.p, nodes.data(), nn * sizeof(RfNode), hipMemcpyHostToDevice, ctx->stream));
-    VSC_HIP(ctx, hipMemcpyAsync(ctx->score_feat.p, features, n * VSC_N_FEATURES, hipMemcpyHostToDevice, ctx->stream));
     VSC_HIP(ctx, hipMemcpyAsync(ctx->score_mit.p, activity, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    RfArgs a{};
+    a.nodes = (const RfNode *)ctx->guides.p;
+    a.n_trees = model->n_trees;
+    a.n_nodes = model->n_nodes;
+    a.columns = d_columns;
+    a.n_columns = (uint32_t)columns.size();
+    a.activity = (const double *)ctx->score_mit.p;
+    a.n = n;
+    a.votes = (uint32_t *)ctx->score_flags.p;
+    if (dense) {
+        VSC_HIP(ctx, ctx->score_feat.ensure(n * VSC_N_FEATURES));
+        VSC_HIP(ctx, hipMemcpyAsync(ctx->score_feat.p, dense, n * VSC_N_FEATURES, hipMemcpyHostToDevice, ctx->stream));
+        a.dense = (const uint8_t *)ctx->score_feat.p;
+    } else if (packed_on_device) {
+        a.packed = (const uint4 *)packed;
+    } else {
+        VSC_HIP(ctx, ctx->score_feat.ensure(n * VSC_PACKED_FEATURE_BYTES));
+        VSC_HIP(ctx, hipMemcpyAsync(ctx->score_feat.p, packed, n * VSC_PACKED_FEATURE_BYTES, hipMemcpyHostToDevice, ctx->stream));
+        a.packed = (const uint4 *)ctx->score_feat.p;
+    }
+    // few rows: split the trees over several workgroups per row tile so that the device is filled
+    const uint64_t tiles = (n + kRfRows - 1) / kRfRows;
+    a.tree_splits = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)4 * ctx->n_cus / tiles, 32, model->n_trees}));
+    if (a.tree_splits > 1) VSC_HIP(ctx, hipMemsetAsync(a.votes, 0, n * sizeof(uint32_t), ctx->stream));
     VSC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    VSC_HIP(ctx, launch_rf_predict((const RfNode *)ctx->guides.p, model->n_trees, model->n_nodes, (const uint8_t *)ctx->score_feat.p,
-                                   (const double *)ctx->score_mit.p, n, (uint32_t *)ctx->score_flags.p, ctx->stream));
+    VSC_HIP(ctx, launch_rf_predict(a, ctx->stream));
     VSC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     std::vector<uint32_t> votes(n);
-    VSC_HIP(ctx, hipMemcpyAsync(votes.data(), ctx->score_flags.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VSC_HIP(ctx, hipMemcpyAsync(votes.data(), a.votes, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (uint64_t i = 0; i < n; ++i) {
         if (prob) prob[i] = (double)votes[i] / (double)model->n_trees;  // type = "prob": votes / ntree
@@ -1351,6 +1397,24 @@ int vsc_rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *featu
     VSC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->timing.score_ms = ms;
     return VSC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vsc_rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *features, const double *activity, uint64_t n,
+                   double *prob, uint8_t *cls, uint8_t *tie)
+{
+    if (!ctx) return VSC_ERR_INVALID;
+    return rf_predict(ctx, model, features, nullptr, 0, activity, n, prob, cls, tie, "vsc_rf_predict");
+}
+
+int vsc_rf_predict_packed(vsc_ctx *ctx, const vsc_rf_model *model, const void *packed_rows, int rows_on_device,
+                          const double *activity, uint64_t n, double *prob, uint8_t *cls, uint8_t *tie)
+{
+    if (!ctx) return VSC_ERR_INVALID;
+    return rf_predict(ctx, model, nullptr, packed_rows, rows_on_device, activity, n, prob, cls, tie, "vsc_rf_predict_packed");
 }
 
 }  // extern "C"

@@ -189,13 +189,31 @@ struct SeedArgs {
     unsigned long long *counters;  // kCntPart + 4 p + {0,1,2}, kCntSites (= pairs compared), kCntVisited, kCntOverflow, cursors
 };
 
-// One node of a random-forest tree, 16 bytes: a node visit is one load.
+// One node of a random-forest tree, 16 bytes: a node visit is one LDS read.
 struct RfNode {
     double split;
-    uint16_t feature;  // column of the feature row; VSC_N_FEATURES = the on-target activity
     uint16_t left, right;  // 1-based daughters
-    int8_t status;     // 1 split, -1 terminal
-    uint8_t node_class;  // terminal: 1 = class "0", 2 = class "1"
+    uint8_t column;        // which of the forest's (at most kRfMaxColumns) predictor columns; kRfActivity = the on-target activity
+    int8_t status;         // 1 split, -1 terminal
+    uint8_t node_class;    // terminal: 1 = class "0", 2 = class "1"
+    uint8_t pad;
+};
+constexpr int kRfRows = 256;          // feature rows per workgroup (one thread each)
+constexpr int kRfMaxColumns = 128;    // distinct feature columns a forest may test (rfClassifier: 79 + the activity)
+constexpr int kRfActivity = 255;
+constexpr int kRfTileBytes = 48 * 1024;  // whole trees staged in LDS per step
+
+struct RfArgs {
+    const RfNode *nodes;        // [n_trees * n_nodes], tree-major
+    uint32_t n_trees, n_nodes;
+    const uint16_t *columns;    // [n_columns] dense feature columns (0..441) the forest tests
+    uint32_t n_columns;
+    const uint8_t *dense;       // n rows of 442 bytes, or null:
+    const uint4 *packed;        // n rows of 64 bytes (vsc_score_hits_packed)
+    const double *activity;     // [n]
+    uint64_t n;
+    uint32_t *votes;            // [n] trees voting class "1" (zeroed before the launch when tree_splits > 1)
+    uint32_t tree_splits;       // gridDim.y: every workgroup row walks n_trees / tree_splits trees
 };
 
 // Launch wrappers implemented in vsc_kernels.hip.  They only enqueue work on `stream`.
@@ -205,8 +223,7 @@ hipError_t launch_bin_hist(const SortArgs &args, hipStream_t stream);
 hipError_t launch_bin_scan(const SortArgs &args, hipStream_t stream);
 hipError_t launch_bin_partition(const SortArgs &args, hipStream_t stream);
 hipError_t launch_bin_finalize(const FinArgs &args, hipStream_t stream);
-hipError_t launch_rf_predict(const RfNode *nodes, uint32_t n_trees, uint32_t n_nodes, const uint8_t *features,
-                             const double *activity, uint64_t n, uint32_t *votes_out, hipStream_t stream);
+hipError_t launch_rf_predict(const RfArgs &args, hipStream_t stream);
 hipError_t launch_interleave(const uint32_t *hi, const uint32_t *lo, uint64_t n, uint2 *hl, hipStream_t stream);
 hipError_t launch_score(const ScoreArgs &args, hipStream_t stream);
 hipError_t launch_score_packed(const ScoreArgs &args, uint4 *packed, hipStream_t stream);

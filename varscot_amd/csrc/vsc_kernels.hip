@@ -557,25 +557,40 @@ __device__ void feature_row_packed(uint32_t on_h, uint32_t on_l, uint32_t off_h,
     }
 }
 
+// One thread per hit computes the row; the rows of a wave (64 x 64 bytes) then go through LDS so that every
+// store instruction writes 1 KB of consecutive addresses (a lane storing its own row would write 16 bytes into
+// each of 64 different 64-byte sectors per instruction - the kernel is a 64-bytes-per-hit stream).
 __global__ __launch_bounds__(256) void score_packed_kernel(const ScoreArgs a, uint4 *packed)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const vsc_hit h = a.hits[i];
-    uint32_t oh, ol;
-    site_planes(a, h, oh, ol);
-    const uint2 g = a.guides[h.guide];
+    __shared__ uint4 s_rows[256][4];
+    const uint32_t t = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + t;
     uint32_t w[16];
-    feature_row_packed(g.x, g.y, oh, ol, w);
-    uint4 *dst = packed + i * 4;
-    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    dst[2] = make_uint4(w[8], w[9], w[10], w[11]);
-    dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
-    if (a.mit) {
-        int ub;
-        a.mit[i] = mit_score(VSC_HIT_MASK(h.info), &ub);
-        if (a.mit_flags) a.mit_flags[i] = (uint8_t)ub;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = 0;
+    if (i < a.n) {
+        const vsc_hit h = a.hits[i];
+        uint32_t oh, ol;
+        site_planes(a, h, oh, ol);
+        const uint2 g = a.guides[h.guide];
+        feature_row_packed(g.x, g.y, oh, ol, w);
+        if (a.mit) {
+            int ub;
+            a.mit[i] = mit_score(VSC_HIT_MASK(h.info), &ub);
+            if (a.mit_flags) a.mit_flags[i] = (uint8_t)ub;
+        }
+    }
+    // quarter q of row t sits in slot q ^ (t & 3): neighbouring lanes then write to different banks
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_rows[t][q ^ (t & 3u)] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    wave_sync();  // a wave only reads back its own 64 rows
+    const uint32_t wave_row0 = t & ~63u, lane = t & 63u;
+    const uint64_t first = (uint64_t)blockIdx.x * 256 + wave_row0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t e = k * 64 + lane;  // 16-byte piece e of the wave's 4 KB
+        const uint32_t row = e >> 2, q = e & 3u;
+        if (first + row < a.n) packed[(first + row) * 4 + q] = s_rows[wave_row0 + row][q ^ (row & 3u)];
     }
 }
 
@@ -626,41 +641,100 @@ hipError_t launch_score(const ScoreArgs &args, hipStream_t stream)
 
 // ------------------------------------------------------------------------------------------------
 // random-forest inference (classification/classificationPipeline.R:27-34, randomForest's classForest):
-// one thread per feature row walks every tree: x[var] <= split ? left : right until a terminal node
+// x[var] <= split ? left : right from the root until a terminal node, for every tree; votes for class "1".
+//
+// A workgroup takes 256 feature rows, one thread each.  The forest tests at most 128 distinct columns of the
+// 442 (rfClassifier: 79): the workgroup first copies those columns of its rows into LDS - from dense rows, or
+// decoded straight from the 64-byte packed rows of vsc_score_hits_packed, so that a result can be classified
+// without ever expanding it - then walks the trees tile by tile: as many whole trees as fit 48 KB of LDS are
+// staged with coalesced loads, every thread walks them from LDS (a node visit = one 16-byte LDS read + one byte).
+// Few rows: gridDim.y splits the trees over several workgroups per row tile, votes meet in an atomic add.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void rf_predict_kernel(const RfNode *nodes, uint32_t n_trees, uint32_t n_nodes,
-                                                        const uint8_t *features, const double *activity, uint64_t n,
-                                                        uint32_t *votes_out)
+// column `col` (0..441) of the dense feature row that a packed row stands for (layout: feature_row_packed)
+__device__ __forceinline__ uint32_t packed_column(const uint32_t (&w)[16], uint32_t col)
 {
-    __shared__ uint8_t rows[64][VSC_N_FEATURES + 6];
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;
-    if (live)
-        for (int k = 0; k < VSC_N_FEATURES; ++k) rows[threadIdx.x][k] = features[i * VSC_N_FEATURES + k];
-    const double act = live ? activity[i] : 0.0;
-    if (!live) return;
-    const uint8_t *x = rows[threadIdx.x];
-    uint32_t ones = 0;
-    for (uint32_t t = 0; t < n_trees; ++t) {
-        const RfNode *tree = nodes + (size_t)t * n_nodes;
-        uint32_t k = 0;
-        RfNode nd = tree[0];
-        while (nd.status != -1) {
-            const double v = nd.feature == VSC_N_FEATURES ? act : (double)x[nd.feature];
-            k = (v <= nd.split ? nd.left : nd.right) - 1u;
-            nd = tree[k];
-        }
-        ones += nd.node_class == 2;
+    if (col == 0) return (w[0] >> 21) & 31u;                 // totalMismatches
+    if (col <= 21) return (w[0] >> (col - 1)) & 1u;          // mismatchPos1..21
+    if (col <= 33) return (w[1] >> (col - 22)) & 1u;         // AtoC..TtoG
+    if (col == 34) return (w[1] >> 12) & 31u;                // transitions
+    if (col == 35) return (w[1] >> 17) & 31u;                // transversions
+    if (col < 120) {                                         // A1..T20, PAMA..PAMT
+        const uint32_t bit = col - 36;
+        return (w[2 + (bit >> 5)] >> (bit & 31u)) & 1u;
     }
-    votes_out[i] = ones;
+    if (col < 424) {                                         // AA1..TT19
+        const uint32_t bit = col - 120;
+        return (w[5 + (bit >> 5)] >> (bit & 31u)) & 1u;
+    }
+    if (col < 440) {                                         // AA..TT: column sums of the dinucleotide flags
+        const uint32_t pair = col - 424;
+        uint32_t sum = 0;
+        for (uint32_t i = 0; i < 19; ++i) {
+            const uint32_t bit = 16u * i + pair;
+            sum += (w[5 + (bit >> 5)] >> (bit & 31u)) & 1u;
+        }
+        return sum;
+    }
+    return col == 440 ? (w[0] >> 26) & 31u : (w[1] >> 22) & 15u;  // adjacentMismatches, seedMismatches
 }
 
-hipError_t launch_rf_predict(const RfNode *nodes, uint32_t n_trees, uint32_t n_nodes, const uint8_t *features,
-                             const double *activity, uint64_t n, uint32_t *votes_out, hipStream_t stream)
+__global__ __launch_bounds__(kRfRows) void rf_predict_kernel(const RfArgs a)
 {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(rf_predict_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, nodes, n_trees, n_nodes, features,
-                       activity, n, votes_out);
+    __shared__ uint8_t s_x[kRfMaxColumns][kRfRows];  // column-major: the threads of a wave read neighbouring bytes
+    __shared__ uint4 s_nodes[kRfTileBytes / sizeof(uint4)];
+    const uint32_t t = threadIdx.x;
+    const uint64_t row = (uint64_t)blockIdx.x * kRfRows + t;
+    const bool live = row < a.n;
+    if (a.dense) {
+        for (uint32_t c = 0; c < a.n_columns; ++c) s_x[c][t] = live ? a.dense[row * VSC_N_FEATURES + a.columns[c]] : 0;
+    } else {
+        uint32_t w[16] = {};
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = a.packed[row * 4 + q];
+                w[4 * q] = v.x, w[4 * q + 1] = v.y, w[4 * q + 2] = v.z, w[4 * q + 3] = v.w;
+            }
+        }
+        for (uint32_t c = 0; c < a.n_columns; ++c) s_x[c][t] = (uint8_t)packed_column(w, a.columns[c]);
+    }
+    const double act = live ? a.activity[row] : 0.0;
+    // this workgroup's share of the trees
+    const uint32_t per_split = (a.n_trees + a.tree_splits - 1) / a.tree_splits;
+    const uint32_t tree_begin = blockIdx.y * per_split, tree_end = min(tree_begin + per_split, a.n_trees);
+    const uint32_t tile_trees = max(1u, (uint32_t)(kRfTileBytes / sizeof(RfNode)) / a.n_nodes);
+    uint32_t ones = 0;
+    for (uint32_t t0 = tree_begin; t0 < tree_end; t0 += tile_trees) {
+        const uint32_t nt = min(tile_trees, tree_end - t0);
+        block_sync();  // the previous tile is done with (first round: the feature columns are in place)
+        const uint4 *src = (const uint4 *)(a.nodes + (size_t)t0 * a.n_nodes);
+        for (uint32_t i = t; i < nt * a.n_nodes; i += kRfRows) s_nodes[i] = src[i];
+        block_sync();
+        const RfNode *tile = (const RfNode *)s_nodes;
+        for (uint32_t k = 0; k < nt; ++k) {
+            const RfNode *tree = tile + (size_t)k * a.n_nodes;
+            RfNode nd = tree[0];
+            while (nd.status != -1) {
+                const double v = nd.column == kRfActivity ? act : (double)s_x[nd.column][t];
+                nd = tree[(v <= nd.split ? nd.left : nd.right) - 1u];
+            }
+            ones += nd.node_class == 2;
+        }
+    }
+    if (!live) return;
+    if (a.tree_splits > 1)
+        atomicAdd(&a.votes[row], ones);
+    else
+        a.votes[row] = ones;
+}
+
+hipError_t launch_rf_predict(const RfArgs &args, hipStream_t stream)
+{
+    if (args.n == 0) return hipSuccess;
+    if (args.n_columns > (uint32_t)kRfMaxColumns || (size_t)args.n_nodes * sizeof(RfNode) > (size_t)kRfTileBytes) return hipErrorInvalidValue;
+    const uint64_t tiles = (args.n + kRfRows - 1) / kRfRows;
+    if (tiles >= (1ull << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rf_predict_kernel, dim3((unsigned)tiles, args.tree_splits), dim3(kRfRows), 0, stream, args);
     return hipGetLastError();
 }
 
