@@ -625,6 +625,15 @@ def test_scoring_in_several_passes(ctx, oracle, monkeypatch):
     many = h.scores(mit=True, features=True)
     many_rows, many_mit = h.packed_features(mit=True)
     sub = h.scores(first=100, count=170, mit=True, features=True)
+    # the packed rows again in slice-major processing order (what large results on large genomes get): slices of
+    # 2^12 positions here, alone and together with the passes of 50 rows
+    monkeypatch.setenv("VSC_SCORE_SLICES", "1")
+    monkeypatch.setenv("VSC_SCORE_SLICE_SHIFT", "12")
+    sliced_rows, sliced_mit = h.packed_features(mit=True)
+    monkeypatch.delenv("VSC_SCORE_CHUNK")
+    sliced_rows2, sliced_mit2 = h.packed_features(first=37, count=len(rec) - 60, mit=True)
+    assert np.array_equal(sliced_rows, one_rows) and np.array_equal(sliced_mit, one_mit)
+    assert np.array_equal(sliced_rows2, one_rows[37:len(rec) - 23]) and np.array_equal(sliced_mit2, one_mit[37:len(rec) - 23])
     h.close()
     gen.close()
     for a, b in zip(one, many):

@@ -178,7 +178,7 @@ int vsc_ctx_destroy(vsc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->sort_temp,
-                         &ctx->score_mit, &ctx->score_flags, &ctx->score_feat, &ctx->sort_segs, &ctx->sort_tabs,
+                         &ctx->score_mit, &ctx->score_flags, &ctx->score_feat, &ctx->score_sched, &ctx->sort_segs, &ctx->sort_tabs,
                          &ctx->sort_over, &ctx->seed_k1, &ctx->seed_k2, &ctx->seed_v1, &ctx->seed_v2, &ctx->seed_off,
                          &ctx->seed_poff, &ctx->seed_lrest})
         b->release();
@@ -1289,6 +1289,30 @@ int vsc_score_hits_packed(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits
         if (mit_host) s.mit = (double *)ctx->score_mit.p;
         uint4 *dst = packed_dev ? (uint4 *)packed_dev + done * 4 : (uint4 *)ctx->score_feat.p;
         VSC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+        // large results on a large genome: visit the rows genome slice by genome slice (launch_score_schedule)
+        uint32_t kSliceShift = 28;  // 2^28 positions = 64 MB of interleaved planes
+        const uint64_t positions = genome->dev_words * 32;
+        bool scheduled = m >= (1u << 22) && positions > (3ull << kSliceShift);
+        if (const char *o = std::getenv("VSC_SCORE_SLICES")) scheduled = o[0] == '1';  // tests / experiments
+        if (const char *o = std::getenv("VSC_SCORE_SLICE_SHIFT")) kSliceShift = (uint32_t)std::min(31, std::max(8, std::atoi(o)));
+        if (scheduled) {
+            uint32_t g_edge[2] = {0, 0};
+            VSC_HIP(ctx, hipMemcpyAsync(&g_edge[0], &s.hits[0].guide, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            VSC_HIP(ctx, hipMemcpyAsync(&g_edge[1], &s.hits[m - 1].guide, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const uint32_t n_slices = (uint32_t)((positions + (1ull << kSliceShift) - 1) >> kSliceShift);
+            const uint64_t n_pairs = 2ull * (g_edge[1] - g_edge[0] + 1), n_segs = n_pairs * n_slices;
+            if (g_edge[1] >= g_edge[0] && n_segs < (1u << 24)) {
+                const size_t words = (size_t)(n_pairs * (n_slices + 1) + n_segs + n_segs + 1);
+                VSC_HIP(ctx, ctx->score_sched.ensure(words * sizeof(uint64_t)));
+                uint64_t *bounds = (uint64_t *)ctx->score_sched.p;
+                uint64_t *seg_start = bounds + n_pairs * (n_slices + 1), *seg_prefix = seg_start + n_segs;
+                VSC_HIP(ctx, launch_score_schedule(s, g_edge[0], g_edge[1], kSliceShift, n_slices, bounds, seg_start, seg_prefix, ctx->stream));
+                s.seg_start = seg_start;
+                s.seg_prefix = seg_prefix;
+                s.n_segs = (uint32_t)n_segs;
+            }
+        }
         VSC_HIP(ctx, launch_score_packed(s, dst, ctx->stream));
         VSC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         if (packed_host)

@@ -167,6 +167,12 @@ struct ScoreArgs {
     double *mit;          // may be null
     uint8_t *mit_flags;   // may be null
     uint8_t *features;    // may be null; n * 442 bytes
+    // optional processing order (score_packed_kernel): the rows are visited genome slice by genome slice so that
+    // the window gathers of everything in flight fall into one slice of the planes (see launch_score_schedule);
+    // virtual position v lies in segment j (seg_prefix[j] <= v < seg_prefix[j + 1]) and is row seg_start[j] + v - seg_prefix[j]
+    const uint64_t *seg_prefix;  // [n_segs + 1]; null: rows in index order
+    const uint64_t *seg_start;   // [n_segs]
+    uint32_t n_segs;
 };
 
 struct SeedArgs {
@@ -227,6 +233,11 @@ hipError_t launch_rf_predict(const RfArgs &args, hipStream_t stream);
 hipError_t launch_interleave(const uint32_t *hi, const uint32_t *lo, uint64_t n, uint2 *hl, hipStream_t stream);
 hipError_t launch_score(const ScoreArgs &args, hipStream_t stream);
 hipError_t launch_score_packed(const ScoreArgs &args, uint4 *packed, hipStream_t stream);
+// Fills seg_start / seg_prefix for the hits of args (sorted by guide, strand, position; guides g_lo .. g_hi occur):
+// segments = (slice of 2^slice_shift positions, guide, strand), slice-major.  bounds: scratch of
+// (g_hi - g_lo + 1) * 2 * (n_slices + 1) 64-bit words.
+hipError_t launch_score_schedule(const ScoreArgs &args, uint32_t g_lo, uint32_t g_hi, uint32_t slice_shift, uint32_t n_slices,
+                                 uint64_t *bounds, uint64_t *seg_start, uint64_t *seg_prefix, hipStream_t stream);
 hipError_t launch_score_pairs(const uint2 *on, const uint2 *off, const uint32_t *masks, uint64_t n, double *mit,
                               uint8_t *mit_flags, uint8_t *features, hipStream_t stream);
 hipError_t sort32_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);

@@ -557,18 +557,109 @@ __device__ void feature_row_packed(uint32_t on_h, uint32_t on_l, uint32_t off_h,
     }
 }
 
+// ---- processing order of the packed scoring ------------------------------------------------------------------
+// The rows are a 64-byte-per-hit stream, but every hit also gathers its 23-base window from the planes: 16 bytes
+// that cost a 64-byte sector each, at random positions of a 0.75 GB array - more traffic than the rows themselves
+// (75 B fetched per hit, round 1).  Hits are sorted by (read, strand, position), so the hits of one (read, strand)
+// inside a slice of 2^28 positions are one contiguous piece of the result.  Visiting the pieces slice by slice
+// keeps the windows of everything in flight inside 64 MB of planes, which the Infinity Cache holds; the rows still
+// land at their own index.
+//
+// bounds[k * (n_slices + 1) + e] = first hit with (read, strand) = k-th pair and position >= e << slice_shift
+__global__ __launch_bounds__(256) void score_bounds_kernel(const ScoreArgs a, uint32_t g_lo, uint32_t n_pairs, uint32_t slice_shift,
+                                                           uint32_t n_slices, uint64_t *bounds)
+{
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (uint64_t)n_pairs * (n_slices + 1)) return;
+    const uint32_t k = (uint32_t)(id / (n_slices + 1)), e = (uint32_t)(id % (n_slices + 1));
+    // key = (read << 1 | strand) << 33 | position relative to the shard; e = n_slices: the start of the next pair
+    const uint64_t want = e == n_slices ? (uint64_t)(2u * g_lo + k + 1u) << 33 : ((uint64_t)(2u * g_lo + k) << 33) | ((uint64_t)e << slice_shift);
+    uint64_t lo = 0, hi = a.n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const vsc_hit h = a.hits[mid];
+        const uint64_t key = ((uint64_t)(2u * h.guide + VSC_HIT_STRAND(h.info)) << 33) | (uint64_t)(a.contig_off[h.contig] + h.pos - a.first_pos);
+        if (key < want) lo = mid + 1; else hi = mid;
+    }
+    bounds[id] = lo;
+}
+
+// segments in slice-major order and the running sum of their lengths; one workgroup
+__global__ __launch_bounds__(1024) void score_segments_kernel(const uint64_t *bounds, uint32_t n_pairs, uint32_t n_slices,
+                                                             uint64_t *seg_start, uint64_t *seg_prefix)
+{
+    __shared__ uint64_t partial[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t n_segs = n_pairs * n_slices;
+    const uint32_t per = (n_segs + 1023) / 1024;
+    const uint32_t j0 = min(t * per, n_segs), j1 = min(j0 + per, n_segs);
+    auto length = [&](uint32_t j) {
+        const uint32_t s = j / n_pairs, k = j % n_pairs;
+        return bounds[(size_t)k * (n_slices + 1) + s + 1] - bounds[(size_t)k * (n_slices + 1) + s];
+    };
+    uint64_t sum = 0;
+    for (uint32_t j = j0; j < j1; ++j) sum += length(j);
+    partial[t] = sum;
+    block_sync();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint64_t v = t >= d ? partial[t - d] : 0;
+        block_sync();
+        partial[t] += v;
+        block_sync();
+    }
+    uint64_t run = partial[t] - sum;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint32_t s = j / n_pairs, k = j % n_pairs;
+        seg_start[j] = bounds[(size_t)k * (n_slices + 1) + s];
+        seg_prefix[j] = run;
+        run += length(j);
+    }
+    if (t == 1023) seg_prefix[n_segs] = partial[1023];
+}
+
+hipError_t launch_score_schedule(const ScoreArgs &args, uint32_t g_lo, uint32_t g_hi, uint32_t slice_shift, uint32_t n_slices,
+                                 uint64_t *bounds, uint64_t *seg_start, uint64_t *seg_prefix, hipStream_t stream)
+{
+    const uint32_t n_pairs = 2u * (g_hi - g_lo + 1u);
+    const uint64_t n_bounds = (uint64_t)n_pairs * (n_slices + 1);
+    hipLaunchKernelGGL(score_bounds_kernel, dim3((unsigned)((n_bounds + 255) / 256)), dim3(256), 0, stream, args, g_lo, n_pairs,
+                       slice_shift, n_slices, bounds);
+    hipLaunchKernelGGL(score_segments_kernel, dim3(1), dim3(1024), 0, stream, (const uint64_t *)bounds, n_pairs, n_slices, seg_start,
+                       seg_prefix);
+    return hipGetLastError();
+}
+
 // One thread per hit computes the row; the rows of a wave (64 x 64 bytes) then go through LDS so that every
 // store instruction writes 1 KB of consecutive addresses (a lane storing its own row would write 16 bytes into
 // each of 64 different 64-byte sectors per instruction - the kernel is a 64-bytes-per-hit stream).
 __global__ __launch_bounds__(256) void score_packed_kernel(const ScoreArgs a, uint4 *packed)
 {
     __shared__ uint4 s_rows[256][4];
+    __shared__ uint64_t s_index[256];  // the row every thread computed
+    __shared__ uint32_t s_seg;
     const uint32_t t = threadIdx.x;
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + t;
+    const uint64_t v = (uint64_t)blockIdx.x * 256 + t;  // position in processing order
+    uint64_t i = v;
+    if (a.seg_prefix) {
+        if (t == 0) {  // the segment of the workgroup's first position: the last j with seg_prefix[j] <= v
+            uint32_t lo = 0, hi = a.n_segs;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (a.seg_prefix[mid] <= v) lo = mid; else hi = mid;
+            }
+            s_seg = lo;
+        }
+        block_sync();
+        if (v < a.n) {
+            uint32_t j = s_seg;
+            while (v >= a.seg_prefix[j + 1]) ++j;  // a workgroup's 256 positions span one to three segments
+            i = a.seg_start[j] + (v - a.seg_prefix[j]);
+        }
+    }
     uint32_t w[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) w[k] = 0;
-    if (i < a.n) {
+    if (v < a.n) {
         const vsc_hit h = a.hits[i];
         uint32_t oh, ol;
         site_planes(a, h, oh, ol);
@@ -580,17 +671,18 @@ __global__ __launch_bounds__(256) void score_packed_kernel(const ScoreArgs a, ui
             if (a.mit_flags) a.mit_flags[i] = (uint8_t)ub;
         }
     }
+    s_index[t] = v < a.n ? i : ~0ull;
     // quarter q of row t sits in slot q ^ (t & 3): neighbouring lanes then write to different banks
 #pragma unroll
     for (int q = 0; q < 4; ++q) s_rows[t][q ^ (t & 3u)] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
     wave_sync();  // a wave only reads back its own 64 rows
     const uint32_t wave_row0 = t & ~63u, lane = t & 63u;
-    const uint64_t first = (uint64_t)blockIdx.x * 256 + wave_row0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t e = k * 64 + lane;  // 16-byte piece e of the wave's 4 KB
-        const uint32_t row = e >> 2, q = e & 3u;
-        if (first + row < a.n) packed[(first + row) * 4 + q] = s_rows[wave_row0 + row][q ^ (row & 3u)];
+        const uint32_t row = wave_row0 + (e >> 2), q = e & 3u;
+        const uint64_t at = s_index[row];
+        if (at != ~0ull) packed[at * 4 + q] = s_rows[row][q ^ (row & 3u)];
     }
 }
 
