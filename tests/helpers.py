@@ -72,3 +72,62 @@ def hits_as_tuples(h):
     """(guide, strand, contig, pos, nm, mask) tuples, ignoring the secondary flag."""
     return [(int(a), int(i >> 31), int(c), int(p), int((i >> 23) & 31), int(i & 0x7FFFFF))
             for a, c, p, i in zip(h["guide"], h["contig"], h["pos"], h["info"])]
+
+
+def real_guides(golden_dir):
+    """(names, 23-mers, activities) of the reference's own on-target list (workflow/guideseq-data/
+    guideseqOntargets.fasta + guideseqOntargetActivity.txt): several are G-rich / low complexity."""
+    import os
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(golden_dir, "guides_ontargets.tsv")) if not l.startswith("#")]
+    return [r[0] for r in rows], [r[1] for r in rows], [float(r[2]) for r in rows]
+
+
+def repeat_rich_genome(seed, n_bases, guides, n_contigs=3):
+    """A genome that is NOT uniform: Alu-like and L1-like repeat families (hundreds to thousands of diverged
+    copies), one family built around a guide (thousands of near-hits for that read), homopolymer tracts, tandem
+    repeats, GC-rich islands and N gaps.  What the uniform synthetic genome never exercises: hit buffers sized
+    from the uniform model overflow, single reads own whole bins of the sort, buckets of the seed index differ in
+    size by orders of magnitude."""
+    rng = np.random.default_rng(seed)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seq = lut[rng.integers(0, 4, size=n_bases)].copy()
+
+    def diverged(cons, rate):
+        c = cons.copy()
+        m = rng.random(len(c)) < rate
+        c[m] = lut[rng.integers(0, 4, size=int(m.sum()))]
+        return c
+
+    def paste(piece):
+        at = int(rng.integers(0, n_bases - len(piece)))
+        seq[at:at + len(piece)] = piece
+
+    g = [np.frombuffer(x.encode(), dtype=np.uint8) for x in guides]
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    alu = lut[rng.integers(0, 4, size=300)].copy()
+    alu[100:123] = g[0]                       # a family that carries the first guide ...
+    alu[200:223] = comp[g[1][::-1]]           # ... and the reverse complement of the second
+    for _ in range(max(50, n_bases // 4000)):
+        paste(diverged(alu, 0.12))
+    l1 = lut[rng.integers(0, 4, size=2000)].copy()
+    for _ in range(max(5, n_bases // 200000)):
+        paste(diverged(l1, 0.05))
+    for _ in range(max(20, n_bases // 50000)):    # homopolymers and tandem repeats
+        unit = [b"A", b"T", b"G", b"C", b"CA", b"GGAA", b"CAG", b"GT", b"GGGGCC"][int(rng.integers(0, 9))]
+        reps = int(rng.integers(20, 400)) // len(unit) + 1
+        paste(np.frombuffer(unit * reps, dtype=np.uint8))
+    for _ in range(max(5, n_bases // 500000)):    # GC-rich islands
+        n = int(rng.integers(200, 2000))
+        paste(lut[rng.choice(4, size=n, p=[0.1, 0.4, 0.4, 0.1])])
+    for gi in range(len(g)):                      # a handful of close copies of every guide, both strands
+        for _ in range(6):
+            piece = diverged(g[gi], 0.15)
+            piece[21:] = g[gi][21:]
+            paste(piece if rng.integers(0, 2) else comp[piece[::-1]])
+    for _ in range(4):                             # N gaps
+        at = int(rng.integers(0, n_bases - 5000))
+        seq[at:at + int(rng.integers(1, 3000))] = ord("N")
+    cuts = sorted(int(x) for x in rng.choice(np.arange(1000, n_bases - 1000), size=n_contigs - 1, replace=False))
+    return [p.tobytes().decode() for p in np.split(seq, cuts)]

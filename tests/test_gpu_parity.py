@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import varscot_amd as va
-from helpers import hits_as_tuples, make_genome, mutate, random_guides, random_seq, revcomp
+from helpers import real_guides, repeat_rich_genome, hits_as_tuples, make_genome, mutate, random_guides, random_seq, revcomp
 
 pytestmark = pytest.mark.gpu
 
@@ -713,3 +713,30 @@ def test_multi_device_exchange_over_rccl_with_one_rank(oracle, monkeypatch):
     finally:
         m.close()
     assert len(want) > 200 and got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("n_bases,max_mm", [(8_000_000, 8), (50_000_000, 6)])
+def test_reference_guides_on_a_repeat_rich_genome(ctx, oracle, golden_dir, n_bases, max_mm):
+    """The 16 on-target guides the reference ships (several G-rich) on a genome with repeat families, tandem
+    repeats and homopolymers: hit counts per read differ by orders of magnitude, so the hit buffers sized from the
+    uniform-genome model overflow (second search launch), single reads own oversized bins of the sort (extra
+    partition levels), and the seed buckets are skewed.  Records equal the oracle's; a second search on the same
+    genome starts from the observed hit rate and needs no re-run."""
+    names, guides, _ = real_guides(golden_dir)
+    contigs = repeat_rich_genome(20 + max_mm, n_bases, guides)
+    want = oracle.search_fast(contigs, guides, max_mm)
+    per_read = np.bincount(want["guide"], minlength=len(guides))
+    assert per_read.max() > 4 * max(1, int(np.median(per_read)))  # skew: the repeat family's guides dominate
+    gen = ctx.load_genome(va.PackedGenome.from_sequences(contigs))
+    stats = []
+    for algo in ("seed", "seed", "scan"):
+        h = gen.search(guides, max_mm, algorithm=algo)
+        got = h.to_numpy()
+        t = ctx.timing()
+        stats.append((algo, t["passes"], t["sort_levels"], len(got)))
+        h.close()
+        assert got.tobytes() == want.tobytes(), stats
+    gen.close()
+    print("repeat-rich genome, %d bases, m=%d: %d hits, per read min/median/max %d/%d/%d; (algorithm, search launches, "
+          "sort levels, hits) = %s" % (n_bases, max_mm, len(want), per_read.min(), int(np.median(per_read)), per_read.max(), stats))
+    assert stats[0][1] >= 1 and stats[1][1] == 1  # the second seed search is sized from the first one's result

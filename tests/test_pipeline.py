@@ -170,6 +170,9 @@ def test_driver_end_to_end(scenario, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     scores = [float(l.split("\t")[4]) for l in out.read_text().splitlines()[1:]]
     assert len(scores) > 20 and all(0.0 <= s <= 1.0 for s in scores)
+    # the feature matrix stays next to the result, as the reference leaves it (VARSCOT:334-342)
+    fm = (tmp_path / "res_prob_feature_matrix.txt").read_text().splitlines()
+    assert len(fm) == len(scores) + 1 and fm[0].split("\t")[0] == "totalMismatches"
     r = subprocess.run(["bash", driver, "-b", "x.bed", "-o", "o.txt", "-g", "g.fa", "-i", "i", "-m", "9", "-T", str(tmp_path / "t2")],
                        capture_output=True, text=True)
     assert r.returncode == 2 and "between 0 and 8" in r.stdout

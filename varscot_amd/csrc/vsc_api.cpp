@@ -694,6 +694,8 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
     const double own_bases = (double)genome->n_tiles * kTileBases;
     const double sites_est = genome->sites ? (double)genome->sites : own_bases / 4;
     uint64_t cap = (uint64_t)(1.5 * sites_est * n_guides * hit_probability(params->max_mismatches)) + (1u << 20);
+    const double seen_rate = genome->seen_rate[params->max_mismatches];  // 0: no search with this budget yet
+    if (algo == VSC_ALGO_SCAN) cap = std::max<uint64_t>(cap, (uint64_t)(1.2 * seen_rate * n_guides) + 4096);
     unsigned long long cnt[kCntPart + 4 * kParts] = {};
     const int n_parts = (int)((n_guides + kRegionReads - 1) / kRegionReads);  // output regions of 64 reads
 
@@ -763,7 +765,9 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         sa.reserve = 1u << sa.reserve_log2;
         sa.n_parts = (uint32_t)n_parts;
         // a region gets its share of the expected hits + 15 % (read ranges differ) + the open blocks
-        part_cap = cap / n_parts + cap / n_parts / 7 + 4096 + (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
+        part_cap = cap / n_parts + cap / n_parts / 7 + 4096;
+        part_cap = std::max<uint64_t>(part_cap, (uint64_t)(1.2 * seen_rate * std::min<uint32_t>(n_guides, kRegionReads)) + 4096);
+        part_cap += (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
         cap = part_cap * n_parts;
     }
 
@@ -819,6 +823,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         t.sites = cnt[kCntSites];
         t.pairs += cnt[kCntSites] * n_guides;
         n = cnt[kCntHits];
+        const_cast<vsc_genome *>(genome)->seen_rate[params->max_mismatches] = (double)n / n_guides;
         if (n >= (1ull << 32)) return fail(ctx, VSC_ERR_RANGE, "vsc_search: more than 2^32 hits in one scan pass (split the read set)");
         if (n > 0) {
             // level 0: (key, value) pairs -> packed records, partitioned by region
@@ -863,12 +868,15 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         t.sites = genome->index_sites;
         t.pairs += cnt[kCntSites];
         t.genome_bytes += cnt[kCntVisited] * sizeof(uint32_t);  // sites visited, 4 bytes each bit-sliced
+        double fullest = 0;
         for (int q = 0; q < n_parts; ++q) {
             const uint64_t placed = cnt[kCntPart + 4 * q], real = placed - cnt[kCntPart + 4 * q + 1];
+            fullest = std::max(fullest, (double)placed / std::min<uint32_t>(kRegionReads, n_guides - (uint32_t)q * kRegionReads));
             if (placed) segs.push_back(SortSeg{(uint64_t)q * part_cap, (uint64_t)q * part_cap, used + n, (uint32_t)placed,
                                                guide_base + (uint32_t)q * kRegionReads});
             n += real;
         }
+        const_cast<vsc_genome *>(genome)->seen_rate[params->max_mismatches] = fullest;
         if (n > 0) {
             VSC_HIP_H(ctx->keys_b.ensure(cap * sizeof(uint64_t)));
             other = (uint64_t *)ctx->keys_b.p;

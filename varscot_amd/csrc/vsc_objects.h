@@ -66,6 +66,9 @@ struct vsc_genome {
     uint32_t n_tiles = 0, n_contigs = 0;
     uint64_t device_bytes = 0;
     uint64_t sites = 0;  // PAM-valid windows seen by the last scan (sizes the next hit buffer)
+    // hits per read the last search with mismatch budget m produced (scan: all reads; seed: the fullest output
+    // region) - real genomes are not the uniform model the first buffer size comes from
+    double seen_rate[VSC_MAX_MISMATCHES + 1] = {};
     // seed index (vsc_seed.hip): the PAM-valid sites filed once per segment, sorted by bucket
     bool has_index = false;
     uint8_t index_has_extra_pam = 0;
