@@ -507,8 +507,9 @@ struct SortInfo {
 // pair_keys != null: level 0 of the streaming scan - one segment of (key, value) pairs, partitioned by region
 // into `other` and packed on the way; the regions then are the segments.
 hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg> segs, uint64_t *src, uint64_t *other,
-                    unsigned key_bits, vsc_hit *out, hipEvent_t ev_sorted, SortInfo *info)
+                    unsigned key_bits, unsigned pos_pad, vsc_hit *out, hipEvent_t ev_sorted, SortInfo *info)
 {
+    // (key_bits counts the meaningful bits: the pos_pad zero bits at the bottom of every position field are not among them)
     hipStream_t st = ctx->stream;
     unsigned rem = key_bits;  // key bits no partition level has used yet
     bool sorted_marked = false;
@@ -571,7 +572,7 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             a.cursor = a.hist + n_bins;
             a.bin_start = a.cursor + n_bins;
             a.bin_bits = bits;
-            a.bin_shift = kRecPosShift + rem - bits;
+            a.bin_shift = kRecPosShift + pos_pad + rem - bits;
             if (tiles >= 64 && !(std::getenv("VSC_SORT_XCD") && std::getenv("VSC_SORT_XCD")[0] == '0')) a.xcd_tiles = (uint32_t)((tiles + 7) / 8);
             VSC_TRY(hipMemsetAsync(a.hist, 0, n_bins * sizeof(uint32_t), st));
             VSC_TRY(launch_bin_hist(a, st));
@@ -589,7 +590,7 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
                     for (uint64_t r : recs) {
                         if (r >> 63) continue;
                         want[(r >> a.bin_shift) & (((uint64_t)1 << bits) - 1)]++;
-                        if ((r >> kRecPosShift & 0xFFFFFFFFu) > 100000u) odd++;
+                        if (((r >> kRecPosShift & 0xFFFFFFFFu) >> pos_pad) > 100000u) odd++;
                     }
                     for (size_t b = 0; b < want.size(); ++b)
                         if (want[b] != h[(i << bits) + b] || odd)
@@ -614,7 +615,8 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             sorted_marked = true;
         }
         f.sub_bits = std::min<unsigned>(kSortSubBits, rem);
-        f.sub_shift = kRecPosShift + rem - f.sub_bits;
+        f.sub_shift = kRecPosShift + pos_pad + rem - f.sub_bits;
+        f.pos_pad = pos_pad;
         f.low_bits = rem - f.sub_bits;
         f.over = (SortSeg *)((char *)ctx->sort_over.p + 256);
         f.over_cap = (uint32_t)std::min<size_t>(n_bins, 0xFFFFFFFFu);
@@ -698,6 +700,9 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
     if (algo == VSC_ALGO_SCAN) cap = std::max<uint64_t>(cap, (uint64_t)(1.2 * seen_rate * n_guides) + 4096);
     unsigned long long cnt[kCntPart + 4 * kParts] = {};
     const int n_parts = (int)((n_guides + kRegionReads - 1) / kRegionReads);  // output regions of 64 reads
+    // bits the positions of this shard need; the records keep them at the top of their 32-bit position field
+    const unsigned pos_bits = std::max(1u, ceil_log2(((uint64_t)genome->first_word + genome->dev_words) * 32));
+    const unsigned pos_pad = pos_bits < 32 ? 32 - pos_bits : 0;
 
     ScanArgs a{};
     SeedArgs sa{};
@@ -764,6 +769,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         while ((2u << sa.reserve_log2) <= want_reserve) ++sa.reserve_log2;
         sa.reserve = 1u << sa.reserve_log2;
         sa.n_parts = (uint32_t)n_parts;
+        sa.pos_pad = pos_pad;
         // a region gets its share of the expected hits + 15 % (read ranges differ) + the open blocks
         part_cap = cap / n_parts + cap / n_parts / 7 + 4096;
         part_cap = std::max<uint64_t>(part_cap, (uint64_t)(1.2 * seen_rate * std::min<uint32_t>(n_guides, kRegionReads)) + 4096);
@@ -849,6 +855,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
             l0.bin_start = l0.cursor + n_bins;
             l0.bin_bits = bits0;
             l0.bin_shift = kRecKeyBits;  // key >> 39 = read index >> 6 = region
+            l0.pos_pad = pos_pad;
             VSC_HIP_H(hipMemsetAsync(l0.hist, 0, n_bins * sizeof(uint32_t), ctx->stream));
             VSC_HIP_H(launch_bin_hist(l0, ctx->stream));
             VSC_HIP_H(launch_bin_scan(l0, ctx->stream));
@@ -887,8 +894,8 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         ht.lap("sort buffers");
         VSC_HIP_H(result_room(ctx, hits, used, n, projected));
         ht.lap("record storage");
-        const unsigned key_bits = 33 + ceil_log2(std::min<uint32_t>(n_guides, kRegionReads));
-        VSC_HIP_H(bin_sort(ctx, genome, std::move(segs), src, other, key_bits, hits->d_records, ctx->ev[3], &info));
+        const unsigned key_bits = pos_bits + 1 + ceil_log2(std::min<uint32_t>(n_guides, kRegionReads));
+        VSC_HIP_H(bin_sort(ctx, genome, std::move(segs), src, other, key_bits, pos_pad, hits->d_records, ctx->ev[3], &info));
     } else {
         VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
     }

@@ -502,7 +502,7 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
         if (at_edge && is_contig_end(a.contig_end, a.n_contigs, pos + VSC_READ_LEN)) hit = false;
     }
     const uint64_t rec = ((uint64_t)(gid_of & (uint32_t)(kRegionReads - 1)) << kRecReadShift) | ((uint64_t)strand << kRecStrandShift) |
-                         ((uint64_t)pos << kRecPosShift) | mask;
+                         ((uint64_t)(pos << a.pos_pad) << kRecPosShift) | mask;
     sliced_store(a, w, hit, gid_of >> kRegionBits, rec);
 }
 

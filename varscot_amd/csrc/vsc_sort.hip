@@ -82,9 +82,10 @@ __device__ __forceinline__ uint32_t segment_of_tile(const uint32_t *seg_tile0, u
 }
 
 // level 0: a (key, value) pair of the streaming scan -> packed record (the read's region is the bin, not part of it)
-__device__ __forceinline__ uint64_t pack_pair(uint64_t key, uint32_t val)
+__device__ __forceinline__ uint64_t pack_pair(uint64_t key, uint32_t val, uint32_t pos_pad)
 {
-    return ((key & ((1ull << kRecKeyBits) - 1ull)) << kRecPosShift) | (val & kMask23);
+    const uint64_t high = (key >> 32) & ((1ull << (kRecKeyBits - 32)) - 1ull);  // read inside its region, strand
+    return (((high << 32) | (uint32_t)((uint32_t)key << pos_pad)) << kRecPosShift) | (val & kMask23);
 }
 
 }  // namespace
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
         const uint64_t at = sg.in_off + first + (in_tile ? i : 0u);
         if (kPairs) {
             const uint64_t key = a.pair_keys[at];
-            r[k] = in_tile ? pack_pair(key, a.pair_vals[at]) : kRecSentinel;
+            r[k] = in_tile ? pack_pair(key, a.pair_vals[at], a.pos_pad) : kRecSentinel;
             bin[k] = in_tile ? (uint32_t)(key >> a.bin_shift) : 0u;
         } else {
             const uint64_t v = a.in[at];
@@ -381,8 +382,8 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
             // the end of the last sub-bin (slot nsub: the low half of the spare word, or the high half of the only word)
             if (nsub > 1u) s_sub[nwords] = n;
             // contigs the bin's position range touches: keys agree in all bits above the sub-bin and rank fields
-            const uint32_t free_bits = a.sub_bits + a.low_bits;
-            const uint32_t any = (uint32_t)(in[0] >> kRecPosShift);  // sentinels (level 1 without partition) have all bits set: range = everything
+            const uint32_t free_bits = a.sub_bits + a.low_bits;  // key bits the bin leaves open, all of them position bits or more
+            const uint32_t any = (uint32_t)(in[0] >> kRecPosShift) >> a.pos_pad;  // sentinels (level 1 without partition) have all bits set: range = everything
             const uint32_t p_lo = free_bits >= 32u ? 0u : (any >> free_bits) << free_bits;
             const uint32_t p_hi = free_bits >= 32u ? 0xFFFFFFFFu : p_lo | ((1u << free_bits) - 1u);
             uint32_t c_lo, c_hi;
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
             }
         }
         if (!live) continue;
-        const uint32_t pos = (uint32_t)(x >> kRecPosShift);
+        const uint32_t pos = (uint32_t)(x >> kRecPosShift) >> a.pos_pad;
         uint32_t c, start;
         if (c_n <= (uint32_t)kFinalizeNear) {
             // the usual case: the bin's positions lie in at most four contigs - three comparisons
