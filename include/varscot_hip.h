@@ -163,8 +163,8 @@ int vsc_genome_load(vsc_ctx *ctx, const uint32_t *hi, const uint32_t *lo, const 
 int vsc_genome_free(vsc_genome *genome);
 /* Builds (or keeps, if it matches) the seed index of a resident genome for the PAM set of `params`
  * (NULL = GG, GA only): the PAM-valid, N-free windows of both strands, filed once per 7-base
- * segment in bucket order (a 16-byte record + 4 bytes of bit-sliced planes per window and segment:
- * 60 bytes per window).  Plays the part of `bidir_index`
+ * segment in bucket order (an 8-byte record + 4 bytes of bit-sliced planes per window and segment:
+ * 36 bytes per window).  Plays the part of `bidir_index`
  * (read_mapping/bidir_index.cpp:45-47); vsc_search builds it on demand. */
 int vsc_genome_build_index(vsc_ctx *ctx, vsc_genome *genome, const vsc_search_params *params);
 /* Bytes of HBM the resident genome (planes + seed index) occupies. */

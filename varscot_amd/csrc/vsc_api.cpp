@@ -280,7 +280,7 @@ int vsc_genome_free(vsc_genome *g)
     if (!g) return VSC_OK;
     if (g->ctx) (void)hipSetDevice(g->ctx->device);
     for (void *p : {(void *)g->d_hi, (void *)g->d_lo, (void *)g->d_nm, (void *)g->d_contig_off, (void *)g->d_contig_end, (void *)g->d_hl,
-                    (void *)g->d_ix_bucket_start, (void *)g->d_ix_chunk_tab, (void *)g->d_ix_vert, (void *)g->d_ix_sites})
+                    (void *)g->d_ix_chunk_tab, (void *)g->d_ix_vert, (void *)g->d_ix_sites, (void *)g->d_ix_edge})
         if (p) (void)hipFree(p);
     delete g;
     return VSC_OK;
@@ -341,7 +341,7 @@ bool index_matches(const vsc_genome *g, const vsc_search_params *p)
 
 void free_index(vsc_genome *g)
 {
-    for (void **p : {(void **)&g->d_ix_bucket_start, (void **)&g->d_ix_chunk_tab, (void **)&g->d_ix_vert, (void **)&g->d_ix_sites}) {
+    for (void **p : {(void **)&g->d_ix_chunk_tab, (void **)&g->d_ix_vert, (void **)&g->d_ix_sites, (void **)&g->d_ix_edge}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -374,21 +374,28 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         *why = "too many PAM-valid sites for 32-bit table indices";
         return hipErrorInvalidValue;
     }
-    DeviceBuf sx, sl, sp, k1, k2, i1, i2, tmp;
+    // Temporaries: the extracted sites (sx, sl, sp), sort scratch, the bucket-ordered sites as 16-byte records
+    // (full planes: what the bit-slicing pass reads) and the (bucket, strand) starts; all released before returning.
+    DeviceBuf sx, sl, sp, k1, k2, i1, i2, tmp, full, starts;
     auto release = [&]() {
-        for (DeviceBuf *b : {&sx, &sl, &sp, &k1, &k2, &i1, &i2, &tmp}) b->release();
+        for (DeviceBuf *b : {&sx, &sl, &sp, &k1, &k2, &i1, &i2, &tmp, &full, &starts}) b->release();
     };
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t r) {
         if (e == hipSuccess) e = r;
     };
+    constexpr uint32_t kKeys = 2 * kBuckets;  // (bucket, strand) pairs: inside a bucket '+' sites precede '-' sites
     const size_t n4 = std::max<uint64_t>(S, 1) * sizeof(uint32_t);
     for (DeviceBuf *b : {&sx, &sl, &sp, &k1, &k2, &i1, &i2}) step(b->ensure(n4));
     size_t temp_bytes = 0;
-    step(sort32_temp_bytes(S, 2 * kSegBases, &temp_bytes));
+    step(sort32_temp_bytes(S, 2 * kSegBases + 1, &temp_bytes));
     step(tmp.ensure(std::max<size_t>(temp_bytes, 16)));
-    step(hipMalloc((void **)&g->d_ix_sites, std::max<uint64_t>(3 * S, 1) * sizeof(uint4)));
-    step(hipMalloc((void **)&g->d_ix_bucket_start, (kBuckets + 1) * sizeof(uint32_t)));
+    step(full.ensure(std::max<uint64_t>(3 * S, 1) * sizeof(uint4)));
+    step(starts.ensure((kKeys + 1) * sizeof(uint32_t)));
+    const size_t edge_words = (size_t)((3 * S + 31) / 32 + 1);
+    step(hipMalloc((void **)&g->d_ix_sites, std::max<uint64_t>(3 * S, 1) * sizeof(uint2)));
+    step(hipMalloc((void **)&g->d_ix_edge, edge_words * sizeof(uint32_t)));
+    if (e == hipSuccess) step(hipMemsetAsync(g->d_ix_edge, 0, edge_words * sizeof(uint32_t), st));
     if (e == hipSuccess && S > 0) {
         // pass 2: emit
         a.site_x = (uint32_t *)sx.p;
@@ -398,40 +405,46 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         step(hipMemsetAsync(ctx->counters.p, 0, sizeof cnt, st));
         step(launch_scan(a, n_groups, true, st));
     }
+    uint4 *const sites16 = (uint4 *)full.p;
     for (int s = 0; s < kSegments && e == hipSuccess; ++s) {
         step(launch_seed_keys((const uint32_t *)sx.p, (const uint32_t *)sl.p, S, s, (uint32_t *)k1.p, (uint32_t *)i1.p, st));
         step(launch_sort32(tmp.p, temp_bytes, (const uint32_t *)k1.p, (uint32_t *)k2.p, (const uint32_t *)i1.p,
-                           (uint32_t *)i2.p, S, 2 * kSegBases, st));
+                           (uint32_t *)i2.p, S, 2 * kSegBases + 1, st));
         step(launch_seed_gather16((const uint32_t *)sx.p, (const uint32_t *)sl.p, (const uint32_t *)sp.p,
-                                  (const uint32_t *)i2.p, S, g->d_ix_sites + (size_t)s * S, st));
-        step(launch_lower_bound((const uint32_t *)k2.p, S, kBucketsPerSeg, 0, (uint32_t)(s * S),
-                                g->d_ix_bucket_start + (size_t)s * kBucketsPerSeg, st));
+                                  (const uint32_t *)i2.p, S, sites16 + (size_t)s * S, st));
+        step(launch_lower_bound((const uint32_t *)k2.p, S, 2 * kBucketsPerSeg, 0, (uint32_t)(s * S),
+                                (uint32_t *)starts.p + (size_t)s * 2 * kBucketsPerSeg, st));
     }
-    std::vector<uint32_t> bs(kBuckets + 1, 0);
+    std::vector<uint32_t> bs(kKeys + 1, 0);  // bs[2 b + strand] = first site of bucket b on that strand
     if (e == hipSuccess) {
-        step(hipMemcpyAsync(bs.data(), g->d_ix_bucket_start, bs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        step(launch_seed_compact(sites16, std::max<uint64_t>(S, 1), 3 * S, g->d_ix_sites, g->d_ix_edge, st));
+        step(hipMemcpyAsync(bs.data(), starts.p, bs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         step(hipStreamSynchronize(st));
     }
-    release();
     if (e != hipSuccess) {
+        release();
         free_index(g);
         return e;
     }
     // chunks: at most kSlicedChunk sites of one bucket each; the sites of a chunk also exist bit-sliced, in
-    // blocks of 32, from block `vfirst` on
+    // blocks of 32, from block `vfirst` on.  Word z: bucket | rank in the chunk of its first '-' site << 16
+    // (| edge flag << 28, set on the device below)
     const uint64_t chunk_sites = kSlicedChunk;
-    std::vector<uint32_t> ctab;  // {first site, site count, bucket, first vertical block} per chunk
+    std::vector<uint32_t> ctab;  // {first site, site count, z, first vertical block} per chunk
     ctab.reserve(4 * (3 * S / chunk_sites + kBuckets));
     uint64_t n_blocks = 0;
-    for (uint32_t b = 0; b < (uint32_t)kBuckets; ++b)
-        for (uint64_t p = bs[b]; p < bs[b + 1]; p += chunk_sites) {
-            const uint64_t count = std::min<uint64_t>(chunk_sites, bs[b + 1] - p);
+    for (uint32_t b = 0; b < (uint32_t)kBuckets; ++b) {
+        const uint64_t minus = bs[2 * b + 1];
+        for (uint64_t p = bs[2 * b]; p < bs[2 * b + 2]; p += chunk_sites) {
+            const uint64_t count = std::min<uint64_t>(chunk_sites, bs[2 * b + 2] - p);
+            const uint64_t minus_from = minus <= p ? 0 : std::min<uint64_t>(minus - p, count);
             ctab.push_back((uint32_t)p);
             ctab.push_back((uint32_t)count);
-            ctab.push_back(b);
+            ctab.push_back(b | (uint32_t)(minus_from << kChunkMinusShift));
             ctab.push_back((uint32_t)n_blocks);
             n_blocks += (count + kSlicedSites - 1) / kSlicedSites;
         }
+    }
     g->ix_chunks = (uint32_t)(ctab.size() / 4);
     const size_t cb = std::max<size_t>(ctab.size(), 4) * sizeof(uint32_t);
     const size_t vb = std::max<uint64_t>(n_blocks, 1) * 2 * kRestBases * sizeof(uint32_t);
@@ -439,9 +452,11 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
     if (e == hipSuccess && !ctab.empty())
         step(hipMemcpyAsync(g->d_ix_chunk_tab, ctab.data(), ctab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     step(hipMalloc((void **)&g->d_ix_vert, vb));
-    if (e == hipSuccess) step(launch_seed_transpose(g->d_ix_sites, g->d_ix_chunk_tab, g->ix_chunks, g->d_ix_vert, st));
+    if (e == hipSuccess) step(launch_seed_transpose(sites16, g->d_ix_chunk_tab, g->ix_chunks, g->d_ix_vert, st));
+    if (e == hipSuccess) step(launch_seed_chunk_flags(g->d_ix_chunk_tab, g->ix_chunks, g->d_ix_edge, st));
     step(hipEventRecord(ctx->ev[6], st));
     step(hipStreamSynchronize(st));
+    release();
     if (e != hipSuccess) {
         free_index(g);
         return e;
@@ -457,7 +472,7 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         g->index_extra_pam[0] = params->extra_pam[0];
         g->index_extra_pam[1] = params->extra_pam[1];
     }
-    g->index_bytes = 3 * S * sizeof(uint4) + (kBuckets + 1) * sizeof(uint32_t) + cb + vb;
+    g->index_bytes = 3 * S * sizeof(uint2) + edge_words * sizeof(uint32_t) + cb + vb;
     return hipSuccess;
 }
 
@@ -740,12 +755,12 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
                                     (uint32_t *)ctx->seed_off.p, (uint32_t *)ctx->seed_poff.p, (const uint2 *)ctx->guides.p,
                                     (uint4 *)ctx->seed_lrest.p, ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
-        sa.bucket_start = genome->d_ix_bucket_start;
         sa.chunk_tab = genome->d_ix_chunk_tab;
         sa.n_chunks = genome->ix_chunks;
         sa.vert = genome->d_ix_vert;
         sa.list_rest = (const uint4 *)ctx->seed_lrest.p;
         sa.sites = genome->d_ix_sites;
+        sa.edge_bits = genome->d_ix_edge;
         sa.guides = (const uint2 *)ctx->guides.p;
         sa.poff = (const uint32_t *)ctx->seed_poff.p;
         sa.max_mm = params->max_mismatches;

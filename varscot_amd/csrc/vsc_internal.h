@@ -39,6 +39,11 @@ constexpr int kTokLaneShift = 26;               // sliced hit token, high word: 
 constexpr int kSlicedResolve = 3;                // sliced kernel: resolve when this many passes of 64 tokens wait (the
                                                 // gathers of the later passes overlap the earlier ones)
 constexpr int kSlicedTokCap = (kSlicedResolve + 4) * 64;  // per-wave LDS ring of 16-byte hit tokens: a group of four reads adds <= 256
+// chunk table word z: bucket (16 bits) | rank in the chunk of its first '-' site (0 .. 2048) << 16 | "holds a window
+// that is followed by N" << 28
+constexpr uint32_t kChunkBucketMask = 0xFFFFu;
+constexpr int kChunkMinusShift = 16;
+constexpr int kChunkEdgeBit = 28;
 constexpr int kSlicedGrab = 8;                  // chunks of 2048 sites per grab of the work counter (sliced kernel)
 
 // counters[] slots of one scan launch
@@ -180,11 +185,11 @@ struct ScoreArgs {
 };
 
 struct SeedArgs {
-    const uint32_t *bucket_start;  // [kBuckets + 1] first site of every bucket
-    const uint4 *chunk_tab;        // [n_chunks] {first site, site count, bucket, first vertical block}
+    const uint4 *chunk_tab;        // [n_chunks] {first site, site count, bucket | first '-' rank << 16 | edge << 28, first vertical block}
     const uint32_t *vert;          // bit-sliced copies of the sites: 32 words per block of 32 sites (see seed_transpose_kernel)
     const uint4 *list_rest;        // per list entry {rest(hi) | rest(lo) << 16, read | distance << 30, hi, lo}
-    const uint4 *sites;            // {hi plane | strand | edge, lo plane, position, 0} per site
+    const uint2 *sites;            // {rest(hi) | rest(lo) << 16, position} per site
+    const uint32_t *edge_bits;     // 1 bit per site: its window is followed by N
     const uint2 *guides;           // (hi plane, lo plane) per read
     uint32_t n_chunks;
     const uint32_t *poff;          // [kBuckets + 1] first list entry of every bucket (multiples of kGuideUnroll)
@@ -259,6 +264,9 @@ hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted
                              uint32_t *poff, const uint2 *guides, uint4 *list_rest, hipStream_t stream);
 hipError_t launch_seed_gather16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, const uint32_t *idx, uint64_t n,
                                 uint4 *out, hipStream_t stream);
+hipError_t launch_seed_compact(const uint4 *sites16, uint64_t n_per_table, uint64_t n, uint2 *sites8, uint32_t *edge_bits,
+                               hipStream_t stream);
+hipError_t launch_seed_chunk_flags(uint4 *chunk_tab, uint32_t n_chunks, const uint32_t *edge_bits, hipStream_t stream);
 hipError_t launch_seed_transpose(const uint4 *sites, const uint4 *chunk_tab, uint32_t n_chunks, uint32_t *vert,
                                  hipStream_t stream);
 hipError_t launch_seed_sliced(const SeedArgs &args, int n_groups, hipStream_t stream);

@@ -74,10 +74,10 @@ struct vsc_genome {
     uint8_t index_has_extra_pam = 0;
     char index_extra_pam[2] = {0, 0};
     uint64_t index_sites = 0;  // S
-    uint32_t *d_ix_bucket_start = nullptr;
     uint4 *d_ix_chunk_tab = nullptr;
     uint32_t *d_ix_vert = nullptr;  // bit-sliced blocks of 32 sites
-    uint4 *d_ix_sites = nullptr;    // 16-byte site records
+    uint2 *d_ix_sites = nullptr;    // 8-byte site records {rest planes, position}
+    uint32_t *d_ix_edge = nullptr;  // 1 bit per site: window followed by N
     uint32_t ix_chunks = 0;
     uint64_t index_bytes = 0;
     double index_ms = 0;

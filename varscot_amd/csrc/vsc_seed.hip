@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void seed_key_kernel(const uint32_t *x, const 
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    keys[i] = segment_key(x[i], l[i], seg);
+    // bucket, then strand: inside a bucket the '+' sites precede the '-' sites, so that a chunk needs one number
+    // (where its '-' sites begin) instead of a strand bit per site record
+    keys[i] = (segment_key(x[i], l[i], seg) << 1) | ((x[i] >> kSiteStrandBit) & 1u);
     idx[i] = (uint32_t)i;
 }
 
@@ -79,6 +81,57 @@ hipError_t launch_seed_gather16(const uint32_t *x, const uint32_t *l, const uint
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(seed_gather16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, l, pos, idx, n, out);
+    return hipGetLastError();
+}
+
+// The resident site records of the hit path, 8 bytes: x = the 16 read positions OUTSIDE the table's segment
+// (rest(hi) | rest(lo) << 16, the layout of a read-list entry), y = global position.  The segment's 7 bases
+// are the bucket's code, the strand follows from the site's rank in its chunk (chunk table), and the rare
+// "window is followed by N" flag lives in a bitmap that only chunks flagged in the chunk table look at.
+__device__ __forceinline__ uint32_t rest_of(uint32_t v, uint32_t seg);
+
+__global__ __launch_bounds__(256) void seed_compact_kernel(const uint4 *sites16, uint64_t n_per_table, uint64_t n, uint2 *sites8,
+                                                           uint32_t *edge_bits)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 r = sites16[i];
+    const uint32_t seg = (uint32_t)(i / n_per_table);
+    sites8[i] = make_uint2(rest_of(r.x, seg) | (rest_of(r.y, seg) << 16), r.z);
+    if ((r.x >> kSiteEdgeBit) & 1u) atomicOr(&edge_bits[i >> 5], 1u << (i & 31u));
+}
+
+// chunk_tab[c].z |= 1 << 28 where the chunk holds a site whose window is followed by N
+__global__ __launch_bounds__(256) void seed_chunk_flags_kernel(uint4 *chunk_tab, uint32_t n_chunks, const uint32_t *edge_bits)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint4 ct = chunk_tab[c];
+    if (ct.y == 0) return;
+    const uint32_t first = ct.x, last = ct.x + ct.y - 1;
+    uint32_t any = 0;
+    for (uint32_t w = first >> 5; w <= last >> 5; ++w) {
+        uint32_t bits = edge_bits[w];
+        if (w == first >> 5) bits &= 0xFFFFFFFFu << (first & 31u);
+        if (w == last >> 5) bits &= 0xFFFFFFFFu >> (31u - (last & 31u));
+        any |= bits;
+    }
+    if (any) chunk_tab[c].z = ct.z | (1u << kChunkEdgeBit);
+}
+
+hipError_t launch_seed_compact(const uint4 *sites16, uint64_t n_per_table, uint64_t n, uint2 *sites8, uint32_t *edge_bits,
+                               hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(seed_compact_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sites16, n_per_table, n, sites8,
+                       edge_bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_seed_chunk_flags(uint4 *chunk_tab, uint32_t n_chunks, const uint32_t *edge_bits, hipStream_t stream)
+{
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(seed_chunk_flags_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, chunk_tab, n_chunks, edge_bits);
     return hipGetLastError();
 }
 
@@ -222,6 +275,7 @@ struct SeedWave {
     uint32_t thead;  // ring slot of the oldest pending token
     uint32_t *parts; // per output region: this wave's open block, block number << 11 | records claimed in it
     uint32_t *first; // first site of every chunk of the current grab (tokens name their chunk by slot)
+    uint32_t *info;  // ... and word z of its chunk table entry: bucket | rank of the first '-' site << 16 | edge flag << 28
 };
 
 // A per-pair comparison (xor, or, popcount, compare) spends 4 VALU instructions per (site, read) pair and lane.
@@ -250,7 +304,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_transpose_kernel(c
     if (c >= n_chunks) return;
     const uint32_t lane = threadIdx.x % kWave;
     const uint4 ct = chunk_tab[c];
-    const uint32_t seg = ct.z / (uint32_t)kBucketsPerSeg;
+    const uint32_t seg = (ct.z & kChunkBucketMask) / (uint32_t)kBucketsPerSeg;
     for (uint32_t k = 0; k * kWave < ct.y; ++k) {
         const uint32_t i = k * kWave + lane;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -367,14 +421,15 @@ __device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[2 * kRestB
 }
 
 // Second half of the hit path.  A token = {hit word of one lane's block, read | owner lane << 26, read hi
-// plane, read lo plane}; a lane takes one token and resolves its LOWEST set bit: one 16-byte gather of the
-// site record gives the full 23-position mask, the strand and the position.  A token with more bits goes
+// plane | chunk slot << 23, read lo plane}; a lane takes one token and resolves its LOWEST set bit: one 8-byte
+// gather of the site record (rest planes, position) + the bucket's code and the chunk's strand boundary (LDS)
+// give the full 23-position mask, the strand and the position.  A token with more bits goes
 // back into the ring with that bit cleared, so every pass over 64 tokens is dense.  The gather of the next
 // 64 tokens is issued before the current 64 are consumed.
 struct SlicedFetch {
     uint32_t word, hi, site0, z;  // z = read hi plane | chunk slot << 23, as in the token
     uint2 gp;   // read planes
-    uint4 rec;  // site record of the lowest set bit
+    uint2 rec;  // site record of the lowest set bit
 };
 
 // Output of the sliced kernel.  A wave keeps, per output region (64 reads), an open block of `reserve`
@@ -460,7 +515,7 @@ __device__ __forceinline__ SlicedFetch sliced_fetch(const SeedArgs &a, const See
     f.site0 = 0;
     f.z = 0;
     f.gp = make_uint2(0u, 0u);
-    f.rec = make_uint4(0u, 0u, 0u, 0u);
+    f.rec = make_uint2(0u, 0u);
     if (w.lane < n) {
         const uint4 tk = w.tok4[ring_slot(head + w.lane)];
         f.word = tk.x;
@@ -491,15 +546,29 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
     // few instructions cost more scalar mask bookkeeping than the instructions themselves.  Only the
     // right-edge rule - a binary search, needed by windows that end a contig - sits behind a wave-uniform test.
     const uint32_t gid_of = f.hi & ((1u << kTokLaneShift) - 1u);
-    const uint32_t t = ((f.rec.x ^ f.gp.x) | (f.rec.y ^ f.gp.y)) & kMask23;
-    const uint32_t strand = (f.rec.x >> kSiteStrandBit) & 1u;
-    const uint32_t pos = f.rec.z;
+    // the site's 23-base planes: its 16 rest positions from the record, the 7 segment positions = the bucket's code
+    const uint32_t info = w.info[f.z >> 23];  // chunk table word z of the token's chunk
+    const uint32_t bucket = info & kChunkBucketMask;
+    const uint32_t sh = (uint32_t)kSegBases * (bucket >> (2 * kSegBases));  // 7 x segment
+    const uint32_t low = (1u << sh) - 1u;
+    const uint32_t rest_hi = f.rec.x & 0xFFFFu, rest_lo = f.rec.x >> 16;
+    const uint32_t site_hi = (rest_hi & low) | (((bucket >> kSegBases) & 0x7Fu) << sh) | ((rest_hi >> sh) << (sh + kSegBases));
+    const uint32_t site_lo = (rest_lo & low) | ((bucket & 0x7Fu) << sh) | ((rest_lo >> sh) << (sh + kSegBases));
+    const uint32_t t = ((site_hi ^ f.gp.x) | (site_lo ^ f.gp.y)) & kMask23;
+    // '-' sites are the tail of their bucket: from rank `minus_from` of the chunk on
+    const uint32_t rank_in_chunk = (f.hi >> kTokLaneShift) * kSlicedSites + (uint32_t)__builtin_ctz(f.word | 0x80000000u);
+    const uint32_t strand = rank_in_chunk >= ((info >> kChunkMinusShift) & 0xFFFu) ? 1u : 0u;
+    const uint32_t pos = f.rec.y;
     // (pairs that an earlier segment reports never become tokens: sliced_within)
     const uint32_t mask = strand ? reverse23(t) : t;
-    // right-edge rule, bidir_mapping.cpp:51-52 (see emit_hits in vsc_kernels.hip)
-    const bool at_edge = hit && ((f.rec.x >> kSiteEdgeBit) & 1u) && (uint32_t)__popc(mask >> (VSC_READ_LEN / 2)) > a.k_half;
-    if (__ballot(at_edge) != 0) {
-        if (at_edge && is_contig_end(a.contig_end, a.n_contigs, pos + VSC_READ_LEN)) hit = false;
+    // right-edge rule, bidir_mapping.cpp:51-52 (see emit_hits in vsc_kernels.hip): only chunks that hold a window
+    // followed by N are flagged, and only their hits look the site up in the bitmap
+    const bool maybe_edge = hit && ((info >> kChunkEdgeBit) & 1u) && (uint32_t)__popc(mask >> (VSC_READ_LEN / 2)) > a.k_half;
+    if (__ballot(maybe_edge) != 0) {
+        if (maybe_edge) {
+            const uint32_t site = f.site0 + (uint32_t)__builtin_ctz(f.word);
+            if (((a.edge_bits[site >> 5] >> (site & 31u)) & 1u) && is_contig_end(a.contig_end, a.n_contigs, pos + VSC_READ_LEN)) hit = false;
+        }
     }
     const uint64_t rec = ((uint64_t)(gid_of & (uint32_t)(kRegionReads - 1)) << kRecReadShift) | ((uint64_t)strand << kRecStrandShift) |
                          ((uint64_t)(pos << a.pos_pad) << kRecPosShift) | mask;
@@ -561,7 +630,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     __shared__ uint4 s_tok[kWavesPerGroup][kSlicedTokCap];
     __shared__ uint4 s_list[kWavesPerGroup][kWave];  // the current tile of 64 read-list entries
     __shared__ uint32_t s_parts[kWavesPerGroup][kParts];
-    __shared__ uint32_t s_first[kWavesPerGroup][kSlicedGrab];
+    __shared__ uint32_t s_first[kWavesPerGroup][2 * kSlicedGrab];
 
     const uint32_t wave = threadIdx.x / kWave;
     SeedWave w;
@@ -571,6 +640,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     w.thead = 0;
     w.parts = s_parts[wave];
     w.first = s_first[wave];
+    w.info = s_first[wave] + kSlicedGrab;
     for (uint32_t q = w.lane; q < (uint32_t)kParts; q += kWave) w.parts[q] = a.reserve;  // no block yet = a used-up one
 
     uint4 *const lt = s_list[wave];
@@ -605,11 +675,11 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
         // With ~13 reads per bucket (1 000 reads) a chunk is compared in less time than one HBM round trip.
         v4u t0 = ctab[first];                             // chunk c     : A done
         v4u t1 = ctab[min(first + 1, last - 1)];          // chunk c + 1 : A in flight
-        uint32_t p0a = poff[t0.z], p0b = poff[t0.z + 1];  // chunk c     : B done
+        uint32_t p0a = poff[t0.z & kChunkBucketMask], p0b = poff[(t0.z & kChunkBucketMask) + 1];  // chunk c     : B done
         uint32_t nv[2 * kRestBases];
         sliced_load_sites(a, t0, p0a != p0b, w.lane, nv);  // chunk c     : C in flight
         uint4 nl = sliced_load_list(a, p0a, p0b, w.lane);   //               and the first 64 entries of its read list
-        uint32_t p1a = poff[t1.z], p1b = poff[t1.z + 1];  // chunk c + 1 : B in flight
+        uint32_t p1a = poff[t1.z & kChunkBucketMask], p1b = poff[(t1.z & kChunkBucketMask) + 1];  // chunk c + 1 : B in flight
         v4u t2 = ctab[min(first + 2, last - 1)];          // chunk c + 2 : A in flight
         for (uint32_t c = first; c < last; ++c) {
             const v4u cur = t0;
@@ -625,14 +695,17 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
             sliced_load_sites(a, t0, c + 1 < last && p0a != p0b, w.lane, nv);
             nl = sliced_load_list(a, p0a, c + 1 < last ? p0b : p0a, w.lane);
             t1 = t2;
-            p1a = poff[t1.z];
-            p1b = poff[t1.z + 1];
+            p1a = poff[t1.z & kChunkBucketMask];
+            p1b = poff[(t1.z & kChunkBucketMask) + 1];
             t2 = ctab[min(c + 3, last - 1)];
             if (g0 == g1) continue;  // no read has this bucket in its neighbourhood
             const uint32_t slot_tag = (c - first) << 23;  // the tokens of this chunk carry its slot in the grab
-            if (w.lane == 0) w.first[c - first] = cur.x;
+            if (w.lane == 0) {
+                w.first[c - first] = cur.x;
+                w.info[c - first] = cur.z;
+            }
             wave_sync();
-            const uint32_t seg = cur.z / (uint32_t)kBucketsPerSeg;
+            const uint32_t seg = (cur.z & kChunkBucketMask) / (uint32_t)kBucketsPerSeg;
             // sites of this lane's block that exist
             const int32_t left = (int32_t)cur.y - (int32_t)(w.lane * kSlicedSites);
             const uint32_t valid = left >= kSlicedSites ? 0xFFFFFFFFu : (left > 0 ? (1u << left) - 1u : 0u);
