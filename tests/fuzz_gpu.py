@@ -24,7 +24,7 @@ from oracle import pyoracle  # noqa: E402
 def one(ctx, seed):
     rng = np.random.default_rng(seed)
     max_mm = int(rng.integers(0, 9))
-    n_guides = int(rng.choice([1, 3, 17, 64, 300]))
+    n_guides = int(rng.choice([1, 3, 17, 64, 65, 300, 1500]))
     guides = random_guides(rng, n_guides, pam=str(rng.choice(["GG", "GG", "GA", "AG"])))
     # near-duplicate reads and low-complexity reads
     for _ in range(n_guides // 4):
@@ -60,6 +60,28 @@ def one(ctx, seed):
     n_rec = 0
     for algo in ("scan", "seed"):
         world = int(rng.integers(1, 4))
+        # sort knobs: smaller LDS capacity / fewer bits per level force partition levels and the oversize path
+        for k, choices in (("VSC_SORT_CAP", [None, None, "64", "1000"]), ("VSC_SORT_MAX_BITS", [None, None, "2", "5"]),
+                           ("VSC_SEED_RESERVE", [None, "64", "1024"])):
+            v = choices[int(rng.integers(0, len(choices)))]
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        if world > 1 and rng.integers(0, 2):  # the shards behind the C ABI: contexts on this device, gather, merge
+            m = va.MultiContext([0] * world)
+            g = m.load_genome(packed)
+            h = g.search(guides, max_mm, extra, algorithm=algo)
+            got = h.to_numpy().copy()
+            h.close()
+            g.close()
+            m.close()
+            if hits_as_tuples(got) != hits_as_tuples(want):
+                return "seed %d: %s multi x%d differs (m=%d, %d reads, contigs %s, extra %s, env %s): %d vs %d records" % (
+                    seed, algo, world, max_mm, len(guides), lens, extra,
+                    {k: os.environ.get(k) for k in ("VSC_SORT_CAP", "VSC_SORT_MAX_BITS", "VSC_SEED_RESERVE")}, len(got), len(want))
+            n_rec = len(got)
+            continue
         parts = []
         for rank in range(world):
             b, e = packed.shard_words(rank, world)
@@ -75,8 +97,9 @@ def one(ctx, seed):
             key = (got["guide"].astype(np.int64) << 1) | (got["info"] >> 31)
             got = got[np.argsort(key, kind="stable")]
         if hits_as_tuples(got) != hits_as_tuples(want):
-            return "seed %d: %s x%d differs (m=%d, %d reads, contigs %s, extra %s): %d vs %d records" % (
-                seed, algo, world, max_mm, len(guides), lens, extra, len(got), len(want))
+            return "seed %d: %s x%d differs (m=%d, %d reads, contigs %s, extra %s, env %s): %d vs %d records" % (
+                seed, algo, world, max_mm, len(guides), lens, extra,
+                {k: os.environ.get(k) for k in ("VSC_SORT_CAP", "VSC_SORT_MAX_BITS", "VSC_SEED_RESERVE")}, len(got), len(want))
         n_rec = len(got)
     return n_rec
 

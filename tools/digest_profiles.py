@@ -74,6 +74,18 @@ for w in ("c2", "c3"):
         "pairs": bench["config"].get("hits_per_step") and bench["roofline"]["valu"]["pair_compares_per_s"] * launch_ms * 1e-3,
     }
     traffic["%s/seed/1" % w] = hbm
+    # the sort kernels of the same runs (round 2 on: vsc_sort.hip)
+    sort = {}
+    for kname in ("bin_hist_kernel", "bin_partition_kernel", "bin_finalize_kernel"):
+        ck = {}
+        for grp in ("sq", "fetch", "write"):
+            ck.update(counters(os.path.join(src, "pmc_%s_%s" % (grp, w), "**", "*counter_collection.csv"), kname))
+        if ck:
+            sort[kname] = {"counters": ck, "fetch_bytes_x2": 2048.0 * ck.get("FETCH_SIZE", 0.0), "write_bytes": 1024.0 * ck.get("WRITE_SIZE", 0.0),
+                           "rocprof_avg_ms": kernel_avg_ms(stats[0], kname) if stats else None}
+    summary[w]["sort_kernels"] = sort
 json.dump(summary, open(os.path.join(dst, "%s_seed_pmc.json" % tag), "w"), indent=1)
+traffic["_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh, digested into profiles/%s_seed_pmc.json (FETCH_SIZE x 2 + WRITE_SIZE per launch of the search kernel)" % tag
 json.dump(traffic, open(traffic_path, "w"))
 print(json.dumps({w: summary[w]["derived"] for w in ("c2", "c3")}, indent=1))
+print(json.dumps({w: {k: (v["rocprof_avg_ms"], v["fetch_bytes_x2"], v["write_bytes"]) for k, v in summary[w]["sort_kernels"].items()} for w in ("c2", "c3")}, indent=1))

@@ -552,7 +552,8 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
         if (std::getenv("VSC_DEBUG_SORT"))
             std::fprintf(stderr, "[vsc sort] level %u: %zu segments, %llu records, largest %llu, %u bits (of %u left), cap %llu\n", level,
                          n_segs, (unsigned long long)n_all, (unsigned long long)n_max, bits, rem, (unsigned long long)sort_cap);
-        std::vector<uint32_t> tile0(n_segs + 1, 0);
+        std::vector<uint32_t> &tile0 = ctx->host_tile0;
+        tile0.assign(n_segs + 1, 0);
         uint64_t tiles = 0;
         for (size_t i = 0; i < n_segs; ++i) {
             tile0[i] = (uint32_t)tiles;
@@ -564,7 +565,8 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
         VSC_TRY(ctx->sort_segs.ensure(seg_bytes + tile0.size() * sizeof(uint32_t)));
         SortSeg *d_segs = (SortSeg *)ctx->sort_segs.p;
         uint32_t *d_tile0 = (uint32_t *)((char *)ctx->sort_segs.p + seg_bytes);
-        VSC_TRY(hipMemcpyAsync(d_segs, segs.data(), n_segs * sizeof(SortSeg), hipMemcpyHostToDevice, st));
+        ctx->host_segs = segs;  // (the copy the asynchronous upload reads from)
+        VSC_TRY(hipMemcpyAsync(d_segs, ctx->host_segs.data(), n_segs * sizeof(SortSeg), hipMemcpyHostToDevice, st));
         VSC_TRY(hipMemcpyAsync(d_tile0, tile0.data(), tile0.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         const size_t n_bins = n_segs << bits;
         VSC_TRY(ctx->sort_over.ensure(256 + n_bins * sizeof(SortSeg)));
