@@ -30,6 +30,20 @@ namespace vsc {
 
 namespace {
 
+// Which record of its tile a thread takes as its k-th: two consecutive records per thread (one coalesced
+// 16 bytes per lane) and pair of k.  Consecutive hits of a wave of the search kernel sit next to each other in a
+// region and often share their bin (same read and strand, positions in the same slice); with one record per lane
+// (record = k * threads + lane) the lanes of one LDS atomic carried runs of equal bins and the atomics serialised
+// (hist + partition 9.0 -> 10.5 ms when strand-sorted buckets doubled the runs).  This way neighbours meet in
+// different instructions: 9.3 ms.  (Four per lane 9.7, eight 12.5, sixteen 18.7: the loads stop coalescing.
+// Scattering the records at the source instead - slot 37 i mod 128 of a block - brought the sort to 8.6 ms and
+// the search kernel from 27 to 43 ms: its stores have to stay contiguous.)
+constexpr int kLaneRun = 2;
+__device__ __forceinline__ uint32_t tile_record(int k, uint32_t t)
+{
+    return (uint32_t)(k / kLaneRun) * (uint32_t)(kLaneRun * kSortThreads) + t * (uint32_t)kLaneRun + (uint32_t)(k % kLaneRun);
+}
+
 // Exclusive scan, in place, of the n (a power of two, <= 4 * kThreads) counters s[0..n); returns the total.
 // Ends with a barrier; s_wave needs kThreads / 64 words.
 template <int kThreads>
@@ -120,8 +134,8 @@ __global__ __launch_bounds__(kSortThreads) void bin_hist_kernel(const SortArgs a
         const uint32_t n = min(sg.n_in - first, (uint32_t)kSortTile);
 #pragma unroll 4
         for (int k = 0; k < kSortItems; ++k) {
-            const uint32_t i = k * kSortThreads + t;
-            if (i >= n) break;
+            const uint32_t i = tile_record(k, t);
+            if (i >= n) continue;
             if (kPairs) {
                 atomicAdd(&s_hist[(uint32_t)(a.pair_keys[sg.in_off + first + i] >> a.bin_shift)], 1u);
             } else {
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
     uint32_t bin[kSortItems];  // bin | rank inside (tile, bin) << 16
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
-        const uint32_t i = k * kSortThreads + t;
+        const uint32_t i = tile_record(k, t);
         const bool in_tile = i < n;
         const uint64_t at = sg.in_off + first + (in_tile ? i : 0u);
         if (kPairs) {
