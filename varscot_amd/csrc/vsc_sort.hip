@@ -194,7 +194,7 @@ template <bool kPairs>
 __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortArgs a)
 {
     __shared__ uint64_t s_rec[kSortTile];
-    __shared__ uint32_t s_cnt[(1 << kSortMaxBinBits) + 1];  // records per bin, then their first slot in s_rec (+ a spare)
+    __shared__ uint32_t s_cnt[(1 << kSortMaxBinBits) + kWave];  // records per bin, then their first slot in s_rec (+ spares)
     __shared__ uint32_t s_gbase[1 << kSortMaxBinBits];  // where this tile's records of a bin go in the bin
     __shared__ uint32_t s_wave[kSortThreads / kWave];
     const uint32_t t = threadIdx.x;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
     const SortSeg sg = a.segs[seg];
     const uint32_t first = (tile - a.seg_tile0[seg]) * (uint32_t)kSortTile;
     const uint32_t n = min(sg.n_in - first, (uint32_t)kSortTile);
-    for (uint32_t b = t; b <= nbins; b += kSortThreads) s_cnt[b] = 0;
+    for (uint32_t b = t; b < nbins + kWave; b += kSortThreads) s_cnt[b] = 0;
     block_sync();
     // records of the tile in registers; sentinels (and the slots past the tile) take no part.  Branch-free on
     // purpose (clamped loads + selects): with conditional stores into r[] / bin[] the compiler keeps the arrays
@@ -233,11 +233,14 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
             bin[k] = (uint32_t)(r[k] >> a.bin_shift) & (nbins - 1u);
         }
     }
-    // rank inside (tile, bin) = what the LDS atomic returns; sentinels add nothing to a spare counter
+    // rank inside (tile, bin) = what the LDS atomic returns; sentinels add nothing to a spare counter - one per
+    // lane: sentinels come in runs (the unused tail of a wave's block), and 64 lanes on ONE spare word would be
+    // the slowest atomic of the kernel
+    const uint32_t spare = nbins + (t % kWave);
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         const bool real = !(r[k] >> 63);
-        const uint32_t rank = atomicAdd(&s_cnt[real ? bin[k] : nbins], real ? 1u : 0u);
+        const uint32_t rank = atomicAdd(&s_cnt[real ? bin[k] : spare], real ? 1u : 0u);
         bin[k] |= rank << 16;  // a tile has <= 16 384 records: the rank fits 16 bits
     }
     block_sync();
@@ -299,7 +302,7 @@ constexpr int kFinalizeRange = 64;  // ... for a binary search in LDS (more: in 
 __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs a)
 {
     __shared__ uint64_t s_rec[kSortCap];
-    __shared__ uint32_t s_sub[(1 << kSortSubBits) / 2 + 1];  // packed pairs of 16-bit counters, then first slots
+    __shared__ uint32_t s_sub[(1 << kSortSubBits) / 2 + 1 + kWave];  // packed pairs of 16-bit counters, then first slots (+ spares)
     __shared__ uint32_t s_wave[kFinThreads / kWave];
     __shared__ uint32_t s_range[2 + kFinalizeRange];  // first contig of the bin's position range, contigs in it, their starts
     const uint32_t t = threadIdx.x;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
     }
     const uint32_t nsub = 1u << a.sub_bits;
     const uint32_t nwords = nsub > 1u ? nsub / 2u : 1u;
-    for (uint32_t i = t; i <= nwords; i += kFinThreads) s_sub[i] = 0;
+    for (uint32_t i = t; i <= nwords + kWave; i += kFinThreads) s_sub[i] = 0;
     block_sync();
     const uint64_t *const in = a.src + src;
     uint64_t r[kFinItems];
@@ -349,8 +352,11 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
         const bool real = !(r[k] >> 63);
         const uint32_t sb = (uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u);
         const uint32_t sh = (sb & 1u) * 16u;
-        // sentinels (and the slots past the bin) add nothing to the spare word
-        rk[k] = (atomicAdd(&s_sub[real ? sb >> 1 : nwords], real ? 1u << sh : 0u) >> sh) & 0xFFFFu;
+        // sentinels (and the slots past the bin) add nothing to a spare word of their own lane (one shared word
+        // would serialise the 64 lanes of every instruction that lies wholly past the bin - a third of them).
+        // (Skipping those instructions with a workgroup-uniform test made the compiler interleave loads and
+        // atomics item by item: 13.9 -> 18.0 ms.)
+        rk[k] = (atomicAdd(&s_sub[real ? sb >> 1 : nwords + 1u + (t % kWave)], real ? 1u << sh : 0u) >> sh) & 0xFFFFu;
     }
     block_sync();
     // exclusive scan of the packed counters: a thread owns `per` consecutive words
