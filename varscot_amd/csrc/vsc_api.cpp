@@ -456,7 +456,6 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
     if (e == hipSuccess) step(launch_seed_chunk_flags(g->d_ix_chunk_tab, g->ix_chunks, g->d_ix_edge, st));
     step(hipEventRecord(ctx->ev[6], st));
     step(hipStreamSynchronize(st));
-    if (std::getenv("VSC_INDEX_KEEP_TEMP")) full.p = nullptr;  // experiment: leak the 16-byte record buffer instead of freeing it
     release();
     if (e != hipSuccess) {
         free_index(g);
@@ -903,11 +902,8 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         }
         const_cast<vsc_genome *>(genome)->seen_rate[params->max_mismatches] = fullest;
         if (n > 0) {
-            // (VSC_SORT_PAD_KB: experiment - shifts the second record buffer against the first)
-            size_t pad = 0;
-            if (const char *o = std::getenv("VSC_SORT_PAD_KB")) pad = (size_t)std::max(0, std::atoi(o)) * 1024;
-            VSC_HIP_H(ctx->keys_b.ensure(cap * sizeof(uint64_t) + pad));
-            other = (uint64_t *)((char *)ctx->keys_b.p + pad);
+            VSC_HIP_H(ctx->keys_b.ensure(cap * sizeof(uint64_t)));
+            other = (uint64_t *)ctx->keys_b.p;
         }
     }
     t.hits += n;
