@@ -296,6 +296,7 @@ __device__ __forceinline__ uint32_t sub_slot(const uint32_t *s_sub, uint32_t sb)
     return (s_sub[sb >> 1] >> ((sb & 1u) * 16u)) & 0xFFFFu;
 }
 
+constexpr int kFinalizeAhead = 4;  // records of a sub-bin the ranking reads at once
 constexpr int kFinalizeNear = 4;    // contigs a bin's position range may touch for the straight-line contig lookup
 constexpr int kFinalizeRange = 64;  // ... for a binary search in LDS (more: in global memory - variant genomes)
 
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
     __shared__ uint32_t s_sub[(1 << kSortSubBits) / 2 + 1 + kWave];  // packed pairs of 16-bit counters, then first slots (+ spares)
     __shared__ uint32_t s_wave[kFinThreads / kWave];
     __shared__ uint32_t s_range[2 + kFinalizeRange];  // first contig of the bin's position range, contigs in it, their starts
+    __shared__ uint32_t s_edge[4];                    // the bin's position range [0], [1]; contigs starting at or below either end [2], [3]
     const uint32_t t = threadIdx.x;
     const uint32_t seg = blockIdx.x >> a.bin_bits, bin = blockIdx.x & ((1u << a.bin_bits) - 1u);
     const SortSeg sg = a.segs[seg];
@@ -337,6 +339,11 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
     const uint32_t nsub = 1u << a.sub_bits;
     const uint32_t nwords = nsub > 1u ? nsub / 2u : 1u;
     for (uint32_t i = t; i <= nwords + kWave; i += kFinThreads) s_sub[i] = 0;
+    if (t < 4) s_edge[t] = 0;
+    // a genome's contig table fits one entry per thread: loaded now, used after the counting pass (variant genomes
+    // with millions of contigs take the binary searches further down)
+    const bool few_contigs = a.n_contigs <= (uint32_t)kFinThreads;
+    const uint32_t my_contig = (few_contigs && t < a.n_contigs) ? a.contig_off[t] : 0xFFFFFFFFu;
     block_sync();
     const uint64_t *const in = a.src + src;
     uint64_t r[kFinItems];
@@ -346,6 +353,16 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
         const uint32_t i = k * kFinThreads + t;
         const uint64_t v = in[i < n_src ? i : 0u];
         r[k] = i < n_src ? v : kRecSentinel;
+    }
+    if (t == 0) {
+        // the bin's position range: its keys agree in all bits above the sub-bin and rank fields (a sentinel - level 1
+        // without a partition pass - has all bits set: the range then is everything, and so it is whenever those
+        // fields cover the whole position)
+        const uint32_t free_bits = a.sub_bits + a.low_bits;
+        const uint32_t any = (uint32_t)(r[0] >> kRecPosShift) >> a.pos_pad;
+        const uint32_t p_lo = free_bits >= 32u ? 0u : (any >> free_bits) << free_bits;
+        s_edge[0] = p_lo;
+        s_edge[1] = free_bits >= 32u ? 0xFFFFFFFFu : p_lo | ((1u << free_bits) - 1u);
     }
 #pragma unroll
     for (int k = 0; k < kFinItems; ++k) {
@@ -359,6 +376,16 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
         rk[k] = (atomicAdd(&s_sub[real ? sb >> 1 : nwords + 1u + (t % kWave)], real ? 1u << sh : 0u) >> sh) & 0xFFFFu;
     }
     block_sync();
+    // contigs the range touches, all threads at once: one comparison per contig and thread, counted per wave
+    // (thread 0 walking two binary searches through global memory here cost as much as loading the bin)
+    if (few_contigs) {
+        const uint32_t p_lo = s_edge[0], p_hi = s_edge[1];
+        const uint64_t le_lo = __ballot(my_contig <= p_lo), le_hi = __ballot(my_contig <= p_hi);
+        if (t % kWave == 0) {
+            if (le_lo) atomicAdd(&s_edge[2], (uint32_t)__popcll(le_lo));
+            if (le_hi) atomicAdd(&s_edge[3], (uint32_t)__popcll(le_hi));
+        }
+    }
     // exclusive scan of the packed counters: a thread owns `per` consecutive words
     uint32_t n;
     {
@@ -398,35 +425,37 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
             run += w[i] >> 16;
             if (mine && (uint32_t)i < per) s_sub[t * per + i] = lo | (hi << 16);
         }
-        if (t == 0) {
-            // the end of the last sub-bin (slot nsub: the low half of the spare word, or the high half of the only word)
-            if (nsub > 1u) s_sub[nwords] = n;
-            // contigs the bin's position range touches: keys agree in all bits above the sub-bin and rank fields
-            const uint32_t free_bits = a.sub_bits + a.low_bits;  // key bits the bin leaves open, all of them position bits or more
-            const uint32_t any = (uint32_t)(in[0] >> kRecPosShift) >> a.pos_pad;  // sentinels (level 1 without partition) have all bits set: range = everything
-            const uint32_t p_lo = free_bits >= 32u ? 0u : (any >> free_bits) << free_bits;
-            const uint32_t p_hi = free_bits >= 32u ? 0xFFFFFFFFu : p_lo | ((1u << free_bits) - 1u);
-            uint32_t c_lo, c_hi;
-            {
-                uint32_t lo = 0, hi = a.n_contigs;
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (a.contig_off[mid] <= p_lo) lo = mid; else hi = mid;
-                }
-                c_lo = lo;
-                hi = a.n_contigs;
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (a.contig_off[mid] <= p_hi) lo = mid; else hi = mid;
-                }
-                c_hi = lo;
+        // the end of the last sub-bin (slot nsub: the low half of the spare word, or the high half of the only word)
+        if (t == 0 && nsub > 1u) s_sub[nwords] = n;
+        if (few_contigs) {
+            // every contig start at or below p_lo counts: the last of them is the range's first contig (start 0 exists)
+            const uint32_t c_lo = max(s_edge[2], 1u) - 1u, c_hi = max(s_edge[3], 1u) - 1u;
+            if (t == 0) {
+                s_range[0] = c_lo;
+                s_range[1] = c_hi - c_lo + 1u;
+            }
+            if (t >= c_lo && t < c_lo + (uint32_t)kFinalizeRange && t < a.n_contigs) s_range[2 + t - c_lo] = my_contig;
+            // the slots past the last contig: a position no window has
+            if (t < (uint32_t)kFinalizeRange && a.n_contigs - c_lo + t < (uint32_t)kFinalizeRange) s_range[2 + a.n_contigs - c_lo + t] = 0xFFFFFFFFu;
+        } else if (t == 0) {
+            const uint32_t p_lo = s_edge[0], p_hi = s_edge[1];
+            uint32_t lo = 0, hi = a.n_contigs;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (a.contig_off[mid] <= p_lo) lo = mid; else hi = mid;
+            }
+            const uint32_t c_lo = lo;
+            hi = a.n_contigs;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (a.contig_off[mid] <= p_hi) lo = mid; else hi = mid;
             }
             s_range[0] = c_lo;
-            s_range[1] = c_hi - c_lo + 1u;
+            s_range[1] = lo - c_lo + 1u;
         }
         block_sync();
-        // their starts (absent: a position no window has)
-        if (t < (uint32_t)kFinalizeRange) s_range[2 + t] = t < s_range[1] ? a.contig_off[s_range[0] + t] : 0xFFFFFFFFu;
+        // many contigs: the starts of the range's first contigs (absent: a position no window has)
+        if (!few_contigs && t < (uint32_t)kFinalizeRange) s_range[2 + t] = t < s_range[1] ? a.contig_off[s_range[0] + t] : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int k = 0; k < kFinItems; ++k)
@@ -434,55 +463,83 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
     block_sync();
     const uint32_t c_lo = s_range[0], c_n = s_range[1];
     const uint32_t st0 = s_range[2], st1 = s_range[3], st2 = s_range[4], st3 = s_range[5];
-    for (uint32_t base = 0; base < n; base += kFinThreads) {
-        const uint32_t i = base + t;
-        const bool live = i < n;
-        const uint64_t x = live ? s_rec[i] : 0ull;
-        const uint32_t sb = (uint32_t)(x >> a.sub_shift) & (nsub - 1u);
-        const uint32_t s = sub_slot(s_sub, sb), e = live ? sub_slot(s_sub, sb + 1u) : s;
-        // rank among the records of the sub-bin (keys are unique).  Wave-uniform trip count, predicated body:
-        // per-lane loops cost more in execution-mask bookkeeping than they save.
-        uint32_t smaller = 0;
+    // Two records per thread and round, every LDS read unconditional (clamped) so that independent reads leave
+    // together: the phase is bound by LDS round trips (record -> sub-bin bounds -> the sub-bin's records), not by
+    // bandwidth or issue.
+    for (uint32_t base = 0; base < n; base += 2 * kFinThreads) {
+        uint32_t s[2], e[2], smaller[2] = {0u, 0u};
+        uint64_t x[2];
+        bool live[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t idx = base + u * kFinThreads + t;
+            live[u] = idx < n;
+            const uint64_t v = s_rec[live[u] ? idx : 0u];
+            x[u] = live[u] ? v : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t sb = (uint32_t)(x[u] >> a.sub_shift) & (nsub - 1u);
+            const uint32_t first = sub_slot(s_sub, sb), next = sub_slot(s_sub, sb + 1u);
+            s[u] = first;
+            e[u] = live[u] ? next : first;
+        }
+        // rank among the records of the sub-bin (keys are unique): its first kFinalizeAhead records in one go, the
+        // few longer sub-bins in a loop with a wave-uniform trip count (per-lane loops cost more in execution-mask
+        // bookkeeping than they save)
         if (a.low_bits) {
-            for (uint32_t d = 0;; ++d) {
-                const uint32_t j = s + d;
-                const bool act = j < e;
-                if (__ballot(act) == 0) break;
-                if (act) smaller += s_rec[j] < x;
+            uint64_t y[2][kFinalizeAhead];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < kFinalizeAhead; ++j) y[u][j] = s_rec[min(s[u] + (uint32_t)j, (uint32_t)kSortCap - 1u)];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < kFinalizeAhead; ++j) smaller[u] += (uint32_t)(s[u] + (uint32_t)j < e[u] && y[u][j] < x[u]);
+            for (uint32_t d = kFinalizeAhead;; ++d) {
+                const bool act0 = s[0] + d < e[0], act1 = s[1] + d < e[1];
+                if (__ballot(act0 || act1) == 0) break;
+                const uint64_t y0 = s_rec[act0 ? s[0] + d : 0u], y1 = s_rec[act1 ? s[1] + d : 0u];
+                smaller[0] += (uint32_t)(act0 && y0 < x[0]);
+                smaller[1] += (uint32_t)(act1 && y1 < x[1]);
             }
         }
-        if (!live) continue;
-        const uint32_t pos = (uint32_t)(x >> kRecPosShift) >> a.pos_pad;
-        uint32_t c, start;
-        if (c_n <= (uint32_t)kFinalizeNear) {
-            // the usual case: the bin's positions lie in at most four contigs - three comparisons
-            const uint32_t k = (uint32_t)(pos >= st1) + (uint32_t)(pos >= st2) + (uint32_t)(pos >= st3);
-            c = c_lo + k;
-            start = k == 0 ? st0 : (k == 1 ? st1 : (k == 2 ? st2 : st3));
-        } else if (c_n <= (uint32_t)kFinalizeRange) {
-            uint32_t lo = 0, hi = c_n;  // last contig of the staged range whose start is <= pos
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_range[2 + mid] <= pos) lo = mid; else hi = mid;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!live[u]) continue;
+            const uint32_t pos = (uint32_t)(x[u] >> kRecPosShift) >> a.pos_pad;
+            uint32_t c, start;
+            if (c_n <= (uint32_t)kFinalizeNear) {
+                // the usual case: the bin's positions lie in at most four contigs - three comparisons
+                const uint32_t k = (uint32_t)(pos >= st1) + (uint32_t)(pos >= st2) + (uint32_t)(pos >= st3);
+                c = c_lo + k;
+                start = k == 0 ? st0 : (k == 1 ? st1 : (k == 2 ? st2 : st3));
+            } else if (c_n <= (uint32_t)kFinalizeRange) {
+                uint32_t lo = 0, hi = c_n;  // last contig of the staged range whose start is <= pos
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_range[2 + mid] <= pos) lo = mid; else hi = mid;
+                }
+                c = c_lo + lo;
+                start = s_range[2 + lo];
+            } else {
+                uint32_t lo = c_lo, hi = c_lo + c_n;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (a.contig_off[mid] <= pos) lo = mid; else hi = mid;
+                }
+                c = lo;
+                start = a.contig_off[c];
             }
-            c = c_lo + lo;
-            start = s_range[2 + lo];
-        } else {
-            uint32_t lo = c_lo, hi = c_lo + c_n;
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (a.contig_off[mid] <= pos) lo = mid; else hi = mid;
-            }
-            c = lo;
-            start = a.contig_off[c];
+            const uint32_t mask = (uint32_t)x[u] & kMask23;
+            uint4 h;
+            h.x = sg.guide_base + ((uint32_t)(x[u] >> kRecReadShift) & (uint32_t)(kRegionReads - 1));  // vsc_hit.guide
+            h.y = c;                                                                              // .contig
+            h.z = pos - start;                                                                    // .pos
+            h.w = ((uint32_t)(x[u] >> kRecStrandShift) & 1u) << 31 | (uint32_t)__popc(mask) << 23 | mask;  // .info
+            ((uint4 *)a.out)[dst + s[u] + smaller[u]] = h;
         }
-        const uint32_t mask = (uint32_t)x & kMask23;
-        uint4 h;
-        h.x = sg.guide_base + ((uint32_t)(x >> kRecReadShift) & (uint32_t)(kRegionReads - 1));  // vsc_hit.guide
-        h.y = c;                                                                           // .contig
-        h.z = pos - start;                                                                 // .pos
-        h.w = ((uint32_t)(x >> kRecStrandShift) & 1u) << 31 | (uint32_t)__popc(mask) << 23 | mask;  // .info
-        ((uint4 *)a.out)[dst + s + smaller] = h;
     }
 }
 
