@@ -740,3 +740,49 @@ def test_reference_guides_on_a_repeat_rich_genome(ctx, oracle, golden_dir, n_bas
     print("repeat-rich genome, %d bases, m=%d: %d hits, per read min/median/max %d/%d/%d; (algorithm, search launches, "
           "sort levels, hits) = %s" % (n_bases, max_mm, len(want), per_read.min(), int(np.median(per_read)), per_read.max(), stats))
     assert stats[0][1] >= 1 and stats[1][1] == 1  # the second seed search is sized from the first one's result
+
+
+def test_seed_index_file_round_trip(tmp_path):
+    """vsc_genome_index_save / _load: a second genome object that loads the file returns the records of the one
+    that built the index, without building (timing: no index build); files of another genome, of another PAM set's
+    search and truncated files are refused or rebuilt around."""
+    rng = np.random.default_rng(77)
+    guides = random_guides(rng, 12)
+    contigs = make_genome(77, [60000, 25000], guides, 6, n_plant=300, n_runs=2)
+    packed = va.PackedGenome.from_sequences(contigs)
+    ctx = va.Context(0)
+    g1 = ctx.load_genome(packed)
+    with pytest.raises(va.VarscotError):
+        g1.save_index(str(tmp_path / "none.vsi"))  # nothing to save yet
+    g1.build_index()
+    h = g1.search(guides, 6, algorithm="seed")
+    want = h.to_numpy().copy()
+    h.close()
+    path = str(tmp_path / "g.vsi")
+    g1.save_index(path)
+    g2 = ctx.load_genome(packed)
+    g2.load_index(path)
+    h = g2.search(guides, 6, algorithm="auto")  # auto takes the seed path when an index is resident
+    got = h.to_numpy().copy()
+    h.close()
+    assert got.tobytes() == want.tobytes() and len(want) > 200
+    assert g2.device_bytes == g1.device_bytes
+    # an extra PAM needs another index: the loaded one is replaced by a build, results as from a fresh genome
+    h = g2.search(guides, 6, extra_pam="AG", algorithm="seed")
+    h1 = g1.search(guides, 6, extra_pam="AG", algorithm="scan")
+    assert h.to_numpy().tobytes() == h1.to_numpy().tobytes()
+    h.close()
+    h1.close()
+    # another genome
+    g3 = ctx.load_genome(va.PackedGenome.from_sequences([c[::-1] for c in contigs]))
+    with pytest.raises(va.VarscotError, match="another genome"):
+        g3.load_index(path)
+    open(str(tmp_path / "cut.vsi"), "wb").write(open(path, "rb").read()[:5000])
+    with pytest.raises(va.VarscotError, match="truncated"):
+        g2.load_index(str(tmp_path / "cut.vsi"))
+    h = g2.search(guides, 6, algorithm="seed")  # left without an index: builds again
+    assert h.to_numpy().tobytes() == want.tobytes()
+    h.close()
+    for g in (g1, g2, g3):
+        g.close()
+    ctx.close()

@@ -178,3 +178,44 @@ def test_driver_end_to_end(scenario, tmp_path):
     assert r.returncode == 2 and "between 0 and 8" in r.stdout
     r = subprocess.run(["bash", driver, "-o", "o.txt", "-T", str(tmp_path / "t3")], capture_output=True, text=True)
     assert r.returncode == 2 and "No on-target file path" in r.stdout
+
+
+def test_driver_several_samples_in_one_run(scenario, tmp_path):
+    """-s 0,1 / -s all: what the reference's parallel.py does with one driver process per VCF sample column
+    (parallel.py:49-63) in one run that shares the reference search.  Every sample's result and feature matrix must be
+    byte-identical to a single-sample run of that column."""
+    d, records, bed, tus, targets = scenario
+    driver = os.path.join(ROOT, "varscot_amd", "driver", "VARSCOT")
+    # a second sample column with other genotypes (some sites absent, some homozygous)
+    other = ["0|0", "1|1", "0|1", "1|0", "./.", "1/1"]
+    lines, k = [], 0
+    for l in (d / "in.vcf").read_text().splitlines():
+        if l.startswith("##"):
+            lines.append(l)
+        elif l.startswith("#CHROM"):
+            lines.append(l + "\tS1")
+        else:
+            lines.append(l + "\t" + other[k % len(other)])
+            k += 1
+    vcf2 = tmp_path / "two.vcf"
+    vcf2.write_text("\n".join(lines) + "\n")
+    base = ["bash", driver, "-b", str(d / "targets.bed"), "-g", str(d / "genome.fa"), "-i", str(tmp_path / "idx"), "-m", "5",
+            "-t", "2", "-a", str(d / "activity.txt"), "-f", str(vcf2), "-e", "prob"]
+    single = {}
+    for s in (0, 1):
+        out = tmp_path / ("one_%d.txt" % s)
+        r = subprocess.run(base + ["-o", str(out), "-T", str(tmp_path / "tmp1"), "-s", str(s)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        single[s] = (out.read_bytes(), (tmp_path / ("one_%d_feature_matrix.txt" % s)).read_bytes())
+    assert single[0][0] != single[1][0]  # the columns differ, so do the results
+    for spec in ("0,1", "all"):
+        out = tmp_path / ("multi_%s.txt" % spec.replace(",", ""))
+        r = subprocess.run(base + ["-o", str(out), "-T", str(tmp_path / "tmp2"), "-s", spec], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.count("Searching for off-targets") == 1
+        stem = str(out)[:-4]
+        for s in (0, 1):
+            assert open("%s_sample%d.txt" % (stem, s), "rb").read() == single[s][0]
+            assert open("%s_sample%d_feature_matrix.txt" % (stem, s), "rb").read() == single[s][1]
+    r = subprocess.run(base + ["-o", str(tmp_path / "bad.txt"), "-T", str(tmp_path / "tmp3"), "-s", "0,x"], capture_output=True, text=True)
+    assert r.returncode == 2 and "Sample must be" in r.stdout

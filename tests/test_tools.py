@@ -95,6 +95,35 @@ def test_bidir_mapping_over_several_device_contexts(workdir, oracle, devices):
 
 
 @pytest.mark.gpu
+def test_bidir_mapping_loads_a_saved_seed_index(workdir, oracle):
+    """bidir_index -S writes <prefix>.vsi (the seed index built on the device), bidir_mapping loads it instead of
+    building: same SAM as the oracle's.  A file of another genome is refused with a message and the search builds
+    its own index - the SAM stays right."""
+    d, names, contigs, gnames, guides = workdir
+    r = run("bidir_index", "-G", str(d / "genome.fa"), "-I", str(d / "idx"), "-S")
+    assert r.returncode == 0, r.stderr
+    assert (d / "idx.vsi").stat().st_size > 80
+    args = ["-G", str(d / "genome.fa"), "-I", str(d / "idx"), "-R", str(d / "reads.fa"), "-M", "6", "-O", str(d / "out.sam")]
+    r = run("bidir_mapping", *args)
+    assert r.returncode == 0 and r.stderr == "", r.stderr
+    want = oracle.search_sam(contigs, names, guides, gnames, 6, None, 0)
+    assert open(d / "out.sam").read() == want
+    # the index of another genome under this prefix
+    other = [c[::-1] for c in contigs]
+    write_fasta(d / "other.fa", names, other)
+    assert run("bidir_index", "-G", str(d / "other.fa"), "-I", str(d / "other"), "-S").returncode == 0
+    os.replace(d / "other.vsi", d / "idx.vsi")
+    r = run("bidir_mapping", *args)
+    assert r.returncode == 0 and "belongs to another genome" in r.stderr
+    assert open(d / "out.sam").read() == want
+    # truncated file
+    data = (d / "idx.vsi").read_bytes()
+    (d / "idx.vsi").write_bytes(data[:40])
+    r = run("bidir_mapping", *args)
+    assert r.returncode == 0 and "not a seed index file" in r.stderr and open(d / "out.sam").read() == want
+
+
+@pytest.mark.gpu
 def test_bidir_mapping_unwritable_output(workdir):
     d, *_ = workdir
     run("bidir_index", "-G", str(d / "genome.fa"), "-I", str(d / "idx"))

@@ -77,6 +77,8 @@ SYMBOLS = [
                                   C.POINTER(_vp)]),
     ("vsc_genome_free", C.c_int, [_vp]),
     ("vsc_genome_build_index", C.c_int, [_vp, _vp, C.POINTER(SearchParams)]),
+    ("vsc_genome_index_save", C.c_int, [_vp, _vp, C.c_char_p]),
+    ("vsc_genome_index_load", C.c_int, [_vp, _vp, C.c_char_p]),
     ("vsc_genome_device_bytes", C.c_uint64, [_vp]),
     ("vsc_search", C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(SearchParams), C.POINTER(_vp)]),
     ("vsc_search_stream", C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(SearchParams), C.c_uint32, BATCH_FN, _vp]),

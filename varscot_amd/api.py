@@ -2,6 +2,7 @@
 search and per-hit scoring.  Thin plumbing only - every computation happens in libvarscot_hip.so.
 """
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -207,6 +208,14 @@ class Genome:
         """Build the seed index now (vsc_genome_build_index); searches build it on demand otherwise."""
         p = self._params(0, extra_pam, ALGO_SEED)
         check(lib().vsc_genome_build_index(self.ctx._h, self._h, C.byref(p)), self.ctx._h)
+
+    def save_index(self, path):
+        """Write the resident seed index to a file (vsc_genome_index_save)."""
+        check(lib().vsc_genome_index_save(self.ctx._h, self._h, os.fsencode(path)), self.ctx._h)
+
+    def load_index(self, path):
+        """Replace the seed index by a file's (vsc_genome_index_load); refused if it belongs to another genome."""
+        check(lib().vsc_genome_index_load(self.ctx._h, self._h, os.fsencode(path)), self.ctx._h)
 
     def search(self, guides, max_mismatches, extra_pam=None, algorithm="auto"):
         """guides: list of 23-nt strings or a uint64 array from pack_guides().

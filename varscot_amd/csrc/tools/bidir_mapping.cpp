@@ -89,6 +89,11 @@ int main(int argc, char **argv)
             st = vsc_genome_load(ctx, ix.hi.data(), ix.lo.data(), ix.nm.data(), 0, ix.hi.size(), ix.hi.size(), ix.contigs.data(),
                                  (uint32_t)ix.contigs.size(), &genome);
             if (st != VSC_OK) throw std::runtime_error(vsc_last_error(ctx));
+            // a seed index written by `bidir_index -S` is taken if it fits this genome and the default PAM set;
+            // otherwise (absent, stale, other PAM) the search builds the index itself
+            if (pam.size() != 2 && std::ifstream(seed_index_path(index_prefix)).good() &&
+                vsc_genome_index_load(ctx, genome, seed_index_path(index_prefix).c_str()) != VSC_OK)
+                std::fprintf(stderr, "%s: %s - building the seed index instead\n", argv[0], vsc_last_error(ctx));
         } else {
             st = vsc_multi_create(devices.data(), (int)devices.size(), &multi);
             if (st != VSC_OK) throw std::runtime_error(st == VSC_ERR_NODEVICE ? "no HIP device available (there is no CPU fallback)" : "could not create the device contexts");

@@ -80,6 +80,7 @@ struct PackedIndex {
 };
 
 inline std::string index_path(const std::string &prefix) { return prefix + ".vsc"; }
+inline std::string seed_index_path(const std::string &prefix) { return prefix + ".vsi"; }  // optional: bidir_index -S
 
 inline PackedIndex pack_records(const std::vector<FastaRecord> &recs)
 {

@@ -472,7 +472,62 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         g->index_extra_pam[0] = params->extra_pam[0];
         g->index_extra_pam[1] = params->extra_pam[1];
     }
+    g->ix_vert_bytes = vb;
+    g->ix_edge_words = edge_words;
     g->index_bytes = 3 * S * sizeof(uint2) + edge_words * sizeof(uint32_t) + cb + vb;
+    return hipSuccess;
+}
+
+// ---- seed index on disk (vsc_genome_index_save / _load) ---------------------------------------------
+// One header, then the four device arrays as they lie in HBM.  The header pins what the arrays depend on: the
+// library's layout constants, the PAM set and a fingerprint of the genome (size, contig table, the first plane words).
+struct IndexFileHeader {
+    char magic[8];  // "VSCSEED\0"
+    uint32_t abi, seg_bases, sliced_chunk, sliced_sites;
+    uint64_t sites;  // S
+    uint64_t own_words, vert_bytes, edge_words, fingerprint;
+    uint32_t chunks, n_contigs;
+    uint8_t has_extra_pam;
+    char extra_pam[2];
+    uint8_t pad[5];
+};
+static_assert(sizeof(IndexFileHeader) == 80, "index file header layout");
+constexpr char kIndexMagic[8] = {'V', 'S', 'C', 'S', 'E', 'E', 'D', 0};
+constexpr size_t kIndexIoChunk = 64u << 20;
+
+hipError_t genome_fingerprint(const vsc_genome *g, uint64_t *out)
+{
+    const uint64_t probe = std::min<uint64_t>(g->own_words, 1u << 16);
+    std::vector<uint32_t> buf((size_t)g->n_contigs + 2 * probe);
+    if (g->n_contigs) VSC_TRY(hipMemcpy(buf.data(), g->d_contig_off, (size_t)g->n_contigs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (probe) {
+        VSC_TRY(hipMemcpy(buf.data() + g->n_contigs, g->d_hi, probe * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        VSC_TRY(hipMemcpy(buf.data() + g->n_contigs + probe, g->d_lo, probe * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    uint64_t h = 0xcbf29ce484222325ull ^ g->own_words;  // FNV-1a over the words
+    for (uint32_t w : buf) h = (h ^ w) * 0x100000001b3ull;
+    *out = h;
+    return hipSuccess;
+}
+
+struct FileCloser {
+    std::FILE *f;
+    ~FileCloser() { if (f) std::fclose(f); }
+};
+
+// device array <-> file, through one host buffer
+hipError_t index_io(std::FILE *f, void *dev, uint64_t bytes, bool to_file, std::vector<char> &host, bool *io_ok)
+{
+    for (uint64_t off = 0; off < bytes; off += kIndexIoChunk) {
+        const size_t n = (size_t)std::min<uint64_t>(kIndexIoChunk, bytes - off);
+        if (to_file) {
+            VSC_TRY(hipMemcpy(host.data(), (const char *)dev + off, n, hipMemcpyDeviceToHost));
+            if (std::fwrite(host.data(), 1, n, f) != n) { *io_ok = false; return hipSuccess; }
+        } else {
+            if (std::fread(host.data(), 1, n, f) != n) { *io_ok = false; return hipSuccess; }
+            VSC_TRY(hipMemcpy((char *)dev + off, host.data(), n, hipMemcpyHostToDevice));
+        }
+    }
     return hipSuccess;
 }
 
@@ -490,6 +545,100 @@ int vsc_genome_build_index(vsc_ctx *ctx, vsc_genome *genome, const vsc_search_pa
         if (!why.empty()) return fail(ctx, VSC_ERR_RANGE, ("vsc_genome_build_index: " + why).c_str());
         return fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, "vsc_genome_build_index", e);
     }
+    ctx->timing.index_ms = genome->index_ms;
+    return VSC_OK;
+}
+
+int vsc_genome_index_save(vsc_ctx *ctx, const vsc_genome *genome, const char *path)
+{
+    if (!ctx || !genome || genome->ctx != ctx || !path) return VSC_ERR_INVALID;
+    ctx->err.clear();
+    if (!genome->has_index) return fail(ctx, VSC_ERR_INVALID, "vsc_genome_index_save: the genome has no seed index (vsc_genome_build_index)");
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    IndexFileHeader h{};
+    std::memcpy(h.magic, kIndexMagic, sizeof h.magic);
+    h.abi = VSC_ABI_VERSION;
+    h.seg_bases = kSegBases;
+    h.sliced_chunk = kSlicedChunk;
+    h.sliced_sites = kSlicedSites;
+    h.sites = genome->index_sites;
+    h.own_words = genome->own_words;
+    h.vert_bytes = genome->ix_vert_bytes;
+    h.edge_words = genome->ix_edge_words;
+    h.chunks = genome->ix_chunks;
+    h.n_contigs = genome->n_contigs;
+    h.has_extra_pam = genome->index_has_extra_pam;
+    h.extra_pam[0] = genome->index_extra_pam[0];
+    h.extra_pam[1] = genome->index_extra_pam[1];
+    VSC_HIP(ctx, genome_fingerprint(genome, &h.fingerprint));
+    FileCloser fc{std::fopen(path, "wb")};
+    if (!fc.f) return fail(ctx, VSC_ERR_INVALID, (std::string("vsc_genome_index_save: cannot write ") + path).c_str());
+    bool ok = std::fwrite(&h, sizeof h, 1, fc.f) == 1;
+    std::vector<char> host(kIndexIoChunk);
+    const uint64_t S = genome->index_sites;
+    if (ok) VSC_HIP(ctx, index_io(fc.f, genome->d_ix_sites, 3 * S * sizeof(uint2), true, host, &ok));
+    if (ok) VSC_HIP(ctx, index_io(fc.f, genome->d_ix_edge, h.edge_words * sizeof(uint32_t), true, host, &ok));
+    if (ok) VSC_HIP(ctx, index_io(fc.f, genome->d_ix_chunk_tab, (uint64_t)h.chunks * sizeof(uint4), true, host, &ok));
+    if (ok) VSC_HIP(ctx, index_io(fc.f, genome->d_ix_vert, h.vert_bytes, true, host, &ok));
+    if (ok) ok = std::fflush(fc.f) == 0;
+    if (!ok) return fail(ctx, VSC_ERR_DEVICE, (std::string("vsc_genome_index_save: write to ") + path + " failed").c_str());
+    return VSC_OK;
+}
+
+int vsc_genome_index_load(vsc_ctx *ctx, vsc_genome *genome, const char *path)
+{
+    if (!ctx || !genome || genome->ctx != ctx || !path) return VSC_ERR_INVALID;
+    ctx->err.clear();
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    FileCloser fc{std::fopen(path, "rb")};
+    if (!fc.f) return fail(ctx, VSC_ERR_INVALID, (std::string("vsc_genome_index_load: cannot read ") + path).c_str());
+    IndexFileHeader h{};
+    if (std::fread(&h, sizeof h, 1, fc.f) != 1 || std::memcmp(h.magic, kIndexMagic, sizeof h.magic) != 0)
+        return fail(ctx, VSC_ERR_INVALID, (std::string("vsc_genome_index_load: ") + path + " is not a seed index file").c_str());
+    if (h.abi != VSC_ABI_VERSION || h.seg_bases != (uint32_t)kSegBases || h.sliced_chunk != (uint32_t)kSlicedChunk ||
+        h.sliced_sites != (uint32_t)kSlicedSites)
+        return fail(ctx, VSC_ERR_INVALID, "vsc_genome_index_load: the file was written by another version of the library");
+    uint64_t fp = 0;
+    VSC_HIP(ctx, genome_fingerprint(genome, &fp));
+    if (h.own_words != genome->own_words || h.n_contigs != genome->n_contigs || h.fingerprint != fp)
+        return fail(ctx, VSC_ERR_INVALID, "vsc_genome_index_load: the file belongs to another genome");
+    const uint64_t S = h.sites;
+    if (3 * S >= (1ull << 32) || h.edge_words != (3 * S + 31) / 32 + 1 || h.vert_bytes % (2 * kRestBases * sizeof(uint32_t)) != 0)
+        return fail(ctx, VSC_ERR_INVALID, "vsc_genome_index_load: inconsistent header");
+    free_index(genome);
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+    };
+    const uint64_t sb = std::max<uint64_t>(3 * S, 1) * sizeof(uint2), eb = h.edge_words * sizeof(uint32_t);
+    const uint64_t cb = std::max<uint64_t>(h.chunks, 1) * sizeof(uint4), vb = std::max<uint64_t>(h.vert_bytes, 2 * kRestBases * sizeof(uint32_t));
+    step(hipMalloc((void **)&genome->d_ix_sites, sb));
+    step(hipMalloc((void **)&genome->d_ix_edge, eb));
+    step(hipMalloc((void **)&genome->d_ix_chunk_tab, cb));
+    step(hipMalloc((void **)&genome->d_ix_vert, vb));
+    bool ok = true;
+    std::vector<char> host(kIndexIoChunk);
+    if (e == hipSuccess) step(index_io(fc.f, genome->d_ix_sites, 3 * S * sizeof(uint2), false, host, &ok));
+    if (e == hipSuccess && ok) step(index_io(fc.f, genome->d_ix_edge, eb, false, host, &ok));
+    if (e == hipSuccess && ok) step(index_io(fc.f, genome->d_ix_chunk_tab, (uint64_t)h.chunks * sizeof(uint4), false, host, &ok));
+    if (e == hipSuccess && ok) step(index_io(fc.f, genome->d_ix_vert, h.vert_bytes, false, host, &ok));
+    if (e != hipSuccess || !ok) {
+        free_index(genome);
+        if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, "vsc_genome_index_load", e);
+        return fail(ctx, VSC_ERR_INVALID, (std::string("vsc_genome_index_load: ") + path + " is truncated").c_str());
+    }
+    genome->ix_chunks = h.chunks;
+    genome->ix_vert_bytes = vb;
+    genome->ix_edge_words = h.edge_words;
+    genome->index_sites = S;
+    genome->sites = S;
+    genome->has_index = true;
+    genome->index_has_extra_pam = h.has_extra_pam;
+    genome->index_extra_pam[0] = h.extra_pam[0];
+    genome->index_extra_pam[1] = h.extra_pam[1];
+    genome->index_bytes = sb + eb + cb + vb;
+    genome->index_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->timing.index_ms = genome->index_ms;
     return VSC_OK;
 }
