@@ -380,7 +380,8 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
     // (thread 0 walking two binary searches through global memory here cost as much as loading the bin)
     if (few_contigs) {
         const uint32_t p_lo = s_edge[0], p_hi = s_edge[1];
-        const uint64_t le_lo = __ballot(my_contig <= p_lo), le_hi = __ballot(my_contig <= p_hi);
+        const bool mine = t < a.n_contigs;  // (the filler value of the other threads is a valid upper end of a range)
+        const uint64_t le_lo = __ballot(mine && my_contig <= p_lo), le_hi = __ballot(mine && my_contig <= p_hi);
         if (t % kWave == 0) {
             if (le_lo) atomicAdd(&s_edge[2], (uint32_t)__popcll(le_lo));
             if (le_hi) atomicAdd(&s_edge[3], (uint32_t)__popcll(le_hi));
