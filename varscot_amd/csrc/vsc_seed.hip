@@ -470,7 +470,8 @@ __device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, boo
     if (hit) state = atomicAdd(&w.parts[region], 1u);  // LDS; the count may run past `reserve`: those lanes take the path below
     const uint32_t slot = state & kPartUsedMask;
     const bool placed = hit && slot < a.reserve;
-    if (placed) a.hit_recs[(unsigned long long)region * a.part_cap + ((state >> kPartUsedBits) << a.reserve_log2) + slot] = rec;
+    // (part_cap < 2^32 - the host checks - so the slot index is one 32 x 32 -> 64-bit multiply-add)
+    if (placed) a.hit_recs[(unsigned long long)region * (uint32_t)a.part_cap + (((state >> kPartUsedBits) << a.reserve_log2) + slot)] = rec;
     uint64_t todo = __ballot(hit && !placed);
     while (todo != 0) {
         const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)region, (int)__builtin_ctzll(todo));
