@@ -508,16 +508,20 @@ __device__ __forceinline__ uint32_t ring_slot(uint32_t p)
 }
 
 // ring slots head .. head + n - 1 -> one token per lane (lanes >= n stay empty), gather issued
+// (kFull: n == 64, every lane takes a token - no predication, nothing to clear)
+template <bool kFull>
 __device__ __forceinline__ SlicedFetch sliced_fetch(const SeedArgs &a, const SeedWave &w, uint32_t head, uint32_t n)
 {
     SlicedFetch f;
-    f.word = 0;
-    f.hi = 0;
-    f.site0 = 0;
-    f.z = 0;
-    f.gp = make_uint2(0u, 0u);
-    f.rec = make_uint2(0u, 0u);
-    if (w.lane < n) {
+    if (!kFull) {
+        f.word = 0;
+        f.hi = 0;
+        f.site0 = 0;
+        f.z = 0;
+        f.gp = make_uint2(0u, 0u);
+        f.rec = make_uint2(0u, 0u);
+    }
+    if (kFull || w.lane < n) {
         const uint4 tk = w.tok4[ring_slot(head + w.lane)];
         f.word = tk.x;
         f.hi = tk.y;
@@ -533,9 +537,10 @@ __device__ __forceinline__ SlicedFetch sliced_fetch(const SeedArgs &a, const See
 // w.ntok tokens wait in the ring from slot w.thead on; `tail` = first free slot
 __device__ __forceinline__ uint32_t ring_tail(const SeedWave &w) { return ring_slot(w.thead + w.ntok); }
 
+template <bool kFull>
 __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, const SlicedFetch &f)
 {
-    bool hit = f.word != 0;
+    bool hit = kFull || f.word != 0;
     // more hits of the same (block, read): back into the ring
     const uint32_t rest = f.word & (f.word - 1);
     const uint64_t again = __ballot(rest != 0);
@@ -576,21 +581,25 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
     sliced_store(a, w, hit, gid_of >> kRegionBits, rec);
 }
 
-// Resolves tokens in passes of 64.  drain = false: full passes only - what is left (< 64 tokens) waits
-// for more, so that every pass is dense; drain = true (end of a grab of chunks): everything.
-__device__ __forceinline__ void sliced_resolve(const SeedArgs &a, SeedWave &w, bool drain)
+// Resolves tokens in passes of 64.  kDrain = false: full passes only - what is left (< 64 tokens) waits
+// for more, so that every pass is dense (and its code free of predication); kDrain = true (end of a grab of
+// chunks): everything.
+template <bool kDrain>
+__device__ __forceinline__ void sliced_resolve(const SeedArgs &a, SeedWave &w)
 {
     wave_sync();
     bool have = false;
-    SlicedFetch f = sliced_fetch(a, w, 0, 0);
+    SlicedFetch f = sliced_fetch<false>(a, w, 0, 0);
     for (;;) {
         uint32_t n = min(w.ntok, (uint32_t)kWave);
-        if (!drain && n < (uint32_t)kWave) n = 0;
+        if (!kDrain && n < (uint32_t)kWave) n = 0;
         if (n == 0 && !have) break;
-        const SlicedFetch nf = sliced_fetch(a, w, w.thead, n);  // n == 0: empty
+        SlicedFetch nf = f;  // n == 0: not looked at again
+        if (kDrain) nf = sliced_fetch<false>(a, w, w.thead, n);
+        else if (n) nf = sliced_fetch<true>(a, w, w.thead, n);
         w.thead = ring_slot(w.thead + n);
         w.ntok -= n;
-        if (have) sliced_consume(a, w, f);  // may append to the ring
+        if (have) sliced_consume<!kDrain>(a, w, f);  // may append to the ring
         wave_sync();
         f = nf;
         have = n != 0;
@@ -741,11 +750,11 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
                         w.ntok += (uint32_t)__popcll(b);
                     }
                     // a group of four reads adds at most 4 x 64 tokens, a resolve leaves fewer than 64
-                    if (w.ntok >= (uint32_t)kSlicedResolve * kWave) sliced_resolve(a, w, false);
+                    if (w.ntok >= (uint32_t)kSlicedResolve * kWave) sliced_resolve<false>(a, w);
                 }
             }
         }
-        if (w.ntok) sliced_resolve(a, w, true);  // the tokens name chunks of this grab: all out before the next
+        if (w.ntok) sliced_resolve<true>(a, w);  // the tokens name chunks of this grab: all out before the next
     }
     sliced_finish_hits(a, w);
     if (w.lane == 0 && pairs) {
