@@ -720,7 +720,7 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
         const size_t n_bins = n_segs << bits;
         VSC_TRY(ctx->sort_over.ensure(256 + n_bins * sizeof(SortSeg)));
         uint32_t *d_n_over = (uint32_t *)ctx->sort_over.p;
-        VSC_TRY(hipMemsetAsync(d_n_over, 0, sizeof(uint32_t), st));
+        VSC_TRY(hipMemsetAsync(d_n_over, 0, 2 * sizeof(uint32_t), st));  // [0] listed bins, [1] the finalize kernel's bin cursor
         FinArgs f{};
         f.segs = d_segs;
         f.n_segs = (uint32_t)n_segs;
@@ -787,11 +787,12 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
         f.over = (SortSeg *)((char *)ctx->sort_over.p + 256);
         f.over_cap = (uint32_t)std::min<size_t>(n_bins, 0xFFFFFFFFu);
         f.n_over = d_n_over;
+        f.cursor = d_n_over + 1;
         f.cap = (uint32_t)sort_cap;
         f.contig_off = genome->d_contig_off;
         f.n_contigs = genome->n_contigs;
         f.out = out;
-        VSC_TRY(launch_bin_finalize(f, st));
+        VSC_TRY(launch_bin_finalize(f, 2 * ctx->n_cus, st));  // two workgroups fit a CU (LDS)
         if (info) info->bytes += 24 * n_all;  // finalize: 8-byte read, 16-byte write
         if (!bits) break;  // every segment fitted: nothing can come back
         uint32_t n_over = 0;

@@ -160,6 +160,7 @@ struct FinArgs {
     uint32_t over_cap;
     uint32_t cap;                  // <= kSortCap (smaller in tests only)
     uint32_t *n_over;
+    uint32_t *cursor;              // zeroed: the resident workgroups count the bins they take here
     const uint32_t *contig_off;    // ascending global start positions of all contigs
     uint32_t n_contigs;
     vsc_hit *out;
@@ -238,7 +239,7 @@ hipError_t launch_scan(const ScanArgs &args, int n_groups, bool extract, hipStre
 hipError_t launch_bin_hist(const SortArgs &args, hipStream_t stream);
 hipError_t launch_bin_scan(const SortArgs &args, hipStream_t stream);
 hipError_t launch_bin_partition(const SortArgs &args, hipStream_t stream);
-hipError_t launch_bin_finalize(const FinArgs &args, hipStream_t stream);
+hipError_t launch_bin_finalize(const FinArgs &args, int max_groups, hipStream_t stream);
 hipError_t launch_rf_predict(const RfArgs &args, hipStream_t stream);
 hipError_t launch_interleave(const uint32_t *hi, const uint32_t *lo, uint64_t n, uint2 *hl, hipStream_t stream);
 hipError_t launch_score(const ScoreArgs &args, hipStream_t stream);

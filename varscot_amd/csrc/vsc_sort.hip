@@ -300,7 +300,8 @@ constexpr int kFinalizeAhead = 4;  // records of a sub-bin the ranking reads at 
 constexpr int kFinalizeNear = 4;    // contigs a bin's position range may touch for the straight-line contig lookup
 constexpr int kFinalizeRange = 64;  // ... for a binary search in LDS (more: in global memory - variant genomes)
 
-__global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs a)
+// one bin (index `which` over all segments' bins), by the whole workgroup
+__device__ __forceinline__ void finalize_bin(const FinArgs &a, const uint32_t which)
 {
     __shared__ uint64_t s_rec[kSortCap];
     __shared__ uint32_t s_sub[(1 << kSortSubBits) / 2 + 1 + kWave];  // packed pairs of 16-bit counters, then first slots (+ spares)
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
     __shared__ uint32_t s_range[2 + kFinalizeRange];  // first contig of the bin's position range, contigs in it, their starts
     __shared__ uint32_t s_edge[4];                    // the bin's position range [0], [1]; contigs starting at or below either end [2], [3]
     const uint32_t t = threadIdx.x;
-    const uint32_t seg = blockIdx.x >> a.bin_bits, bin = blockIdx.x & ((1u << a.bin_bits) - 1u);
+    const uint32_t seg = which >> a.bin_bits, bin = which & ((1u << a.bin_bits) - 1u);
     const SortSeg sg = a.segs[seg];
     uint64_t src = sg.in_off, dst = sg.final_off;
     uint32_t n_src = sg.n_in;
@@ -544,14 +545,35 @@ __global__ __launch_bounds__(kFinThreads) void bin_finalize_kernel(const FinArgs
     }
 }
 
-hipError_t launch_bin_finalize(const FinArgs &args, hipStream_t stream)
+// Two workgroups per CU stay resident and take bins from a counter.  One workgroup per bin, dealt round-robin over
+// the XCDs in launch order, ran into the layout of the bins: a genome that fills 70 % of the 32-bit position space
+// leaves the same five of every sixteen consecutive bins (one read's, one strand's) empty, always those of the same
+// XCDs, and in-order dispatch makes the others wait for the busy ones (3 Gbp: 12.1 ms; 3.9 Gbp with 30 % more
+// records: 11.2 ms; bins rotated by their group number: 11.1 ms).
+// (amdgpu_waves_per_eu: two workgroups of 8 waves per CU = 4 waves per SIMD = at most 128 VGPRs; the loop makes the allocator ask for 166)
+__global__ __launch_bounds__(kFinThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bin_finalize_kernel(const FinArgs a)
+{
+    __shared__ uint32_t s_next[2];
+    const uint32_t total = a.n_segs << a.bin_bits;
+    uint32_t which = blockIdx.x, parity = 0;
+    while (which < total) {
+        // the next bin's number is asked for now and looked at after this bin
+        if (threadIdx.x == 0) s_next[parity] = atomicAdd(a.cursor, 1u) + gridDim.x;
+        finalize_bin(a, which);
+        block_sync();  // the LDS tables are free again, s_next is written
+        which = s_next[parity];
+        parity ^= 1u;
+    }
+}
+
+hipError_t launch_bin_finalize(const FinArgs &args, int max_groups, hipStream_t stream)
 {
     if (args.n_segs == 0) return hipSuccess;
-    const uint64_t blocks = (uint64_t)args.n_segs << args.bin_bits;
-    if (blocks >= (1ull << 31) || args.sub_bits > (uint32_t)kSortSubBits || args.bin_bits > (uint32_t)kSortMaxBinBits ||
-        args.cap > (uint32_t)kSortCap)
+    const uint64_t bins = (uint64_t)args.n_segs << args.bin_bits;
+    if (bins >= (1ull << 31) || args.sub_bits > (uint32_t)kSortSubBits || args.bin_bits > (uint32_t)kSortMaxBinBits ||
+        args.cap > (uint32_t)kSortCap || max_groups < 1)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bin_finalize_kernel, dim3((unsigned)blocks), dim3(kFinThreads), 0, stream, args);
+    hipLaunchKernelGGL(bin_finalize_kernel, dim3((unsigned)std::min<uint64_t>(bins, (uint64_t)max_groups)), dim3(kFinThreads), 0, stream, args);
     return hipGetLastError();
 }
 
