@@ -308,7 +308,11 @@ __device__ __forceinline__ void finalize_bin(const FinArgs &a, const uint32_t wh
     __shared__ uint32_t s_wave[kFinThreads / kWave];
     __shared__ uint32_t s_range[2 + kFinalizeRange];  // first contig of the bin's position range, contigs in it, their starts
     __shared__ uint32_t s_edge[4];                    // the bin's position range [0], [1]; contigs starting at or below either end [2], [3]
-    const uint32_t t = threadIdx.x;
+    // (opaque to the optimiser: hoisted out of the caller's loop over bins, the addresses derived from the thread
+    // number stay live across it - 166 VGPRs wanted, 128 allowed for two workgroups per CU, the rest spilled)
+    uint32_t t_ = threadIdx.x;
+    asm volatile("" : "+v"(t_));
+    const uint32_t t = t_;
     const uint32_t seg = which >> a.bin_bits, bin = which & ((1u << a.bin_bits) - 1u);
     const SortSeg sg = a.segs[seg];
     uint64_t src = sg.in_off, dst = sg.final_off;
