@@ -23,7 +23,14 @@ def test_header_symbols_are_exported_and_bound():
     L = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert va.lib().vsc_abi_version() == 2
+    version = int(re.search(r"#define\s+VSC_ABI_VERSION\s+(\d+)", text).group(1))
+    assert va.lib().vsc_abi_version() == version == 2
+
+
+def test_graft_entry_build_check_follows_the_header():
+    """__graft_entry__.build() must not pin a version number of its own (it did: 1, while the header said 2)."""
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "VSC_ABI_VERSION" in src and not re.search(r"vsc_abi_version\(\)\s*==\s*\d", src)
 
 
 def test_no_device_fails_loudly():
