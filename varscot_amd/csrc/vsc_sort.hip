@@ -132,15 +132,21 @@ __global__ __launch_bounds__(kSortThreads) void bin_hist_kernel(const SortArgs a
         const SortSeg sg = a.segs[seg];
         const uint32_t first = (tile - a.seg_tile0[seg]) * (uint32_t)kSortTile;
         const uint32_t n = min(sg.n_in - first, (uint32_t)kSortTile);
-#pragma unroll 4
+        // all sixteen loads first, without branches (see bin_partition_kernel), then the counting
+        uint64_t r[kSortItems];
+#pragma unroll
         for (int k = 0; k < kSortItems; ++k) {
             const uint32_t i = tile_record(k, t);
-            if (i >= n) continue;
+            const uint64_t at = sg.in_off + first + (i < n ? i : 0u);
+            const uint64_t v = kPairs ? a.pair_keys[at] : a.in[at];
+            r[k] = i < n ? v : kRecSentinel;
+        }
+#pragma unroll
+        for (int k = 0; k < kSortItems; ++k) {
             if (kPairs) {
-                atomicAdd(&s_hist[(uint32_t)(a.pair_keys[sg.in_off + first + i] >> a.bin_shift)], 1u);
+                if (tile_record(k, t) < n) atomicAdd(&s_hist[(uint32_t)(r[k] >> a.bin_shift)], 1u);
             } else {
-                const uint64_t r = a.in[sg.in_off + first + i];
-                if (!(r >> 63)) atomicAdd(&s_hist[(uint32_t)(r >> a.bin_shift) & (nbins - 1u)], 1u);
+                if (!(r[k] >> 63)) atomicAdd(&s_hist[(uint32_t)(r[k] >> a.bin_shift) & (nbins - 1u)], 1u);
             }
         }
     }
