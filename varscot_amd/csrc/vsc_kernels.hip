@@ -636,22 +636,33 @@ __global__ __launch_bounds__(256) void score_packed_kernel(const ScoreArgs a, ui
 {
     __shared__ uint4 s_rows[256][4];
     __shared__ uint64_t s_index[256];  // the row every thread computed
-    __shared__ uint32_t s_seg;
+    __shared__ uint32_t s_count[2];
     const uint32_t t = threadIdx.x;
     const uint64_t v = (uint64_t)blockIdx.x * 256 + t;  // position in processing order
     uint64_t i = v;
     if (a.seg_prefix) {
-        if (t == 0) {  // the segment of the workgroup's first position: the last j with seg_prefix[j] <= v
-            uint32_t lo = 0, hi = a.n_segs;
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (a.seg_prefix[mid] <= v) lo = mid; else hi = mid;
-            }
-            s_seg = lo;
-        }
+        // The segment of the workgroup's first position v0 (the last j with seg_prefix[j] <= v0): a 256-ary search by
+        // all threads, three rounds of one global load each for 10^5 segments.  (Thread 0 alone, seventeen dependent
+        // loads deep while 255 threads waited at the barrier, was a third of the kernel's time: c5 scoring 525 ms.)
+        const uint64_t v0 = (uint64_t)blockIdx.x * 256;
+        uint32_t lo = 0, hi = a.n_segs;  // seg_prefix[lo] <= v0 < seg_prefix[hi]
+        if (t < 2) s_count[t] = 0;
         block_sync();
+        for (uint32_t round = 0; hi - lo > 1; ++round) {
+            const uint32_t step = (hi - lo + 255u) / 256u;
+            const uint32_t at = lo + t * step;
+            const bool below = t > 0 && at < hi && a.seg_prefix[at] <= v0;  // true for t = 1 .. k, false from k + 1 on
+            const uint64_t b = __ballot(below);
+            if ((t & 63u) == 0 && b) atomicAdd(&s_count[round & 1u], (uint32_t)__popcll(b));
+            if (t == 0) s_count[(round + 1u) & 1u] = 0;
+            block_sync();
+            const uint32_t k = s_count[round & 1u];
+            lo += k * step;
+            hi = min(hi, lo + step);
+            block_sync();  // everybody has read the count before the round after next clears it
+        }
         if (v < a.n) {
-            uint32_t j = s_seg;
+            uint32_t j = lo;
             while (v >= a.seg_prefix[j + 1]) ++j;  // a workgroup's 256 positions span one to three segments
             i = a.seg_start[j] + (v - a.seg_prefix[j]);
         }
