@@ -199,3 +199,54 @@ def test_c4_variant_windows_at_full_size(big, tmp_path):
     assert (k + 1, off) in set(zip(exact["contig"].tolist(), exact["pos"].tolist()))
     one_off = mine[(mine["contig"] == k) & (mine["pos"] == off)]
     assert len(one_off) == 1 and int(one_off["info"][0]) & 0x7FFFFF == 1 << 10  # REF window: the SNP position mismatches
+
+
+def test_skewed_reads_at_scale():
+    """Three of 300 reads with ~130 000 extra sites each inside one 40 Mbp window of a 1 Gbp genome (an Alu-like
+    family): their bins exceed the finalize kernel's capacity by an order of magnitude, so the result goes through
+    further partition levels, and the regions that hold them fill far beyond the uniform model the first buffer
+    size comes from (the search re-runs with more room).  scan == seed, strictly sorted, planted sites found."""
+    from varscot_amd import _lib
+    ctx = va.Context(0)
+    packed = synth.synthetic_genome(1_000_000_000)
+    ids, guides = synth.synthetic_guides(300)
+    rng = np.random.default_rng(99)
+    c = int(np.argmax(packed.contigs["length"]))
+    off, ln = int(packed.contigs[c]["offset"]), int(packed.contigs[c]["length"])
+    assert ln > 45_000_000
+    L = _lib.lib()
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    planted = []
+    starts = rng.choice(40_000_000 // 32, size=400_000, replace=False) * 32 + 1_000_000  # no two sites overlap
+    for k, pos in enumerate(starts.tolist()):
+        gi = k % 3
+        site = list(guides[gi])
+        for q in rng.choice(20, size=int(rng.integers(0, 4)), replace=False):
+            site[q] = "ACGT"[("ACGT".index(site[q]) + 1 + int(rng.integers(0, 3))) % 4]
+        strand = k & 1
+        t = "".join(site)
+        if strand:
+            t = "".join(comp[ch] for ch in reversed(t))
+        L.vsc_pack_bases(t.encode(), 23, off + pos, _lib.ptr(packed.hi), _lib.ptr(packed.lo), _lib.ptr(packed.nmask))
+        if k < 3000:
+            planted.append((gi, c, pos, strand))
+    genome = ctx.load_genome(packed)
+    genome.build_index()
+    h = genome.search(guides, 8, algorithm="seed")
+    t_seed = ctx.timing()
+    a = h.to_numpy().copy()
+    h.close()
+    h = genome.search(guides, 8, algorithm="scan")
+    b = h.to_numpy().copy()
+    h.close()
+    genome.close()
+    ctx.close()
+    assert a.tobytes() == b.tobytes()
+    per_read = np.bincount(a["guide"], minlength=300)
+    assert per_read[:3].min() > 100_000 and per_read[3:].max() < 100_000
+    assert t_seed["sort_levels"] >= 2
+    key = ((a["guide"].astype(np.int64) << 1 | (a["info"] >> 31)) << 6 | a["contig"]) << 32 | a["pos"]
+    assert np.all(np.diff(key) > 0)
+    found = set(zip(a["guide"][a["guide"] < 3].tolist(), a["contig"][a["guide"] < 3].tolist(), a["pos"][a["guide"] < 3].tolist(),
+                    (a["info"][a["guide"] < 3] >> 31).tolist()))
+    assert all(p in found for p in planted)
