@@ -13,10 +13,11 @@
 //                         with LDS atomics, reserves room in every bin with one coalesced returning atomic
 //                         per bin, regroups the tile by bin in LDS and writes each bin's records as one
 //                         contiguous piece.  Pieces of different tiles land in a bin in arbitrary order.
-//   bin_finalize_kernel   one read + the 16-byte result write: a workgroup takes one bin (<= 8 064 records,
-//                         one read's hits on one strand inside a position window), counting-sorts it in LDS
-//                         on the next <= 13 key bits, ranks the handful of records that still agree (keys
-//                         are unique), resolves the contig and writes the vsc_hit records in place.
+//   bin_finalize_kernel   one read + the 16-byte result write: resident workgroups take bins from a counter; a
+//                         bin (<= 8 064 records, one read's hits on one strand inside a position window) is
+//                         counting-sorted in LDS on the next <= 13 key bits, the handful of records that still
+//                         agree are ranked (keys are unique), the contig is resolved and the vsc_hit records
+//                         are written in place.
 //
 // A bin that exceeds the LDS capacity (a read with far more hits than the others - repeats) is listed and
 // goes through another hist / scan / partition level on the following key bits; bins of a level are
