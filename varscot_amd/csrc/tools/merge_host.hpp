@@ -12,7 +12,10 @@
 #include <map>
 #include <sstream>
 #include <stdexcept>
+#include <cstdio>
+#include <functional>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -345,20 +348,72 @@ inline void write_outputs(const std::string &out_path, const std::string *featur
         vsc_ctx_destroy(ctx);
         if (st != VSC_OK) throw std::runtime_error("ERROR: " + err);
     }
-    for (size_t i = 0; i < n; ++i) {
-        const OffTarget &p = *rows[i];
-        const std::string name = p.target + "_" + std::to_string(++count.at(p.target));
-        out << p.chr << "\t" << p.pos << "\t" << (p.pos + 23) << "\t" << name << "\t";
-        if (feature_path) out << ".\t"; else out << fmt_double(mit[i]) << "\t";
-        out << p.strand << "\t" << p.sequence << "\t" << mm_columns(p, merged);
-        if (merged) out << p.snp_type;
-        out << "\n";
-        if (feature_path) {
-            fout << name << "\t";
-            for (int k = 0; k < VSC_N_FEATURES; ++k) fout << (unsigned)feat[i * VSC_N_FEATURES + k] << "\t";
-            fout << fmt_double(activity.at(p.target)) << "\n";
+    // Text: the names carry running numbers per target (sequential), the rows themselves are formatted in blocks
+    // by all host threads and written in order - 443 numbers per feature row through a stream, one `<<` each,
+    // took 20 s for 2.6 M rows.
+    std::vector<uint32_t> number(n);
+    for (size_t i = 0; i < n; ++i) number[i] = ++count.at(rows[i]->target);
+    std::unordered_map<std::string, std::string> activity_text;
+    if (feature_path)
+        for (size_t i = 0; i < n; ++i)
+            if (!activity_text.count(rows[i]->target)) activity_text[rows[i]->target] = fmt_double(activity.at(rows[i]->target));
+    char small[256][4];  // "0" .. "255"
+    uint8_t small_len[256];
+    for (int v = 0; v < 256; ++v) small_len[v] = (uint8_t)std::snprintf(small[v], sizeof small[v], "%d", v);
+    auto format_block = [&](size_t b, size_t e, std::string &tsv, std::string &fm) {
+        tsv.clear();
+        fm.clear();
+        if (feature_path) fm.reserve((e - b) * (2 * VSC_N_FEATURES + 64));
+        for (size_t i = b; i < e; ++i) {
+            const OffTarget &p = *rows[i];
+            const std::string name = p.target + "_" + std::to_string(number[i]);
+            tsv += p.chr;
+            tsv += '\t';
+            tsv += std::to_string(p.pos);
+            tsv += '\t';
+            tsv += std::to_string(p.pos + 23);
+            tsv += '\t';
+            tsv += name;
+            tsv += '\t';
+            tsv += feature_path ? std::string(".") : fmt_double(mit[i]);
+            tsv += '\t';
+            tsv += p.strand;
+            tsv += '\t';
+            tsv += p.sequence;
+            tsv += '\t';
+            tsv += mm_columns(p, merged);
+            if (merged) tsv += p.snp_type;
+            tsv += '\n';
+            if (feature_path) {
+                fm += name;
+                fm += '\t';
+                const uint8_t *f = feat.data() + i * VSC_N_FEATURES;
+                for (int k = 0; k < VSC_N_FEATURES; ++k) {
+                    fm.append(small[f[k]], small_len[f[k]]);
+                    fm += '\t';
+                }
+                fm += activity_text.at(p.target);
+                fm += '\n';
+            }
+        }
+    };
+    const unsigned n_threads = vsc_host::host_threads();
+    const size_t block = 16384;
+    std::vector<std::string> tsv(n_threads), fm(n_threads);
+    for (size_t base = 0; base < n; base += block * n_threads) {
+        std::vector<std::thread> workers;
+        unsigned used = 0;
+        for (unsigned t = 0; t < n_threads && base + t * block < n; ++t, ++used) {
+            const size_t b = base + t * block, e = std::min(n, b + block);
+            workers.emplace_back(format_block, b, e, std::ref(tsv[t]), std::ref(fm[t]));
+        }
+        for (auto &w : workers) w.join();
+        for (unsigned t = 0; t < used; ++t) {
+            out.write(tsv[t].data(), (std::streamsize)tsv[t].size());
+            if (feature_path) fout.write(fm[t].data(), (std::streamsize)fm[t].size());
         }
     }
+    if (!out || (feature_path && !fout)) throw std::runtime_error("ERROR: Could not write the output file.");
 }
 
 }  // namespace vsc_merge

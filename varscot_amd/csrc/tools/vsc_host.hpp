@@ -3,12 +3,15 @@
 // (include/varscot_hip.h).
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "varscot_hip.h"
@@ -78,6 +81,15 @@ struct PackedIndex {
     std::vector<std::string> names;
     std::vector<uint32_t> hi, lo, nm;
 };
+
+// worker threads for host-side text work: OMP_NUM_THREADS if the driver set it (VARSCOT:257), else all cores
+inline unsigned host_threads()
+{
+    const char *e = std::getenv("OMP_NUM_THREADS");
+    const long v = e ? std::strtol(e, nullptr, 10) : 0;
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (unsigned)std::max<long>(1, std::min<long>(v > 0 ? v : (long)(hw ? hw : 1), 64));
+}
 
 inline std::string index_path(const std::string &prefix) { return prefix + ".vsc"; }
 inline std::string seed_index_path(const std::string &prefix) { return prefix + ".vsi"; }  // optional: bidir_index -S
