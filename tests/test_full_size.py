@@ -250,3 +250,49 @@ def test_skewed_reads_at_scale():
     found = set(zip(a["guide"][a["guide"] < 3].tolist(), a["contig"][a["guide"] < 3].tolist(), a["pos"][a["guide"] < 3].tolist(),
                     (a["info"][a["guide"] < 3] >> 31).tolist()))
     assert all(p in found for p in planted)
+
+
+def test_genome_close_to_the_32_bit_position_limit():
+    """4.29e9 positions - 8 192 is what bidir_index accepts (RM/bidir_index.cpp:17: 4 giga bases); here 4.28e9 bases
+    in 24 contigs: positions up to 2^32 - 1.4e7, all 32 position bits in use, bins at the very top of the key space.
+    scan == seed, strictly sorted, planted sites near the end of the last contig found."""
+    ctx = va.Context(0)
+    packed = synth.synthetic_genome(4_280_000_000)
+    last = len(packed.contigs) - 1
+    span = int(packed.contigs[last]["offset"]) + int(packed.contigs[last]["length"])
+    assert (1 << 32) - (1 << 25) < span < (1 << 32) - 8192
+    ids, guides = synth.synthetic_guides(200)
+    L = _lib_handle()
+    planted = []
+    for i in range(40):  # sites in the last 10 Mbp of the last contig, both strands
+        g = guides[i]
+        site = g if i % 2 == 0 else "".join({"A": "T", "C": "G", "G": "C", "T": "A"}[c] for c in reversed(g))
+        pos = int(packed.contigs[last]["length"]) - 10_000_000 + 200_003 * i
+        L.vsc_pack_bases(site.encode(), 23, int(packed.contigs[last]["offset"]) + pos, _ptr(packed.hi), _ptr(packed.lo), _ptr(packed.nmask))
+        planted.append((i, last, pos, i % 2))
+    genome = ctx.load_genome(packed)
+    genome.build_index()
+    h = genome.search(guides, 6, algorithm="seed")
+    a = h.to_numpy().copy()
+    h.close()
+    h = genome.search(guides, 6, algorithm="scan")
+    b = h.to_numpy().copy()
+    h.close()
+    genome.close()
+    ctx.close()
+    assert len(a) > 500_000 and a.tobytes() == b.tobytes()
+    key = ((a["guide"].astype(np.int64) << 1 | (a["info"] >> 31)) << 6 | a["contig"]) << 32 | a["pos"]
+    assert np.all(np.diff(key) > 0)
+    found = set(zip(a["guide"].tolist(), a["contig"].tolist(), a["pos"].tolist(), (a["info"] >> 31).tolist()))
+    assert all(p in found for p in planted)
+    assert int((a["contig"] == last).sum()) > 10_000
+
+
+def _lib_handle():
+    from varscot_amd import _lib
+    return _lib.lib()
+
+
+def _ptr(x):
+    from varscot_amd import _lib
+    return _lib.ptr(x)
