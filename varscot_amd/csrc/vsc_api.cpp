@@ -921,7 +921,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         sa.contig_end = genome->d_contig_end;
         sa.n_contigs = genome->n_contigs;
         sa.counters = (unsigned long long *)ctx->counters.p;
-        uint32_t groups_per_cu = 4;  // resident groups per CU (registers / LDS of the kernel)
+        uint32_t groups_per_cu = kSlicedWavesPerSimd;  // resident groups (of four waves) per CU: registers / LDS of the kernel
         if (const char *o = std::getenv("VSC_SEED_GROUPS_PER_CU")) groups_per_cu = (uint32_t)std::max(1, std::atoi(o));
         const uint32_t n_waves_max = (uint32_t)ctx->n_cus * groups_per_cu * kWavesPerGroup;
         const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, (sa.n_chunks + kSlicedGrab - 1) / kSlicedGrab));

@@ -35,15 +35,18 @@ constexpr int kSlicedSites = 32;                // sites per lane of the bit-sli
 constexpr int kSlicedChunk = kWave * kSlicedSites;  // 2048 sites per wave and chunk
 constexpr int kRestBases = VSC_READ_LEN - kSegBases;  // 16 read positions outside the seed segment
 constexpr int kListDistShift = 30;              // list entry y: read index | seed distance << 30
-constexpr int kTokLaneShift = 26;               // sliced hit token, high word: read index | lane << 26
+constexpr int kTokLaneShift = 26;               // sliced hit token, high word: read of the pass (14 bits) | chunk slot << 14 | lane << 26
+constexpr int kTokSlotShift = 14;
+constexpr uint32_t kTokReadMask = (1u << kTokSlotShift) - 1u;
 constexpr int kSlicedResolve = 3;                // sliced kernel: resolve when this many passes of 64 tokens wait (the
                                                 // gathers of the later passes overlap the earlier ones)
-constexpr int kSlicedTokCap = (kSlicedResolve + 4) * 64;  // per-wave LDS ring of 16-byte hit tokens: a group of four reads adds <= 256
+constexpr int kSlicedTokCap = (kSlicedResolve + 4) * 64;  // per-wave LDS ring of 8-byte hit tokens: a group of four reads adds <= 256
 // chunk table word z: bucket (16 bits) | rank in the chunk of its first '-' site (0 .. 2048) << 16 | "holds a window
 // that is followed by N" << 28
 constexpr uint32_t kChunkBucketMask = 0xFFFFu;
 constexpr int kChunkMinusShift = 16;
 constexpr int kChunkEdgeBit = 28;
+constexpr int kSlicedWavesPerSimd = 5;          // resident waves of the sliced kernel per SIMD (registers and LDS allow five)
 constexpr int kSlicedGrab = 8;                  // chunks of 2048 sites per grab of the work counter (sliced kernel)
 
 // counters[] slots of one scan launch

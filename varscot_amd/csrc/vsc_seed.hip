@@ -270,7 +270,7 @@ hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
 
 struct SeedWave {
-    uint4 *tok4;     // pending hit tokens (see sliced_fetch)
+    uint2 *tok;      // pending hit tokens (see sliced_fetch)
     uint32_t ntok, lane;
     uint32_t thead;  // ring slot of the oldest pending token
     uint32_t *parts; // per output region: this wave's open block, block number << 11 | records claimed in it
@@ -420,14 +420,15 @@ __device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[2 * kRestB
     return ok;
 }
 
-// Second half of the hit path.  A token = {hit word of one lane's block, read | owner lane << 26, read hi
-// plane | chunk slot << 23, read lo plane}; a lane takes one token and resolves its LOWEST set bit: one 8-byte
-// gather of the site record (rest planes, position) + the bucket's code and the chunk's strand boundary (LDS)
-// give the full 23-position mask, the strand and the position.  A token with more bits goes
+// Second half of the hit path.  A token = {hit word of one lane's block, read | chunk slot in the grab << 14 |
+// owner lane << 26} (8 bytes: a ring of seven passes is 3.5 KB per wave, which is what lets five waves per SIMD
+// share the CU's LDS); a lane takes one token and resolves its LOWEST set bit: one 8-byte gather of the site
+// record (rest planes, position), one of the read's planes (a table of 8 bytes per read: cache resident) + the
+// bucket's code and the chunk's strand boundary (LDS) give the full 23-position mask, the strand and the position.  A token with more bits goes
 // back into the ring with that bit cleared, so every pass over 64 tokens is dense.  The gather of the next
 // 64 tokens is issued before the current 64 are consumed.
 struct SlicedFetch {
-    uint32_t word, hi, site0, z;  // z = read hi plane | chunk slot << 23, as in the token
+    uint32_t word, hi, site0;  // hi = read | chunk slot << 14 | owner lane << 26, as in the token
     uint2 gp;   // read planes
     uint2 rec;  // site record of the lowest set bit
 };
@@ -517,18 +518,16 @@ __device__ __forceinline__ SlicedFetch sliced_fetch(const SeedArgs &a, const See
         f.word = 0;
         f.hi = 0;
         f.site0 = 0;
-        f.z = 0;
         f.gp = make_uint2(0u, 0u);
         f.rec = make_uint2(0u, 0u);
     }
     if (kFull || w.lane < n) {
-        const uint4 tk = w.tok4[ring_slot(head + w.lane)];
+        const uint2 tk = w.tok[ring_slot(head + w.lane)];
         f.word = tk.x;
         f.hi = tk.y;
-        f.z = tk.z;
-        f.gp = make_uint2(tk.z & kMask23, tk.w);
+        f.gp = a.guides[tk.y & kTokReadMask];
         // the token's chunk is one of the kSlicedGrab chunks of the current grab (w.first = their first sites)
-        f.site0 = w.first[tk.z >> 23] + (tk.y >> kTokLaneShift) * kSlicedSites;
+        f.site0 = w.first[(tk.y >> kTokSlotShift) & (uint32_t)(kSlicedGrab - 1)] + (tk.y >> kTokLaneShift) * kSlicedSites;
         f.rec = a.sites[f.site0 + (uint32_t)__builtin_ctz(tk.x)];
     }
     return f;
@@ -545,15 +544,15 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
     const uint32_t rest = f.word & (f.word - 1);
     const uint64_t again = __ballot(rest != 0);
     if (again != 0) {
-        if (rest != 0) w.tok4[ring_slot(lanes_below(again, ring_tail(w)))] = make_uint4(rest, f.hi, f.z, f.gp.y);
+        if (rest != 0) w.tok[ring_slot(lanes_below(again, ring_tail(w)))] = make_uint2(rest, f.hi);
         w.ntok += (uint32_t)__popcll(again);
     }
     // Straight-line, computed for every lane (a lane without a token works on zeros): branches around the
     // few instructions cost more scalar mask bookkeeping than the instructions themselves.  Only the
     // right-edge rule - a binary search, needed by windows that end a contig - sits behind a wave-uniform test.
-    const uint32_t gid_of = f.hi & ((1u << kTokLaneShift) - 1u);
+    const uint32_t gid_of = f.hi & kTokReadMask;
     // the site's 23-base planes: its 16 rest positions from the record, the 7 segment positions = the bucket's code
-    const uint32_t info = w.info[f.z >> 23];  // chunk table word z of the token's chunk
+    const uint32_t info = w.info[(f.hi >> kTokSlotShift) & (uint32_t)(kSlicedGrab - 1)];  // chunk table word z of the token's chunk
     const uint32_t bucket = info & kChunkBucketMask;
     const uint32_t sh = (uint32_t)kSegBases * (bucket >> (2 * kSegBases));  // 7 x segment
     const uint32_t low = (1u << sh) - 1u;
@@ -633,11 +632,12 @@ __device__ __forceinline__ void sliced_load_sites(const SeedArgs &a, const v4u &
 }
 
 
-// (amdgpu_waves_per_eu: 4 waves per SIMD = at most 128 VGPRs; without the hint the allocator settles at 129)
-__global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(4, 4))) void seed_sliced_kernel(
+// (amdgpu_waves_per_eu: 5 waves per SIMD = at most 102 VGPRs; LDS: 5.7 KB per wave, 20 waves per CU)
+static_assert(kMaxPassReads <= (1 << kTokSlotShift) && kSlicedGrab <= 8 && kTokSlotShift + 3 <= kTokLaneShift, "token fields");
+__global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(kSlicedWavesPerSimd, kSlicedWavesPerSimd))) void seed_sliced_kernel(
     const SeedArgs a)
 {
-    __shared__ uint4 s_tok[kWavesPerGroup][kSlicedTokCap];
+    __shared__ uint2 s_tok[kWavesPerGroup][kSlicedTokCap];
     __shared__ uint4 s_list[kWavesPerGroup][kWave];  // the current tile of 64 read-list entries
     __shared__ uint32_t s_parts[kWavesPerGroup][kParts];
     __shared__ uint32_t s_first[kWavesPerGroup][2 * kSlicedGrab];
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     const uint32_t wave = threadIdx.x / kWave;
     SeedWave w;
     w.lane = threadIdx.x % kWave;
-    w.tok4 = s_tok[wave];
+    w.tok = s_tok[wave];
     w.ntok = 0;
     w.thead = 0;
     w.parts = s_parts[wave];
@@ -679,37 +679,34 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
         }
         const uint32_t first = slice_begin + off;
         const uint32_t last = min(first + (uint32_t)kSlicedGrab, slice_end);
-        // Three-stage software pipeline over the chunks of this grab, all stages one chunk apart:
-        //   A  chunk table entry (scalar load)   B  its read-list bounds poff[bucket..] (scalar load)
-        //   C  this lane's block of bit-sliced sites (8 x 16-byte vector loads)        then the comparison.
-        // With ~13 reads per bucket (1 000 reads) a chunk is compared in less time than one HBM round trip.
-        v4u t0 = ctab[first];                             // chunk c     : A done
-        v4u t1 = ctab[min(first + 1, last - 1)];          // chunk c + 1 : A in flight
-        uint32_t p0a = poff[t0.z & kChunkBucketMask], p0b = poff[(t0.z & kChunkBucketMask) + 1];  // chunk c     : B done
-        uint32_t nv[2 * kRestBases];
-        sliced_load_sites(a, t0, p0a != p0b, w.lane, nv);  // chunk c     : C in flight
-        uint4 nl = sliced_load_list(a, p0a, p0b, w.lane);   //               and the first 64 entries of its read list
-        uint32_t p1a = poff[t1.z & kChunkBucketMask], p1b = poff[(t1.z & kChunkBucketMask) + 1];  // chunk c + 1 : B in flight
-        v4u t2 = ctab[min(first + 2, last - 1)];          // chunk c + 2 : A in flight
+        // Software pipeline over the chunks of this grab: the chunk table entry (scalar load) runs two chunks ahead,
+        // the read-list bounds poff[bucket..] (scalar load) and the first 64 entries of the list one chunk ahead.
+        // The lane's block of bit-sliced sites (8 x 16-byte vector loads) is NOT fetched ahead: holding the next
+        // block cost 32 VGPRs, and at 93 instead of 125 a fifth wave per SIMD fits, which covers more than the one
+        // exposed round trip per chunk (c3: 26.4 -> 26.0 ms, c2: 2.28 -> 2.07 ms; without the fifth wave 26.6 / 2.27).
+        v4u t0 = ctab[first];                             // chunk c
+        v4u t1 = ctab[min(first + 1, last - 1)];          // chunk c + 1
+        uint32_t p0a = poff[t0.z & kChunkBucketMask], p0b = poff[(t0.z & kChunkBucketMask) + 1];
+        uint4 nl = sliced_load_list(a, p0a, p0b, w.lane);
+        uint32_t p1a = poff[t1.z & kChunkBucketMask], p1b = poff[(t1.z & kChunkBucketMask) + 1];
+        v4u t2 = ctab[min(first + 2, last - 1)];          // chunk c + 2
         for (uint32_t c = first; c < last; ++c) {
             const v4u cur = t0;
             const uint32_t g0 = p0a, g1 = p0b;
             uint32_t v[2 * kRestBases];
-#pragma unroll
-            for (int j = 0; j < 2 * kRestBases; ++j) v[j] = nv[j];
+            sliced_load_sites(a, cur, g0 != g1, w.lane, v);
             // advance the pipeline before the comparison so that its loads overlap it
             t0 = t1;
             p0a = p1a;
             p0b = p1b;
             uint4 tile = nl;
-            sliced_load_sites(a, t0, c + 1 < last && p0a != p0b, w.lane, nv);
             nl = sliced_load_list(a, p0a, c + 1 < last ? p0b : p0a, w.lane);
             t1 = t2;
             p1a = poff[t1.z & kChunkBucketMask];
             p1b = poff[(t1.z & kChunkBucketMask) + 1];
             t2 = ctab[min(c + 3, last - 1)];
             if (g0 == g1) continue;  // no read has this bucket in its neighbourhood
-            const uint32_t slot_tag = (c - first) << 23;  // the tokens of this chunk carry its slot in the grab
+            const uint32_t slot_tag = (c - first) << kTokSlotShift;  // the tokens of this chunk carry its slot in the grab
             if (w.lane == 0) {
                 w.first[c - first] = cur.x;
                 w.info[c - first] = cur.z;
@@ -746,7 +743,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
                         if (b == 0) continue;
                         const uint32_t gid = ry & ((1u << kListDistShift) - 1u);
                         if (word != 0)
-                            w.tok4[ring_slot(lanes_below(b, ring_tail(w)))] = make_uint4(word, gid | lane_tag, rd[u].z | slot_tag, rd[u].w);
+                            w.tok[ring_slot(lanes_below(b, ring_tail(w)))] = make_uint2(word, gid | slot_tag | lane_tag);
                         w.ntok += (uint32_t)__popcll(b);
                     }
                     // a group of four reads adds at most 4 x 64 tokens, a resolve leaves fewer than 64
