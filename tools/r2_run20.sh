@@ -9,5 +9,5 @@ import json
 d=json.load(open('gpurun_out/r2u/b_$1.json'))
 print('$1', round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['kernels_ms'].items() if v})"
 }
-run w5
-run w5b
+run w6c
+run w6cb

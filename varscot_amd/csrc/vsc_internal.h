@@ -46,7 +46,7 @@ constexpr int kSlicedTokCap = (kSlicedResolve + 4) * 64;  // per-wave LDS ring o
 constexpr uint32_t kChunkBucketMask = 0xFFFFu;
 constexpr int kChunkMinusShift = 16;
 constexpr int kChunkEdgeBit = 28;
-constexpr int kSlicedWavesPerSimd = 5;          // resident waves of the sliced kernel per SIMD (registers and LDS allow five)
+constexpr int kSlicedWavesPerSimd = 6;          // resident waves of the sliced kernel per SIMD (registers and LDS allow five)
 constexpr int kSlicedGrab = 8;                  // chunks of 2048 sites per grab of the work counter (sliced kernel)
 
 // counters[] slots of one scan launch

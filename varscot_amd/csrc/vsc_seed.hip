@@ -605,11 +605,15 @@ __device__ __forceinline__ void sliced_resolve(const SeedArgs &a, SeedWave &w)
     }
 }
 
-// entry g0 + lane of a read list [g0, g1) (past the end: padding, y = ~0)
-__device__ __forceinline__ uint4 sliced_load_list(const SeedArgs &a, uint32_t g0, uint32_t g1, uint32_t lane)
+// entry g0 + lane of a read list [g0, g1) (past the end: padding, y = ~0): its first half - rest planes, read |
+// distance << 30; the read's full planes in the second half are for the enumeration's own use
+__device__ __forceinline__ uint2 sliced_load_list(const SeedArgs &a, uint32_t g0, uint32_t g1, uint32_t lane)
 {
-    uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (g0 + lane < g1) e = a.list_rest[g0 + lane];
+    uint2 e = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (g0 + lane < g1) {
+        const uint4 *const at = a.list_rest + (g0 + lane);
+        e = *(const uint2 *)at;
+    }
     return e;
 }
 
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     const SeedArgs a)
 {
     __shared__ uint2 s_tok[kWavesPerGroup][kSlicedTokCap];
-    __shared__ uint4 s_list[kWavesPerGroup][kWave];  // the current tile of 64 read-list entries
+    __shared__ uint2 s_list[kWavesPerGroup][kWave];  // the current tile of 64 read-list entries (first halves)
     __shared__ uint32_t s_parts[kWavesPerGroup][kParts];
     __shared__ uint32_t s_first[kWavesPerGroup][2 * kSlicedGrab];
 
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     w.info = s_first[wave] + kSlicedGrab;
     for (uint32_t q = w.lane; q < (uint32_t)kParts; q += kWave) w.parts[q] = a.reserve;  // no block yet = a used-up one
 
-    uint4 *const lt = s_list[wave];
+    uint2 *const lt = s_list[wave];
     const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
     const const_u32_ptr poff = (const_u32_ptr)(uintptr_t)a.poff;
     const uint32_t m = a.max_mm;
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
         v4u t0 = ctab[first];                             // chunk c
         v4u t1 = ctab[min(first + 1, last - 1)];          // chunk c + 1
         uint32_t p0a = poff[t0.z & kChunkBucketMask], p0b = poff[(t0.z & kChunkBucketMask) + 1];
-        uint4 nl = sliced_load_list(a, p0a, p0b, w.lane);
+        uint2 nl = sliced_load_list(a, p0a, p0b, w.lane);
         uint32_t p1a = poff[t1.z & kChunkBucketMask], p1b = poff[(t1.z & kChunkBucketMask) + 1];
         v4u t2 = ctab[min(first + 2, last - 1)];          // chunk c + 2
         for (uint32_t c = first; c < last; ++c) {
@@ -699,7 +703,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
             t0 = t1;
             p0a = p1a;
             p0b = p1b;
-            uint4 tile = nl;
+            uint2 tile = nl;
             nl = sliced_load_list(a, p0a, c + 1 < last ? p0b : p0a, w.lane);
             t1 = t2;
             p1a = poff[t1.z & kChunkBucketMask];
@@ -729,7 +733,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
                 if (tg + kWave < g1) tile = sliced_load_list(a, tg + kWave, g1, w.lane);
                 const uint32_t in_tile = min(g1 - tg, (uint32_t)kWave);
                 for (uint32_t gi = 0; gi < in_tile; gi += kGuideUnroll) {
-                    uint4 rd[kGuideUnroll];
+                    uint2 rd[kGuideUnroll];
 #pragma unroll
                     for (int u = 0; u < kGuideUnroll; ++u) rd[u] = lt[gi + u];  // same address in every lane
 #pragma unroll
