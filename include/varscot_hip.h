@@ -170,8 +170,9 @@ int vsc_genome_build_index(vsc_ctx *ctx, vsc_genome *genome, const vsc_search_pa
 /* The seed index as a file, for callers that keep `bidir_index`'s contract of an index built once and loaded by
  * every later run (read_mapping/bidir_index.cpp:45-47 writes, bidir_mapping.cpp:96-99 opens): _save writes the
  * resident index of `genome` (VSC_ERR_INVALID if it has none), _load replaces the genome's index with the file's.
- * The file names the library version, the PAM set and a fingerprint of the genome; _load refuses a file that does not
- * match (VSC_ERR_INVALID, vsc_last_error says why) and leaves the genome without an index then.  36 bytes per window:
+ * The file names the library version, the PAM set, a fingerprint of the genome and the sizes of its arrays; _load
+ * refuses a file that does not match or whose length is not what its header announces (VSC_ERR_INVALID,
+ * vsc_last_error says why; the genome's index stays as it was - only a read error half-way leaves it without one).  36 bytes per window:
  * at 3 Gbp the file is 27 GB and rebuilding on the device (0.3 s) is faster than reading it - the tools only use the
  * file when asked to (bidir_index -S). */
 int vsc_genome_index_save(vsc_ctx *ctx, const vsc_genome *genome, const char *path);

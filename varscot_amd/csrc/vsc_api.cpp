@@ -606,6 +606,17 @@ int vsc_genome_index_load(vsc_ctx *ctx, vsc_genome *genome, const char *path)
     const uint64_t S = h.sites;
     if (3 * S >= (1ull << 32) || h.edge_words != (3 * S + 31) / 32 + 1 || h.vert_bytes % (2 * kRestBases * sizeof(uint32_t)) != 0)
         return fail(ctx, VSC_ERR_INVALID, "vsc_genome_index_load: inconsistent header");
+    {
+        // the arrays the header announces must be what the file holds (a cut or padded file is refused before
+        // anything is allocated)
+        const long at = std::ftell(fc.f);
+        const uint64_t want = (uint64_t)sizeof h + 3 * S * sizeof(uint2) + h.edge_words * sizeof(uint32_t) +
+                              (uint64_t)h.chunks * sizeof(uint4) + h.vert_bytes;
+        if (at < 0 || std::fseek(fc.f, 0, SEEK_END) != 0) return fail(ctx, VSC_ERR_INVALID, "vsc_genome_index_load: cannot seek in the file");
+        const long size = std::ftell(fc.f);
+        if (size < 0 || (uint64_t)size != want || std::fseek(fc.f, at, SEEK_SET) != 0)
+            return fail(ctx, VSC_ERR_INVALID, (std::string("vsc_genome_index_load: ") + path + " is truncated or does not match its header").c_str());
+    }
     free_index(genome);
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t r) {
