@@ -376,9 +376,9 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
     }
     // Temporaries: the extracted sites (sx, sl, sp), sort scratch, the bucket-ordered sites as 16-byte records
     // (full planes: what the bit-slicing pass reads) and the (bucket, strand) starts; all released before returning.
-    DeviceBuf sx, sl, sp, k1, k2, i1, i2, tmp, full, starts;
+    DeviceBuf sx, sl, sp, k1, k2, i1, i2, tmp, full, starts, rec16;
     auto release = [&]() {
-        for (DeviceBuf *b : {&sx, &sl, &sp, &k1, &k2, &i1, &i2, &tmp, &full, &starts}) b->release();
+        for (DeviceBuf *b : {&sx, &sl, &sp, &k1, &k2, &i1, &i2, &tmp, &full, &starts, &rec16}) b->release();
     };
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t r) {
@@ -391,6 +391,7 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
     step(sort32_temp_bytes(S, 2 * kSegBases + 1, &temp_bytes));
     step(tmp.ensure(std::max<size_t>(temp_bytes, 16)));
     step(full.ensure(std::max<uint64_t>(3 * S, 1) * sizeof(uint4)));
+    step(rec16.ensure(std::max<uint64_t>(S, 1) * sizeof(uint4)));
     step(starts.ensure((kKeys + 1) * sizeof(uint32_t)));
     const size_t edge_words = (size_t)((3 * S + 31) / 32 + 1);
     step(hipMalloc((void **)&g->d_ix_sites, std::max<uint64_t>(3 * S, 1) * sizeof(uint2)));
@@ -404,14 +405,14 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         a.hit_cap = S;
         step(hipMemsetAsync(ctx->counters.p, 0, sizeof cnt, st));
         step(launch_scan(a, n_groups, true, st));
+        step(launch_seed_pack16((const uint32_t *)sx.p, (const uint32_t *)sl.p, (const uint32_t *)sp.p, S, (uint4 *)rec16.p, st));
     }
     uint4 *const sites16 = (uint4 *)full.p;
     for (int s = 0; s < kSegments && e == hipSuccess; ++s) {
         step(launch_seed_keys((const uint32_t *)sx.p, (const uint32_t *)sl.p, S, s, (uint32_t *)k1.p, (uint32_t *)i1.p, st));
         step(launch_sort32(tmp.p, temp_bytes, (const uint32_t *)k1.p, (uint32_t *)k2.p, (const uint32_t *)i1.p,
                            (uint32_t *)i2.p, S, 2 * kSegBases + 1, st));
-        step(launch_seed_gather16((const uint32_t *)sx.p, (const uint32_t *)sl.p, (const uint32_t *)sp.p,
-                                  (const uint32_t *)i2.p, S, sites16 + (size_t)s * S, st));
+        step(launch_seed_gather16((const uint4 *)rec16.p, (const uint32_t *)i2.p, S, sites16 + (size_t)s * S, st));
         step(launch_lower_bound((const uint32_t *)k2.p, S, 2 * kBucketsPerSeg, 0, (uint32_t)(s * S),
                                 (uint32_t *)starts.p + (size_t)s * 2 * kBucketsPerSeg, st));
     }

@@ -266,8 +266,8 @@ hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_n
                             hipStream_t stream);
 hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted_gids, uint64_t n_pairs, uint32_t *off,
                              uint32_t *poff, const uint2 *guides, uint4 *list_rest, hipStream_t stream);
-hipError_t launch_seed_gather16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, const uint32_t *idx, uint64_t n,
-                                uint4 *out, hipStream_t stream);
+hipError_t launch_seed_pack16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, uint64_t n, uint4 *rec, hipStream_t stream);
+hipError_t launch_seed_gather16(const uint4 *rec, const uint32_t *idx, uint64_t n, uint4 *out, hipStream_t stream);
 hipError_t launch_seed_compact(const uint4 *sites16, uint64_t n_per_table, uint64_t n, uint2 *sites8, uint32_t *edge_bits,
                                hipStream_t stream);
 hipError_t launch_seed_chunk_flags(uint4 *chunk_tab, uint32_t n_chunks, const uint32_t *edge_bits, hipStream_t stream);

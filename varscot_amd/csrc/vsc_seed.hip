@@ -42,15 +42,22 @@ __global__ __launch_bounds__(256) void seed_key_kernel(const uint32_t *x, const 
     idx[i] = (uint32_t)i;
 }
 
-// the sites in bucket order as 16-byte records {hi plane | strand | edge, lo plane, position, 0}: what the hit path
-// reads, one gather per hit (two separate gathers - planes, position - cost the L1 a cache-line transaction per lane each)
-__global__ __launch_bounds__(256) void seed_gather16_kernel(const uint32_t *x, const uint32_t *l, const uint32_t *pos,
-                                                            const uint32_t *idx, uint64_t n, uint4 *out)
+// The extracted sites as 16-byte records {hi plane | strand | edge, lo plane, position, 0}: ordering a table by bucket
+// then is ONE scattered 16-byte read per site (from three separate arrays it was three cache-line transactions per
+// site: 55 ms per table, more than half of the index build).
+__global__ __launch_bounds__(256) void seed_pack16_kernel(const uint32_t *x, const uint32_t *l, const uint32_t *pos, uint64_t n,
+                                                          uint4 *rec)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rec[i] = make_uint4(x[i], l[i], pos[i], 0u);
+}
+
+// the sites in bucket order: out[i] = rec[idx[i]] (what the bit-slicing pass and the compaction read)
+__global__ __launch_bounds__(256) void seed_gather16_kernel(const uint4 *rec, const uint32_t *idx, uint64_t n, uint4 *out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t j = idx[i];
-    out[i] = make_uint4(x[j], l[j], pos[j], 0u);
+    out[i] = rec[idx[i]];
 }
 
 // out[b] = base + (first index i with sorted_keys[i] >= b), b = 0 .. n_buckets (inclusive)
@@ -76,11 +83,17 @@ hipError_t launch_seed_keys(const uint32_t *x, const uint32_t *l, uint64_t n, in
     return hipGetLastError();
 }
 
-hipError_t launch_seed_gather16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, const uint32_t *idx, uint64_t n,
-                                uint4 *out, hipStream_t stream)
+hipError_t launch_seed_pack16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, uint64_t n, uint4 *rec, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(seed_gather16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, l, pos, idx, n, out);
+    hipLaunchKernelGGL(seed_pack16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, l, pos, n, rec);
+    return hipGetLastError();
+}
+
+hipError_t launch_seed_gather16(const uint4 *rec, const uint32_t *idx, uint64_t n, uint4 *out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(seed_gather16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, idx, n, out);
     return hipGetLastError();
 }
 
