@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--algorithm", default="auto", choices=["auto", "scan", "seed"],
                     help="scan = stream the packed planes; seed = resident pigeonhole site tables; auto = seed")
     ap.add_argument("--snps", type=int, default=5_000_000, help="records of the synthetic VCF (workload c4)")
-    ap.add_argument("--batch", type=int, default=5_000, help="reads per search call for the streamed workload c5")
+    ap.add_argument("--batch", type=int, default=10_000, help="reads per search call for the streamed workload c5")
     ap.add_argument("--sub-batches", type=int, default=None,
                     help="multi-rank runs with --exchange reads: cut the reads into this many pieces and overlap the "
                          "exchange of one piece with the search of the next (default: 4 at 2 ranks, 2 at 3-4, 1 otherwise)")
