@@ -385,18 +385,16 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         if (e == hipSuccess) e = r;
     };
     constexpr uint32_t kKeys = 2 * kBuckets;  // (bucket, strand) pairs: inside a bucket '+' sites precede '-' sites
+    // Allocations follow the phases, so that the peak stays at 84 bytes per site (all temporaries at once: 116):
+    //   extract   sx, sl, sp (12 B/site) -> rec16 (16)                      then sx, sl, sp go
+    //   order     rec16 (16) + keys / indices (16) -> full (48)             then rec16, keys, indices go
+    //   compact   full (48) -> the resident 8-byte records (24) + edge bits
+    //   slice     full (48) + records (24) -> bit-sliced blocks (12)        then full goes
     const size_t n4 = std::max<uint64_t>(S, 1) * sizeof(uint32_t);
-    for (DeviceBuf *b : {&sx, &sl, &sp, &k1, &k2, &i1, &i2}) step(b->ensure(n4));
-    size_t temp_bytes = 0;
-    step(sort32_temp_bytes(S, 2 * kSegBases + 1, &temp_bytes));
-    step(tmp.ensure(std::max<size_t>(temp_bytes, 16)));
-    step(full.ensure(std::max<uint64_t>(3 * S, 1) * sizeof(uint4)));
+    for (DeviceBuf *b : {&sx, &sl, &sp}) step(b->ensure(n4));
     step(rec16.ensure(std::max<uint64_t>(S, 1) * sizeof(uint4)));
     step(starts.ensure((kKeys + 1) * sizeof(uint32_t)));
     const size_t edge_words = (size_t)((3 * S + 31) / 32 + 1);
-    step(hipMalloc((void **)&g->d_ix_sites, std::max<uint64_t>(3 * S, 1) * sizeof(uint2)));
-    step(hipMalloc((void **)&g->d_ix_edge, edge_words * sizeof(uint32_t)));
-    if (e == hipSuccess) step(hipMemsetAsync(g->d_ix_edge, 0, edge_words * sizeof(uint32_t), st));
     if (e == hipSuccess && S > 0) {
         // pass 2: emit
         a.site_x = (uint32_t *)sx.p;
@@ -406,16 +404,28 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         step(hipMemsetAsync(ctx->counters.p, 0, sizeof cnt, st));
         step(launch_scan(a, n_groups, true, st));
         step(launch_seed_pack16((const uint32_t *)sx.p, (const uint32_t *)sl.p, (const uint32_t *)sp.p, S, (uint4 *)rec16.p, st));
+        step(hipStreamSynchronize(st));
     }
+    for (DeviceBuf *b : {&sx, &sl, &sp}) b->release();
+    for (DeviceBuf *b : {&k1, &k2, &i1, &i2}) step(b->ensure(n4));
+    size_t temp_bytes = 0;
+    step(sort32_temp_bytes(S, 2 * kSegBases + 1, &temp_bytes));
+    step(tmp.ensure(std::max<size_t>(temp_bytes, 16)));
+    step(full.ensure(std::max<uint64_t>(3 * S, 1) * sizeof(uint4)));
     uint4 *const sites16 = (uint4 *)full.p;
     for (int s = 0; s < kSegments && e == hipSuccess; ++s) {
-        step(launch_seed_keys((const uint32_t *)sx.p, (const uint32_t *)sl.p, S, s, (uint32_t *)k1.p, (uint32_t *)i1.p, st));
+        step(launch_seed_keys((const uint4 *)rec16.p, S, s, (uint32_t *)k1.p, (uint32_t *)i1.p, st));
         step(launch_sort32(tmp.p, temp_bytes, (const uint32_t *)k1.p, (uint32_t *)k2.p, (const uint32_t *)i1.p,
                            (uint32_t *)i2.p, S, 2 * kSegBases + 1, st));
         step(launch_seed_gather16((const uint4 *)rec16.p, (const uint32_t *)i2.p, S, sites16 + (size_t)s * S, st));
         step(launch_lower_bound((const uint32_t *)k2.p, S, 2 * kBucketsPerSeg, 0, (uint32_t)(s * S),
                                 (uint32_t *)starts.p + (size_t)s * 2 * kBucketsPerSeg, st));
     }
+    if (e == hipSuccess) step(hipStreamSynchronize(st));
+    for (DeviceBuf *b : {&k1, &k2, &i1, &i2, &tmp, &rec16}) b->release();
+    step(hipMalloc((void **)&g->d_ix_sites, std::max<uint64_t>(3 * S, 1) * sizeof(uint2)));
+    step(hipMalloc((void **)&g->d_ix_edge, edge_words * sizeof(uint32_t)));
+    if (e == hipSuccess) step(hipMemsetAsync(g->d_ix_edge, 0, edge_words * sizeof(uint32_t), st));
     std::vector<uint32_t> bs(kKeys + 1, 0);  // bs[2 b + strand] = first site of bucket b on that strand
     if (e == hipSuccess) {
         step(launch_seed_compact(sites16, std::max<uint64_t>(S, 1), 3 * S, g->d_ix_sites, g->d_ix_edge, st));

@@ -258,8 +258,7 @@ hipError_t sort32_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
 hipError_t launch_sort32(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
                          const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream);
 // vsc_seed.hip
-hipError_t launch_seed_keys(const uint32_t *x, const uint32_t *l, uint64_t n, int seg, uint32_t *keys, uint32_t *idx,
-                            hipStream_t stream);
+hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint32_t *keys, uint32_t *idx, hipStream_t stream);
 hipError_t launch_lower_bound(const uint32_t *sorted_keys, uint64_t n, uint32_t n_buckets, uint32_t key_offset,
                               uint32_t base, uint32_t *out, hipStream_t stream);
 hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *keys, uint32_t *gids,

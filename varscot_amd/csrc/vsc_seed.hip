@@ -31,14 +31,14 @@ __device__ __forceinline__ uint32_t segment_key(uint32_t x, uint32_t l, int s)
 // ------------------------------------------------------------------------------------------------
 // index build
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void seed_key_kernel(const uint32_t *x, const uint32_t *l, uint64_t n, int seg,
-                                                       uint32_t *keys, uint32_t *idx)
+__global__ __launch_bounds__(256) void seed_key_kernel(const uint4 *rec, uint64_t n, int seg, uint32_t *keys, uint32_t *idx)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint4 r = rec[i];  // {hi plane | strand | edge, lo plane, position, 0}
     // bucket, then strand: inside a bucket the '+' sites precede the '-' sites, so that a chunk needs one number
     // (where its '-' sites begin) instead of a strand bit per site record
-    keys[i] = (segment_key(x[i], l[i], seg) << 1) | ((x[i] >> kSiteStrandBit) & 1u);
+    keys[i] = (segment_key(r.x, r.y, seg) << 1) | ((r.x >> kSiteStrandBit) & 1u);
     idx[i] = (uint32_t)i;
 }
 
@@ -75,11 +75,10 @@ __global__ __launch_bounds__(256) void lower_bound_kernel(const uint32_t *sorted
     out[b] = base + (uint32_t)lo;
 }
 
-hipError_t launch_seed_keys(const uint32_t *x, const uint32_t *l, uint64_t n, int seg, uint32_t *keys, uint32_t *idx,
-                            hipStream_t stream)
+hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint32_t *keys, uint32_t *idx, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(seed_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, l, n, seg, keys, idx);
+    hipLaunchKernelGGL(seed_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, n, seg, keys, idx);
     return hipGetLastError();
 }
 
