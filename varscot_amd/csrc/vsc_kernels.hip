@@ -693,7 +693,15 @@ __global__ __launch_bounds__(256) void score_packed_kernel(const ScoreArgs a, ui
         const uint32_t e = k * 64 + lane;  // 16-byte piece e of the wave's 4 KB
         const uint32_t row = wave_row0 + (e >> 2), q = e & 3u;
         const uint64_t at = s_index[row];
-        if (at != ~0ull) packed[at * 4 + q] = s_rows[row][q ^ (row & 3u)];
+        if (at != ~0ull) {  // nontemporal: the rows are not read again here, the planes' lines should stay cached (-2 %)
+            const uint4 rv = s_rows[row][q ^ (row & 3u)];
+            v4u hv;
+            hv.x = rv.x;
+            hv.y = rv.y;
+            hv.z = rv.z;
+            hv.w = rv.w;
+            __builtin_nontemporal_store(hv, (v4u *)packed + (at * 4 + q));
+        }
     }
 }
 

@@ -551,7 +551,13 @@ __device__ __forceinline__ void finalize_bin(const FinArgs &a, const uint32_t wh
             h.y = c;                                                                              // .contig
             h.z = pos - start;                                                                    // .pos
             h.w = ((uint32_t)(x[u] >> kRecStrandShift) & 1u) << 31 | (uint32_t)__popc(mask) << 23 | mask;  // .info
-            ((uint4 *)a.out)[dst + s[u] + smaller[u]] = h;
+            // (written once, read by a later kernel at the earliest: past the caches - finalize 8.30 -> 8.15 ms)
+            v4u hv;
+            hv.x = h.x;
+            hv.y = h.y;
+            hv.z = h.z;
+            hv.w = h.w;
+            __builtin_nontemporal_store(hv, (v4u *)a.out + (dst + s[u] + smaller[u]));
         }
     }
 }
