@@ -16,6 +16,15 @@ Outputs (data only - inputs and expected outputs, no reference source text):
                                   workflow/evalFunctions.R:7-126 via classificationModel.R:21-23)
       names[442]                 column names as stored in the RData
       activity[6960] float64     the ontargetActivity column (col 442)
+      nm[6960] uint8, cls[6960] uint8, chrom[6960], start[6960] int64, target[6960]
+                                  the NM, Class, Chr, Start and Targetsite columns of datasetsSampling.
+                                  On the 3480 Class-0 rows NM is the `NM:i` tag of VARSCOT's OWN SAM
+                                  output (workflow/processDataForModel.R:257-258 reads
+                                  guideseq-data/bidir_guideseq.sam, :284 takes field 3 of the tag,
+                                  :378-394 samples the records): (guide, site, NM) triples the
+                                  reference's mapper emitted at <= 8 mismatches - the one reference-held
+                                  output of the search.  Class-1 rows are GUIDE-seq sites (NM from the
+                                  GUIDE-seq tables), not mapper output.
   siteseq_pairs.tsv
       4443 (on, off, NM, strand) pairs incl. non-GG PAMs, NM up to 14
       (workflow/data-objects/offtargetBiochemicalData.RData) - inputs only.
@@ -46,6 +55,7 @@ def main():
     ds = load_rdata(f"{REF}/data-objects/datasetsSampling.RData")["datasetsSampling"]
     fm = load_rdata(f"{REF}/data-objects/featureMatrix.RData")["featureMatrix"]
     on, off, feat, act = [], [], [], []
+    nm, cls, chrom, start, target = [], [], [], [], []
     names = None
     for d, f in zip(ds["val"], fm["val"]):
         d = data_frame(d)
@@ -58,6 +68,11 @@ def main():
         n = len(d["Target_Sequence"])
         on += d["Target_Sequence"]
         off += d["Offtarget_Sequence"]
+        nm += [int(v) for v in d["NM"]]
+        cls += [int(v) for v in d["Class"]]
+        chrom += d["Chr"]
+        start += [int(v) for v in d["Start"]]
+        target += d["Targetsite"]
         m = np.zeros((n, 442), dtype=np.uint8)
         for j, c in enumerate(names):
             m[:, j] = np.asarray([int(float(v)) for v in f[c]], dtype=np.uint8)
@@ -66,7 +81,9 @@ def main():
     feat = np.concatenate(feat)
     assert feat.shape == (6960, 442), feat.shape
     np.savez_compressed(f"{HERE}/features_golden.npz", on=np.array(on), off=np.array(off), feat=feat,
-                        names=np.array(names), activity=np.array(act))
+                        names=np.array(names), activity=np.array(act), nm=np.array(nm, dtype=np.uint8),
+                        cls=np.array(cls, dtype=np.uint8), chrom=np.array(chrom), start=np.array(start, dtype=np.int64),
+                        target=np.array(target))
     print("features_golden.npz", feat.shape)
 
     bd = data_frame(load_rdata(f"{REF}/data-objects/offtargetBiochemicalData.RData")["offtargetBiochemicalData"])

@@ -131,3 +131,28 @@ def repeat_rich_genome(seed, n_bases, guides, n_contigs=3):
         seq[at:at + int(rng.integers(1, 3000))] = ord("N")
     cuts = sorted(int(x) for x in rng.choice(np.arange(1000, n_bases - 1000), size=n_contigs - 1, replace=False))
     return [p.tobytes().decode() for p in np.split(seq, cuts)]
+
+
+def reference_sam_triples(golden_dir):
+    """The (guide, site, NM) triples of VARSCOT's own SAM output that the reference still holds: the Class-0 rows
+    of workflow/data-objects/datasetsSampling.RData (workflow/processDataForModel.R:257-258 reads
+    guideseq-data/bidir_guideseq.sam, :284 extracts the `NM:i` tag, :378-394 samples the records; the SAM itself
+    is an absent LFS blob).  Returns (guides, rows) with rows = unique (guide index, site in guide orientation, NM)."""
+    import os
+    g = np.load(os.path.join(golden_dir, "features_golden.npz"))
+    sel = g["cls"] == 0
+    guides = sorted(set(str(s) for s in g["on"][sel]))
+    gidx = {s: i for i, s in enumerate(guides)}
+    rows = sorted(set((gidx[str(a)], str(o), int(n)) for a, o, n in zip(g["on"][sel], g["off"][sel], g["nm"][sel])))
+    return guides, rows
+
+
+def plant_reference_sites(rows):
+    """One contig per triple: the site on `+` (even rows) or reverse-complemented = a `-` hit (odd rows), in T / A
+    flanks that add no PAM of their own next to it.  Returns (contigs, strand per row); the window starts at 4."""
+    contigs, strands = [], []
+    for i, (_, site, _) in enumerate(rows):
+        s = i & 1
+        contigs.append("TTTT" + (revcomp(site) if s else site) + ("AAAA" if s else "TTTT"))
+        strands.append(s)
+    return contigs, strands

@@ -224,11 +224,45 @@ def test_features_match_reference_golden_on_gpu(ctx, golden_dir):
             continue
         i = found[(gidx[a], row)]
         assert np.array_equal(f[i], feat[row]), (a, o)
+        assert (int(rec["info"][i]) >> 23) & 31 == int(g["nm"][row])  # Class 0: the reference mapper's own NM tag
         checked += 1
     assert checked > 6000
     hits.close()
     gen.close()
     assert step == len(contigs[0])
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_search_reports_the_reference_mappers_hits_with_its_nm(ctx, golden_dir, algo):
+    """Rows R2/R3 against the one search output the reference still holds: the (guide, site, NM) triples out of
+    VARSCOT's own SAM file (datasetsSampling.RData, Class 0: workflow/processDataForModel.R:257-258,284,378-394).
+    Every site the reference's mapper reported must be found on the strand it is planted on with the reference's
+    `NM:i` value (= popcount of the record's mask), exactly from the budget m = NM on, by both search kernels."""
+    from helpers import plant_reference_sites, reference_sam_triples
+    guides, rows = reference_sam_triples(golden_dir)
+    assert len(rows) == 2434
+    contigs, strands = plant_reference_sites(rows)
+    gen = ctx.load_genome(va.PackedGenome.from_sequences(contigs))
+    for m in (8, 6, 5, 3, 2):
+        hits = gen.search(guides, m, algorithm=algo)
+        rec = hits.to_numpy()
+        got = {(g, c): (s, nm, mask) for g, s, c, p, nm, mask in hits_as_tuples(rec) if p == 4}
+        n = 0
+        for c, (gi, site, nm) in enumerate(rows):
+            if nm <= m:
+                s, nm_gpu, mask = got[(gi, c)]
+                assert (s, nm_gpu) == (strands[c], nm), (guides[gi], site, nm, m)
+                assert bin(mask).count("1") == nm
+                # the mask is in forward-genome window coordinates (filter_output_bam.h:330-349)
+                w = contigs[c][4:27]
+                r = revcomp(guides[gi]) if s else guides[gi]
+                assert mask == sum(1 << i for i in range(23) if w[i] != r[i])
+                n += 1
+            else:
+                assert (gi, c) not in got, (guides[gi], site, nm, m)
+        assert n == sum(1 for r in rows if r[2] <= m)
+        hits.close()
+    gen.close()
 
 
 # ------------------------------------------------------------------------------------ multi-rank

@@ -238,3 +238,46 @@ def test_sam_text(oracle):
         "guide1\t0\tchrA\t11\t255\t23M\t*\t0\t0\t%s\t%s\tNM:i:1\tMD:Z:22A0" % (g, "I" * 23),
         "guide1\t16\tchrB\t9\t255\t23M\t*\t0\t0\t%s\t%s\tNM:i:0\tMD:Z:23" % (g, "I" * 23),
     ]
+
+
+# ---------------------------------------------------------------- the reference mapper's own NM tags (rows R2/R3)
+@pytest.mark.parametrize("mode", ["predicate", "reference_flow", "fastport", "pigeon"])
+def test_search_reports_the_reference_mappers_hits_with_its_nm(oracle, golden_dir, mode):
+    """Pins rows R2/R3 with the one search output the reference still holds: 2 434 distinct (guide, site sequence, NM)
+    triples out of VARSCOT's own SAM file (datasetsSampling.RData, Class 0 - helpers.reference_sam_triples).
+    Every site the reference's mapper reported at <= 8 mismatches must be reported by every formulation of the
+    oracle, on the strand it is planted on, with the reference's NM (mismatches over all 23 positions,
+    bidir_mapping.cpp:79-86,121), and must appear exactly when the budget reaches that NM (acceptance `<= m`)."""
+    from helpers import plant_reference_sites, reference_sam_triples
+    guides, rows = reference_sam_triples(golden_dir)
+    assert len(rows) == 2434 and len(guides) == 9
+    contigs, strands = plant_reference_sites(rows)
+    pig = oracle.PigeonIndex(contigs) if mode == "pigeon" else None
+    for m in (8, 7, 6, 5, 4, 3, 2, 1):
+        if mode == "predicate":
+            h = oracle.search(contigs, guides, m, mode=oracle.MODE_PREDICATE)
+        elif mode == "reference_flow":
+            h = oracle.search(contigs, guides, m, mode=oracle.MODE_REFERENCE_FLOW)
+        elif mode == "fastport":
+            h = oracle.search_fast(contigs, guides, m)
+        else:
+            h, _ = pig.search(guides, m)
+        got = {(g, c): (s, nm) for g, s, c, p, nm, _ in hits_as_tuples(h) if p == 4}
+        for c, (gi, site, nm) in enumerate(rows):
+            if nm <= m:
+                assert got.get((gi, c)) == (strands[c], nm), (guides[gi], site, nm, m)
+            else:
+                assert (gi, c) not in got, (guides[gi], site, nm, m)
+    if pig:
+        pig.close()
+
+
+def test_reference_sam_triples_are_what_the_generator_says(golden_dir):
+    """The fixture itself: NM of every stored row = Hamming distance over all 23 positions (the reference counts
+    the PAM positions too), all Class-0 sites carry an NGG PAM, 2 <= NM <= 8 (the mapper ran with -M 8)."""
+    g = np.load(os.path.join(golden_dir, "features_golden.npz"))
+    hd = np.array([sum(x != y for x, y in zip(str(a), str(o))) for a, o in zip(g["on"], g["off"])])
+    assert np.array_equal(hd, g["nm"])
+    sel = g["cls"] == 0
+    assert sel.sum() == 3480 and all(str(o)[21:] == "GG" for o in g["off"][sel])
+    assert g["nm"][sel].min() == 2 and g["nm"][sel].max() == 8
