@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VSC_ABI_VERSION 2
+#define VSC_ABI_VERSION 3
 
 #define VSC_OK 0
 #define VSC_ERR_INVALID (-22)  /* EINVAL: bad argument (e.g. mismatches outside 0..8)          */
@@ -283,7 +283,7 @@ int vsc_score_pairs(vsc_ctx *ctx, const uint64_t *on_targets, const uint64_t *of
  * per-thread output buffers (read_mapping/bidir_mapping.cpp:285-295,307-308): the parallel axis is the genome.
  * RCCL is bound at run time (dlopen) and used when n > 1 distinct devices are given; device ids may repeat
  * (several contexts on one GPU: tests and rehearsals on a one-GPU box) - the exchange then is device copies.
- * Environment: VSC_MULTI_RCCL=0 forces copies, =1 insists on RCCL (also for n = 1: a one-rank communicator).
+ * vsc_multi_last_error after vsc_multi_create says why copies are in use when RCCL could not be set up.
  */
 typedef struct vsc_multi vsc_multi;
 typedef struct vsc_multi_genome vsc_multi_genome;

@@ -61,15 +61,13 @@ def one(ctx, seed):
     for algo in ("scan", "seed"):
         world = int(rng.integers(1, 4))
         # sort knobs: smaller LDS capacity / fewer bits per level force partition levels and the oversize path
-        for k, choices in (("VSC_SORT_CAP", [None, None, "64", "1000"]), ("VSC_SORT_MAX_BITS", [None, None, "2", "5"]),
-                           ("VSC_SEED_RESERVE", [None, "64", "1024"])):
-            v = choices[int(rng.integers(0, len(choices)))]
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        hooks = {}
+        for k, choices in (("sort_cap", [0, 0, 64, 1000]), ("sort_max_bits", [0, 0, 2, 5]), ("seed_reserve", [0, 64, 1024])):
+            hooks[k] = choices[int(rng.integers(0, len(choices)))]
+        ctx.set_debug(**hooks)
         if world > 1 and rng.integers(0, 2):  # the shards behind the C ABI: contexts on this device, gather, merge
             m = va.MultiContext([0] * world)
+            m.set_debug(**hooks)
             g = m.load_genome(packed)
             h = g.search(guides, max_mm, extra, algorithm=algo)
             got = h.to_numpy().copy()
@@ -77,9 +75,9 @@ def one(ctx, seed):
             g.close()
             m.close()
             if hits_as_tuples(got) != hits_as_tuples(want):
-                return "seed %d: %s multi x%d differs (m=%d, %d reads, contigs %s, extra %s, env %s): %d vs %d records" % (
+                return "seed %d: %s multi x%d differs (m=%d, %d reads, contigs %s, extra %s, hooks %s): %d vs %d records" % (
                     seed, algo, world, max_mm, len(guides), lens, extra,
-                    {k: os.environ.get(k) for k in ("VSC_SORT_CAP", "VSC_SORT_MAX_BITS", "VSC_SEED_RESERVE")}, len(got), len(want))
+                    hooks, len(got), len(want))
             n_rec = len(got)
             continue
         parts = []
@@ -97,9 +95,9 @@ def one(ctx, seed):
             key = (got["guide"].astype(np.int64) << 1) | (got["info"] >> 31)
             got = got[np.argsort(key, kind="stable")]
         if hits_as_tuples(got) != hits_as_tuples(want):
-            return "seed %d: %s x%d differs (m=%d, %d reads, contigs %s, extra %s, env %s): %d vs %d records" % (
+            return "seed %d: %s x%d differs (m=%d, %d reads, contigs %s, extra %s, hooks %s): %d vs %d records" % (
                 seed, algo, world, max_mm, len(guides), lens, extra,
-                {k: os.environ.get(k) for k in ("VSC_SORT_CAP", "VSC_SORT_MAX_BITS", "VSC_SEED_RESERVE")}, len(got), len(want))
+                hooks, len(got), len(want))
         n_rec = len(got)
     return n_rec
 

@@ -14,17 +14,33 @@ from helpers import make_genome, random_guides, random_seq
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_header_symbols_are_exported_and_bound():
-    text = open(os.path.join(ROOT, "include", "varscot_hip.h")).read()
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    declared = set(re.findall(r"\b(vsc_[a-z0-9_]+)\s*\(", text))
-    bound = {name for name, _, _ in _lib.SYMBOLS}
-    assert declared == bound
+    return text, set(re.findall(r"\b(vsc_[a-z0-9_]+)\s*\(", text))
+
+
+def test_header_symbols_are_exported_and_bound():
+    """Every include/*.h: what it declares is exported by the library and bound by the Python mirror."""
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["varscot_hip.h", "varscot_hip_debug.h"]
+    text, declared = _declared("varscot_hip.h")
+    assert declared == {name for name, _, _ in _lib.SYMBOLS}
+    _, declared_dbg = _declared("varscot_hip_debug.h")
+    assert declared_dbg == {name for name, _, _ in _lib.DEBUG_SYMBOLS}
     L = C.CDLL(_lib.LIB_PATH)
-    for name in declared:
+    for name in declared | declared_dbg:
         assert hasattr(L, name), name
     version = int(re.search(r"#define\s+VSC_ABI_VERSION\s+(\d+)", text).group(1))
-    assert va.lib().vsc_abi_version() == version == 2
+    assert va.lib().vsc_abi_version() == version == 3
+
+
+def test_the_library_reads_no_environment_variable():
+    """Test hooks are explicit calls (varscot_hip_debug.h): a stray VSC_* variable in a user's environment must
+    not steer kernels or buffer sizes."""
+    csrc = os.path.join(ROOT, "varscot_amd", "csrc")
+    for name in os.listdir(csrc):
+        if name.endswith((".cpp", ".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, name)).read(), name
 
 
 def test_graft_entry_build_check_follows_the_header():

@@ -511,18 +511,22 @@ def test_shard_merge_kernels(ctx, oracle, world):
     assert got.tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("cap,max_bits", [(None, None), ("4096", "11"), ("256", "3"), ("16", "1")])
+@pytest.fixture
+def hooks(ctx):
+    """ctx.set_debug(...) for one test (include/varscot_hip_debug.h); the defaults come back afterwards."""
+    yield ctx.set_debug
+    ctx.set_debug()
+
+
+@pytest.mark.parametrize("cap,max_bits", [(None, None), (4096, 11), (256, 3), (16, 1)])
 @pytest.mark.parametrize("algo", ALGOS)
-def test_sort_levels_on_dense_position_runs(ctx, oracle, algo, cap, max_bits, monkeypatch):
+def test_sort_levels_on_dense_position_runs(ctx, oracle, algo, cap, max_bits, hooks):
     """The bin sort (vsc_sort.hip): homopolymer runs give one read a hit at EVERY position - dense sub-bins that
-    the finalize kernel has to rank, bins far larger than their neighbours.  VSC_SORT_CAP / VSC_SORT_MAX_BITS
+    the finalize kernel has to rank, bins far larger than their neighbours.  The hooks sort_cap / sort_max_bits
     shrink the LDS capacity and the bits per partition level so that the partition levels and the oversize
     path (bins handed to a further level, up to dozens of levels) run on a few thousand records."""
-    for k, v in (("VSC_SORT_CAP", cap), ("VSC_SORT_MAX_BITS", max_bits)):
-        if v is None:
-            monkeypatch.delenv(k, raising=False)
-        else:
-            monkeypatch.setenv(k, v)
+    if cap:
+        hooks(sort_cap=cap, sort_max_bits=max_bits)
     rng = np.random.default_rng(77)
     guides = ["G" * 23, "C" * 23, "G" * 11 + "A" + "G" * 11] + random_guides(rng, 5)
     contigs = ["G" * 1500 + random_seq(rng, 300) + "C" * 900, random_seq(rng, 2000), "G" * 700]
@@ -549,13 +553,13 @@ def test_baseline_config_c1(ctx, oracle, algo):
     assert hits_as_tuples(got) == hits_as_tuples(want)
 
 
-@pytest.mark.parametrize("cap", [None, "512"])
-def test_hit_buffer_growth_and_sort_partition(ctx, oracle, cap, monkeypatch):
+@pytest.mark.parametrize("cap", [None, 512])
+def test_hit_buffer_growth_and_sort_partition(ctx, oracle, cap, hooks):
     """Thousands of hits per read on a small genome: the hit buffer sized from the uniform-genome model has to
     grow (second search launch), the second search reuses the grown buffers; with a reduced bin capacity the
     region goes through the partition level.  A read count that is not a multiple of four."""
     if cap:
-        monkeypatch.setenv("VSC_SORT_CAP", cap)
+        hooks(sort_cap=cap)
     rng = np.random.default_rng(909)
     guides = random_guides(rng, 37)
     pieces = []
@@ -642,7 +646,7 @@ def test_streamed_search_equals_one_search(ctx, oracle):
     assert hits_as_tuples(got) == hits_as_tuples(ref)
 
 
-def test_scoring_in_several_passes(ctx, oracle, monkeypatch):
+def test_scoring_in_several_passes(ctx, oracle, hooks):
     """vsc_score_hits / vsc_score_hits_packed score a result that does not fit their scratch buffers in several
     passes (a c3-sized result is 104 GB of packed rows): forced here with passes of 50 rows; scores, flags,
     dense and packed rows equal the one-pass ones and the oracle's."""
@@ -655,16 +659,15 @@ def test_scoring_in_several_passes(ctx, oracle, monkeypatch):
     assert len(rec) > 300
     one = h.scores(mit=True, features=True)
     one_rows, one_mit = h.packed_features(mit=True)
-    monkeypatch.setenv("VSC_SCORE_CHUNK", "50")
+    hooks(score_chunk=50)
     many = h.scores(mit=True, features=True)
     many_rows, many_mit = h.packed_features(mit=True)
     sub = h.scores(first=100, count=170, mit=True, features=True)
     # the packed rows again in slice-major processing order (what large results on large genomes get): slices of
     # 2^12 positions here, alone and together with the passes of 50 rows
-    monkeypatch.setenv("VSC_SCORE_SLICES", "1")
-    monkeypatch.setenv("VSC_SCORE_SLICE_SHIFT", "12")
+    hooks(score_chunk=50, score_slices=1, score_slice_shift=12)
     sliced_rows, sliced_mit = h.packed_features(mit=True)
-    monkeypatch.delenv("VSC_SCORE_CHUNK")
+    hooks(score_slices=1, score_slice_shift=12)
     sliced_rows2, sliced_mit2 = h.packed_features(first=37, count=len(rec) - 60, mit=True)
     assert np.array_equal(sliced_rows, one_rows) and np.array_equal(sliced_mit, one_mit)
     assert np.array_equal(sliced_rows2, one_rows[37:len(rec) - 23]) and np.array_equal(sliced_mit2, one_mit[37:len(rec) - 23])
@@ -726,16 +729,15 @@ def test_multi_device_search_behind_the_abi(oracle, devices, algo):
     assert got2.tobytes() == oracle.search_fast(contigs, guides[:10], 3).tobytes()
 
 
-def test_multi_device_exchange_over_rccl_with_one_rank(oracle, monkeypatch):
-    """The RCCL leg of vsc_multi_search on the one GPU of this box: VSC_MULTI_RCCL=1 sets up a one-rank
+def test_multi_device_exchange_over_rccl_with_one_rank(oracle):
+    """The RCCL leg of vsc_multi_search on the one GPU of this box: the hook rccl=1 sets up a one-rank
     communicator (ncclCommInitAll), the hit counts go through ncclAllGather and the records through a grouped
     ncclSend / ncclRecv to the rank itself; the result is the single-context one."""
-    monkeypatch.setenv("VSC_MULTI_RCCL", "1")
     rng = np.random.default_rng(808)
     guides = random_guides(rng, 40)
     contigs = make_genome(808, [50000, 20000], guides, 5, n_plant=300, n_runs=2)
     want = oracle.search_fast(contigs, guides, 5)
-    m = va.MultiContext([0])
+    m = va.MultiContext([0], rccl=True)
     try:
         assert m.uses_rccl
         g = m.load_genome(va.PackedGenome.from_sequences(contigs))
@@ -747,6 +749,31 @@ def test_multi_device_exchange_over_rccl_with_one_rank(oracle, monkeypatch):
     finally:
         m.close()
     assert len(want) > 200 and got.tobytes() == want.tobytes()
+
+
+def test_multi_device_falls_back_to_copies_when_rccl_cannot_be_loaded(oracle):
+    """librccl missing from the loader path (here: a library name that does not exist): vsc_multi_create used to
+    build its error text from a second dlerror() call - NULL - and crashed; now the context reports why and the
+    exchange runs as device copies.  Insisting on RCCL (rccl=1) is an error instead."""
+    with pytest.raises(va.VarscotError):
+        va.MultiContext([0], rccl=True, rccl_library="libdoes-not-exist-rccl.so")
+    # (the load is only attempted for distinct devices: on this one-GPU box rccl="try" asks for it with one device)
+    rng = np.random.default_rng(818)
+    guides = random_guides(rng, 12)
+    contigs = make_genome(818, [40000, 20000], guides, 4, n_plant=200, n_runs=2)
+    want = oracle.search_fast(contigs, guides, 4)
+    m = va.MultiContext([0], rccl="try", rccl_library="libdoes-not-exist-rccl.so")
+    try:
+        assert not m.uses_rccl and "RCCL not found" in m.last_error()
+        g = m.load_genome(va.PackedGenome.from_sequences(contigs))
+        h = g.search(guides, 4, algorithm="seed")
+        got = h.to_numpy().copy()
+        assert m.timing()["used_rccl"] == 0
+        h.close()
+        g.close()
+    finally:
+        m.close()
+    assert len(want) > 100 and got.tobytes() == want.tobytes()
 
 
 @pytest.mark.parametrize("n_bases,max_mm", [(8_000_000, 8), (50_000_000, 6)])
@@ -815,6 +842,34 @@ def test_seed_index_file_round_trip(tmp_path):
     with pytest.raises(va.VarscotError, match="truncated"):
         g2.load_index(str(tmp_path / "cut.vsi"))
     h = g2.search(guides, 6, algorithm="seed")  # left without an index: builds again
+    assert h.to_numpy().tobytes() == want.tobytes()
+    h.close()
+    # Same length, same contig layout, ONE base changed far behind the start of the planes / one base masked as N:
+    # the fingerprint covers every word of all three planes, so the stale index is refused (it used to probe the
+    # first 2 Mbp of hi / lo only - a patched or hard-masked assembly silently got the old genome's hits).
+    for change in ("base", "mask"):
+        c = list(contigs)
+        at = len(c[1]) - 777
+        c[1] = c[1][:at] + ("N" if change == "mask" else "ACGT"[("ACGT".index(c[1][at]) + 1) % 4]) + c[1][at + 1:]
+        g4 = ctx.load_genome(va.PackedGenome.from_sequences(c))
+        with pytest.raises(va.VarscotError, match="another genome"):
+            g4.load_index(path)
+        g4.close()
+    # a file of the right length whose chunk table is damaged must not turn into out-of-bounds device reads
+    blob = bytearray(open(path, "rb").read())
+    S = int.from_bytes(blob[24:32], "little")
+    edge_words = int.from_bytes(blob[48:56], "little")
+    chunks = int.from_bytes(blob[64:68], "little")
+    tab = 80 + 3 * S * 8 + edge_words * 4
+    assert chunks > 3
+    for field, value in ((0, 3 * S + 5), (1, 4000), (3, 0x7FFFFFF0)):  # first site, site count, first block of chunk 2
+        bad = bytearray(blob)
+        bad[tab + 2 * 16 + 4 * field:tab + 2 * 16 + 4 * field + 4] = int(value).to_bytes(4, "little")
+        open(str(tmp_path / "bad.vsi"), "wb").write(bad)
+        with pytest.raises(va.VarscotError, match="damaged"):
+            g2.load_index(str(tmp_path / "bad.vsi"))
+    g2.load_index(path)  # the intact file still loads
+    h = g2.search(guides, 6, algorithm="seed")
     assert h.to_numpy().tobytes() == want.tobytes()
     h.close()
     for g in (g1, g2, g3):

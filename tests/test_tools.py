@@ -146,3 +146,31 @@ def test_fasta_writer(tmp_path):
     # start 2 - 4 wraps (unsigned) and is clamped to the contig length -> empty sequence, as in the reference
     assert (tmp_path / "b.fa").read_text() == ">fwd\n%s\n>rev\n%s\n>edge\n\n" % (seq[96:126], revcomp(seq[197:227]))
     assert run("fasta_writer", "a", "b").returncode == 1
+
+
+def test_driver_reports_a_vcf_without_sample_columns(tmp_path):
+    """`-s all` on a VCF without a #CHROM line (or without sample columns): the driver's own message and exit code 2
+    (usage error, VARSCOT:213-249) - under `set -Eeuo pipefail` a failing `grep | awk` pipeline used to end the
+    script on the assignment, with exit code 1 and no text.  Needs no device: the check comes before any tool."""
+    import subprocess
+    driver = os.path.join(ROOT, "varscot_amd", "driver", "VARSCOT")
+    for body in ("##fileformat=VCFv4.2\n", "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\n"):
+        vcf = tmp_path / "no_samples.vcf"
+        vcf.write_text(body)
+        r = subprocess.run(["bash", driver, "-f", str(vcf), "-s", "all", "-b", "x.bed", "-o", "out.txt", "-g", "g.fa", "-i", "ix",
+                            "-T", str(tmp_path / "tmp")], capture_output=True, text=True)
+        assert r.returncode == 2, (r.returncode, r.stdout, r.stderr)
+        assert "Error: The VCF file has no sample columns." in r.stdout
+
+
+def test_bidir_index_removes_a_stale_seed_index_file(tmp_path):
+    """`bidir_index` without -S rewrites <prefix>.vsc; a <prefix>.vsi left from an earlier genome under the same
+    prefix would be auto-loaded by bidir_mapping, so it goes.  Host-only (packing needs no device)."""
+    rng = np.random.default_rng(3)
+    fa = str(tmp_path / "g.fa")
+    write_fasta(fa, ["chr1"], ["".join(rng.choice(list("ACGT"), size=500))])
+    prefix = str(tmp_path / "ix")
+    open(prefix + ".vsi", "wb").write(b"stale")
+    r = run("bidir_index", "-G", fa, "-I", prefix)
+    assert r.returncode == 0 and "Index created successfully" in r.stdout
+    assert os.path.exists(prefix + ".vsc") and not os.path.exists(prefix + ".vsi")

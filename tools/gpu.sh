@@ -1,0 +1,85 @@
+#!/bin/bash
+# gpu.sh - the one parameterised command line for the GPU box (replaces the per-experiment tools/r2_*.sh files of
+# round 2, which are in git history up to commit 26167cf).  Run through gpurun from the repository root:
+#
+#   gpurun --timeout 900 -- 'bash tools/gpu.sh tests [pytest args]'            pytest -m gpu (one process)
+#   gpurun -- 'bash tools/gpu.sh bench c3 [bench.py args]'                      one bench line -> gpurun_out/<tag>/
+#   gpurun -- 'bash tools/gpu.sh ab c3 libA.so libB.so [reps]'                  alternate two builds (VSC_LIB_PATH)
+#   gpurun -- 'bash tools/gpu.sh stats c3'                                      rocprofv3 --kernel-trace --stats
+#   gpurun -- 'bash tools/gpu.sh pmc c3 "FETCH_SIZE" [kernel name parts]'      one counter group, one pass
+#   gpurun -- 'bash tools/gpu.sh collect r03'                                   tools/collect_profiles.sh
+#   gpurun -- 'bash tools/gpu.sh bw'                                            fill / read / copy rates of the part
+# TAG (environment) names the directory under gpurun_out/ (default: the subcommand).  Steps are joined so that a
+# step that was killed starts no further GPU step.
+set -o pipefail
+CMD=${1:?subcommand}; shift
+ROOT=$(pwd); TAG=${TAG:-$CMD}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"
+line() { python3 - "$1" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(d["config"]["workload"], "ms/step", round(d["ms_per_step"], 3), "value", round(d["value"], 1), d.get("kernels_ms"), "frac", d.get("roofline", {}).get("frac"))
+PY
+}
+case $CMD in
+tests)
+    timeout -k 10 1100 python3 -m pytest tests -m gpu -x -q "$@" > "$OUT/pytest.log" 2>&1; rc=$?; tail -5 "$OUT/pytest.log"; exit $rc;;
+bench)
+    W=${1:?workload}; shift
+    timeout -k 10 500 python3 bench.py --workload "$W" --no-cpu-baseline "$@" > "$OUT/bench_$W.json" 2> "$OUT/bench_$W.err" || { tail -5 "$OUT/bench_$W.err"; exit 1; }
+    line "$OUT/bench_$W.json";;
+ab)
+    W=${1:?workload}; A=${2:?library A}; B=${3:?library B}; REPS=${4:-2}
+    for rep in $(seq "$REPS"); do for L in "$A" "$B"; do
+        VSC_LIB_PATH=$ROOT/$L timeout -k 10 400 python3 bench.py --workload "$W" --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/ab.json" 2> "$OUT/ab.err" || { tail -5 "$OUT/ab.err"; exit 1; }
+        echo -n "$L: "; line "$OUT/ab.json"
+    done; done;;
+stats)
+    W=${1:?workload}; shift
+    cd /tmp && export TMPDIR=/tmp
+    timeout -k 10 500 rocprofv3 --kernel-trace --stats -d "$OUT/stats_$W" -o run --output-format csv -- python3 "$ROOT/bench.py" --workload "$W" --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$OUT/stats_$W.json" 2> "$OUT/stats_$W.err" || { tail -5 "$OUT/stats_$W.err"; exit 1; }
+    find "$OUT" -name '*kernel_trace.csv' -delete
+    cut -d, -f1-4 "$OUT"/stats_$W/*/*kernel_stats.csv "$OUT"/stats_$W/*kernel_stats.csv 2> /dev/null | grep -E "vsc::" | head -16;;
+pmc)
+    W=${1:?workload}; CTR=${2:?counters}; shift; shift; export PMC_KERNELS="${*:-seed_sliced_kernel}"
+    # TA_* counters are refused: the one pass that used them on this pool (round 1) never returned; cause undetermined
+    case " $CTR " in *" TA_"*) echo "gpu.sh: TA_* counters are refused on this pool" >&2; exit 2;; esac
+    rm -rf "$OUT/pmc"; cd /tmp && export TMPDIR=/tmp
+    timeout -k 10 500 rocprofv3 --pmc $CTR -d "$OUT/pmc" -o run --output-format csv -- python3 "$ROOT/bench.py" --workload "$W" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_bench.json" 2> "$OUT/pmc.err" || { tail -5 "$OUT/pmc.err"; exit 1; }
+    python3 - "$OUT" <<'PY'
+import csv, glob, os, sys
+parts = os.environ["PMC_KERNELS"].split()
+acc = {}
+for path in glob.glob(sys.argv[1] + "/pmc/**/*counter_collection.csv", recursive=True):
+    per = {}
+    for row in csv.DictReader(open(path)):
+        if any(p in row["Kernel_Name"] for p in parts):
+            k = (row["Kernel_Name"].split("(")[0].replace("void ", "")[:44], row["Counter_Name"], row["Dispatch_Id"])
+            per[k] = per.get(k, 0.0) + float(row["Counter_Value"])
+    for (kn, n, _), v in per.items():
+        acc.setdefault((kn, n), []).append(v)
+    os.remove(path)  # (large; the means below are what is kept)
+for (kn, n), v in sorted(acc.items()):
+    print("%-46s %-22s %.5g" % (kn, n, sum(v) / len(v)))
+PY
+    ;;
+collect)
+    bash tools/collect_profiles.sh "${1:-r03}";;
+bw)
+    timeout -k 10 300 python3 - <<'PY'
+import torch
+def bench(f, n=10):
+    f(); torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): f()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+N = 8 << 30
+a = torch.empty(N, dtype=torch.uint8, device="cuda").view(torch.int64); b = torch.empty(N, dtype=torch.uint8, device="cuda").view(torch.int64)
+ms = bench(lambda: a.fill_(7)); print("fill 8 GiB", round(ms, 3), "ms", round(N / ms / 1e9, 2), "TB/s")
+ms = bench(lambda: b.copy_(a)); print("copy 8 GiB", round(ms, 3), "ms", round(2 * N / ms / 1e9, 2), "TB/s (r+w)")
+ms = bench(lambda: a.sum()); print("read 8 GiB", round(ms, 3), "ms", round(N / ms / 1e9, 2), "TB/s")
+PY
+    ;;
+*) echo "gpu.sh: unknown subcommand $CMD" >&2; exit 2;;
+esac

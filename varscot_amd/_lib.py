@@ -55,6 +55,27 @@ class MultiTiming(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class DebugParams(C.Structure):
+    """vsc_debug_params (include/varscot_hip_debug.h): test / experiment hooks; 0 or -1 = the library's default."""
+    _fields_ = [("seed_groups_per_cu", C.c_uint32), ("seed_reserve", C.c_uint32), ("sort_cap", C.c_uint32),
+                ("sort_max_bits", C.c_uint32), ("sort_xcd", C.c_int32), ("sort_debug", C.c_uint32),
+                ("sort_optimistic", C.c_int32), ("sort_slot_cap", C.c_uint32), ("score_chunk", C.c_uint64),
+                ("score_slices", C.c_int32), ("score_slice_shift", C.c_uint32), ("seed_shared", C.c_int32),
+                ("reserved", C.c_uint32 * 4)]
+    SIGNED_DEFAULT = ("sort_xcd", "sort_optimistic", "score_slices", "seed_shared")
+
+    @classmethod
+    def defaults(cls):
+        d = cls()
+        for k in cls.SIGNED_DEFAULT:
+            setattr(d, k, -1)
+        return d
+
+
+class MultiDebugParams(C.Structure):
+    _fields_ = [("rccl", C.c_int32), ("rccl_library", C.c_char_p)]
+
+
 BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32)  # vsc_batch_fn
 
 # every symbol include/varscot_hip.h declares: (name, restype, argtypes)
@@ -116,6 +137,13 @@ SYMBOLS = [
     ("vsc_rf_predict_packed", C.c_int, [_vp, C.POINTER(RfModel), _vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),
     ("vsc_sam_order", None, [_vp, C.c_uint64, _vp, _vp]),
 ]
+# include/varscot_hip_debug.h (test / experiment hooks, not part of the drop-in boundary)
+DEBUG_SYMBOLS = [
+    ("vsc_ctx_set_debug_params", C.c_int, [_vp, C.POINTER(DebugParams)]),
+    ("vsc_ctx_get_debug_params", C.c_int, [_vp, C.POINTER(DebugParams)]),
+    ("vsc_debug_set_host_timing", None, [C.c_int]),
+    ("vsc_multi_create_debug", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(MultiDebugParams), C.POINTER(_vp)]),
+]
 
 _lib = None
 
@@ -145,7 +173,7 @@ def lib():
             except ImportError:
                 pass
         L = C.CDLL(LIB_PATH)
-        for name, restype, argtypes in SYMBOLS:
+        for name, restype, argtypes in SYMBOLS + DEBUG_SYMBOLS:
             fn = getattr(L, name)  # AttributeError = header and library out of sync
             fn.restype = restype
             fn.argtypes = argtypes

@@ -127,6 +127,17 @@ class Context:
         check(lib().vsc_ctx_timing(self._h, C.byref(t)), self._h)
         return t.as_dict()
 
+    def set_debug(self, **hooks):
+        """Test / experiment hooks of include/varscot_hip_debug.h (vsc_ctx_set_debug_params): e.g.
+        set_debug(sort_cap=16) forces many sort levels on a few thousand records.  No arguments: back to the
+        defaults.  The library reads no environment variable."""
+        d = _lib.DebugParams.defaults()
+        for k, v in hooks.items():
+            if k not in dict(_lib.DebugParams._fields_) or k == "reserved":
+                raise TypeError("unknown debug hook %r" % k)
+            setattr(d, k, int(v))
+        check(lib().vsc_ctx_set_debug_params(self._h, C.byref(d) if hooks else None), self._h)
+
     def load_genome(self, packed, rank=0, world=1):
         return Genome(self, packed, rank, world)
 
@@ -355,10 +366,17 @@ class MultiContext:
     entry of `devices`; ids may repeat - several contexts on one GPU).  search() returns the merged records on
     the first context."""
 
-    def __init__(self, devices):
+    def __init__(self, devices, rccl=None, rccl_library=None):
+        """rccl / rccl_library: the hooks of vsc_multi_create_debug (None: vsc_multi_create) - rccl=False forces
+        device copies, rccl=True insists on RCCL (also with one device), rccl="try" attempts it and falls back, rccl_library names the one library to load."""
         ids = (C.c_int * len(devices))(*devices)
         self._h = C.c_void_p()
-        check(lib().vsc_multi_create(ids, len(devices), C.byref(self._h)))
+        if rccl is None and rccl_library is None:
+            check(lib().vsc_multi_create(ids, len(devices), C.byref(self._h)))
+        else:
+            p = _lib.MultiDebugParams(-1 if rccl is None else (2 if rccl == "try" else int(bool(rccl))),
+                                      rccl_library.encode() if rccl_library else None)
+            check(lib().vsc_multi_create_debug(ids, len(devices), C.byref(p), C.byref(self._h)))
         self.devices = list(devices)
         self._genomes = weakref.WeakSet()
         self._results = weakref.WeakSet()
@@ -370,6 +388,17 @@ class MultiContext:
     @property
     def uses_rccl(self):
         return bool(lib().vsc_multi_uses_rccl(self._h))
+
+    def last_error(self):
+        return lib().vsc_multi_last_error(self._h).decode(errors="replace")
+
+    def set_debug(self, **hooks):
+        """Context.set_debug on every context of the set."""
+        d = _lib.DebugParams.defaults()
+        for k, v in hooks.items():
+            setattr(d, k, int(v))
+        for i in range(len(self.devices)):
+            check(lib().vsc_ctx_set_debug_params(lib().vsc_multi_ctx(self._h, i), C.byref(d) if hooks else None))
 
     def timing(self):
         t = _lib.MultiTiming()

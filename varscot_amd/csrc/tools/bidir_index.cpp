@@ -39,6 +39,9 @@ int main(int argc, char **argv)
         }
         const PackedIndex ix = pack_records(recs);
         write_index(prefix, ix);
+        // a seed index file of an earlier genome under this prefix must not outlive the planes it was built from
+        // (bidir_mapping loads <prefix>.vsi whenever it exists; -S below writes the new one)
+        std::remove(seed_index_path(prefix).c_str());
         if (opts[2].set) {
             vsc_ctx *ctx = nullptr;
             vsc_genome *genome = nullptr;

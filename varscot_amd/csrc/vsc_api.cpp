@@ -3,6 +3,7 @@
 // vsc_kernels.hip.  No CPU implementation of the search exists in this library: without a HIP
 // device every compute entry point fails with VSC_ERR_NODEVICE / VSC_ERR_DEVICE.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
@@ -19,9 +20,9 @@ using namespace vsc;
 
 namespace {
 
-// VSC_DEBUG_TIMING=1 prints host-side wall times of the phases of vsc_search to stderr
+// vsc_debug_set_host_timing(1): host-side wall times of the phases of vsc_search on stderr
 struct HostTimer {
-    bool on = std::getenv("VSC_DEBUG_TIMING") != nullptr;
+    bool on = vsc::host_timing_on();
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void lap(const char *what)
     {
@@ -33,6 +34,11 @@ struct HostTimer {
 };
 
 }  // namespace
+
+namespace vsc {
+static std::atomic<int> g_host_timing{0};
+bool host_timing_on() { return g_host_timing.load(std::memory_order_relaxed) != 0; }
+}  // namespace vsc
 
 namespace {
 
@@ -203,6 +209,22 @@ int vsc_ctx_set_stream(vsc_ctx *ctx, void *hip_stream)
 }
 
 const char *vsc_last_error(const vsc_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int vsc_ctx_set_debug_params(vsc_ctx *ctx, const vsc_debug_params *params)
+{
+    if (!ctx) return VSC_ERR_INVALID;
+    ctx->dbg = params ? *params : default_debug_params();
+    return VSC_OK;
+}
+
+int vsc_ctx_get_debug_params(const vsc_ctx *ctx, vsc_debug_params *out)
+{
+    if (!ctx || !out) return VSC_ERR_INVALID;
+    *out = ctx->dbg;
+    return VSC_OK;
+}
+
+void vsc_debug_set_host_timing(int on) { vsc::g_host_timing.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 int vsc_ctx_timing(const vsc_ctx *ctx, vsc_timing *out)
 {
@@ -506,19 +528,66 @@ static_assert(sizeof(IndexFileHeader) == 80, "index file header layout");
 constexpr char kIndexMagic[8] = {'V', 'S', 'C', 'S', 'E', 'E', 'D', 0};
 constexpr size_t kIndexIoChunk = 64u << 20;
 
-hipError_t genome_fingerprint(const vsc_genome *g, uint64_t *out)
+// Every word of all three planes of the shard (a device-side reduction: under 1 ms at 3 Gbp) + the contig table
+// (offsets and ends) + the shard's place in the genome.  A genome of the same size and layout that differs in one
+// base, or only in what is masked as N, gets another fingerprint.
+hipError_t genome_fingerprint(vsc_ctx *ctx, const vsc_genome *g, uint64_t *out)
 {
-    const uint64_t probe = std::min<uint64_t>(g->own_words, 1u << 16);
-    std::vector<uint32_t> buf((size_t)g->n_contigs + 2 * probe);
-    if (g->n_contigs) VSC_TRY(hipMemcpy(buf.data(), g->d_contig_off, (size_t)g->n_contigs * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (probe) {
-        VSC_TRY(hipMemcpy(buf.data() + g->n_contigs, g->d_hi, probe * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        VSC_TRY(hipMemcpy(buf.data() + g->n_contigs + probe, g->d_lo, probe * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    VSC_TRY(ctx->counters.ensure(kCounterWords * sizeof(unsigned long long)));
+    unsigned long long *d_sum = (unsigned long long *)ctx->counters.p;
+    VSC_TRY(hipMemsetAsync(d_sum, 0, sizeof *d_sum, ctx->stream));
+    const uint64_t words = std::min<uint64_t>(g->own_words + 1, g->dev_words);  // own words + the halo word
+    VSC_TRY(launch_plane_hash(g->d_hi, g->d_lo, g->d_nm, words, d_sum, ctx->stream));
+    unsigned long long sum = 0;
+    VSC_TRY(hipMemcpyAsync(&sum, d_sum, sizeof sum, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint32_t> tab(2 * (size_t)g->n_contigs);
+    if (g->n_contigs) {
+        VSC_TRY(hipMemcpyAsync(tab.data(), g->d_contig_off, (size_t)g->n_contigs * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        VSC_TRY(hipMemcpyAsync(tab.data() + g->n_contigs, g->d_contig_end, (size_t)g->n_contigs * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
-    uint64_t h = 0xcbf29ce484222325ull ^ g->own_words;  // FNV-1a over the words
-    for (uint32_t w : buf) h = (h ^ w) * 0x100000001b3ull;
+    VSC_TRY(hipStreamSynchronize(ctx->stream));
+    uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a over the rest
+    auto eat = [&](uint64_t v) {
+        for (int i = 0; i < 8; ++i) h = (h ^ ((v >> (8 * i)) & 0xFF)) * 0x100000001b3ull;
+    };
+    eat(sum);
+    eat(g->own_words);
+    eat(g->first_word);
+    for (uint32_t w : tab) eat(w);
     *out = h;
     return hipSuccess;
+}
+
+// What seed_sliced_kernel reads through the chunk table must lie inside the arrays: a damaged file whose length
+// happens to match its header must not become out-of-bounds device reads.
+bool chunk_table_ok(const std::vector<uint32_t> &ctab, uint64_t S, uint64_t vert_bytes, std::string *why)
+{
+    const uint64_t n_blocks = vert_bytes / (2 * kRestBases * sizeof(uint32_t));
+    uint64_t expect_site = 0, expect_block = 0;
+    uint32_t last_bucket = 0;
+    for (size_t c = 0; c * 4 < ctab.size(); ++c) {
+        const uint64_t first = ctab[4 * c], count = ctab[4 * c + 1], vfirst = ctab[4 * c + 3];
+        const uint32_t z = ctab[4 * c + 2], bucket = z & kChunkBucketMask, minus_from = (z >> kChunkMinusShift) & 0xFFFu;
+        const uint64_t blocks = (count + kSlicedSites - 1) / kSlicedSites;
+        const char *bad = nullptr;
+        if (count == 0 || count > (uint64_t)kSlicedChunk) bad = "site count";
+        else if (first != expect_site || first + count > 3 * S) bad = "first site";
+        else if (vfirst != expect_block || vfirst + blocks > n_blocks) bad = "first block";
+        else if (bucket >= (uint32_t)kBuckets || bucket < last_bucket) bad = "bucket";
+        else if (minus_from > count) bad = "strand boundary";
+        if (bad) {
+            *why = "chunk " + std::to_string(c) + ": bad " + bad;
+            return false;
+        }
+        expect_site = first + count;
+        expect_block = vfirst + blocks;
+        last_bucket = bucket;
+    }
+    if (expect_site != 3 * S) {
+        *why = "the chunks do not cover the site table";
+        return false;
+    }
+    return true;
 }
 
 struct FileCloser {
@@ -581,7 +650,7 @@ int vsc_genome_index_save(vsc_ctx *ctx, const vsc_genome *genome, const char *pa
     h.has_extra_pam = genome->index_has_extra_pam;
     h.extra_pam[0] = genome->index_extra_pam[0];
     h.extra_pam[1] = genome->index_extra_pam[1];
-    VSC_HIP(ctx, genome_fingerprint(genome, &h.fingerprint));
+    VSC_HIP(ctx, genome_fingerprint(ctx, genome, &h.fingerprint));
     FileCloser fc{std::fopen(path, "wb")};
     if (!fc.f) return fail(ctx, VSC_ERR_INVALID, (std::string("vsc_genome_index_save: cannot write ") + path).c_str());
     bool ok = std::fwrite(&h, sizeof h, 1, fc.f) == 1;
@@ -611,7 +680,7 @@ int vsc_genome_index_load(vsc_ctx *ctx, vsc_genome *genome, const char *path)
         h.sliced_sites != (uint32_t)kSlicedSites)
         return fail(ctx, VSC_ERR_INVALID, "vsc_genome_index_load: the file was written by another version of the library");
     uint64_t fp = 0;
-    VSC_HIP(ctx, genome_fingerprint(genome, &fp));
+    VSC_HIP(ctx, genome_fingerprint(ctx, genome, &fp));
     if (h.own_words != genome->own_words || h.n_contigs != genome->n_contigs || h.fingerprint != fp)
         return fail(ctx, VSC_ERR_INVALID, "vsc_genome_index_load: the file belongs to another genome");
     const uint64_t S = h.sites;
@@ -649,6 +718,15 @@ int vsc_genome_index_load(vsc_ctx *ctx, vsc_genome *genome, const char *path)
         free_index(genome);
         if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, "vsc_genome_index_load", e);
         return fail(ctx, VSC_ERR_INVALID, (std::string("vsc_genome_index_load: ") + path + " is truncated").c_str());
+    }
+    {
+        std::vector<uint32_t> ctab((size_t)h.chunks * 4);
+        if (h.chunks) VSC_HIP(ctx, hipMemcpy(ctab.data(), genome->d_ix_chunk_tab, ctab.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::string why;
+        if (!chunk_table_ok(ctab, S, h.vert_bytes, &why)) {
+            free_index(genome);
+            return fail(ctx, VSC_ERR_INVALID, (std::string("vsc_genome_index_load: ") + path + " is damaged (" + why + ")").c_str());
+        }
     }
     genome->ix_chunks = h.chunks;
     genome->ix_vert_bytes = vb;
@@ -699,12 +777,13 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
     hipStream_t st = ctx->stream;
     unsigned rem = key_bits;  // key bits no partition level has used yet
     bool sorted_marked = false;
-    // test knobs: a smaller bin capacity / fewer bits per level make the partition levels and the
-    // oversize path run on inputs of a few thousand records
+    // test hooks (varscot_hip_debug.h): a smaller bin capacity / fewer bits per level make the partition levels
+    // and the oversize path run on inputs of a few thousand records
+    const vsc_debug_params &dbg = ctx->dbg;
     uint64_t sort_cap = kSortCap;
     unsigned max_bits = kSortMaxBinBits;
-    if (const char *o = std::getenv("VSC_SORT_CAP")) sort_cap = (uint64_t)std::min(kSortCap, std::max(16, std::atoi(o)));
-    if (const char *o = std::getenv("VSC_SORT_MAX_BITS")) max_bits = (unsigned)std::min(kSortMaxBinBits, std::max(1, std::atoi(o)));
+    if (dbg.sort_cap) sort_cap = std::min<uint64_t>(kSortCap, std::max<uint32_t>(16, dbg.sort_cap));
+    if (dbg.sort_max_bits) max_bits = std::min<unsigned>(kSortMaxBinBits, std::max<uint32_t>(1, dbg.sort_max_bits));
     for (unsigned level = 1; !segs.empty(); ++level) {
         if (level > 48) return hipErrorUnknown;  // cannot happen: every level consumes key bits, keys are unique
         uint64_t n_max = 0, n_all = 0;
@@ -720,7 +799,7 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             while (bits > 1 && ((uint64_t)segs.size() << bits) > (1ull << 22)) --bits;  // bounded bin tables
         }
         const size_t n_segs = segs.size();
-        if (std::getenv("VSC_DEBUG_SORT"))
+        if (dbg.sort_debug)
             std::fprintf(stderr, "[vsc sort] level %u: %zu segments, %llu records, largest %llu, %u bits (of %u left), cap %llu\n", level,
                          n_segs, (unsigned long long)n_all, (unsigned long long)n_max, bits, rem, (unsigned long long)sort_cap);
         std::vector<uint32_t> &tile0 = ctx->host_tile0;
@@ -761,11 +840,11 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             a.bin_start = a.cursor + n_bins;
             a.bin_bits = bits;
             a.bin_shift = kRecPosShift + pos_pad + rem - bits;
-            if (tiles >= 64 && !(std::getenv("VSC_SORT_XCD") && std::getenv("VSC_SORT_XCD")[0] == '0')) a.xcd_tiles = (uint32_t)((tiles + 7) / 8);
+            if (dbg.sort_xcd != 0 && tiles >= 64) a.xcd_tiles = (uint32_t)((tiles + 7) / 8);
             VSC_TRY(hipMemsetAsync(a.hist, 0, n_bins * sizeof(uint32_t), st));
             VSC_TRY(launch_bin_hist(a, st));
             VSC_TRY(launch_bin_scan(a, st));
-            if (const char *dbg = std::getenv("VSC_DEBUG_SORT"); dbg && dbg[0] == '2') {
+            if (dbg.sort_debug >= 2) {
                 // recount every bin on the host and compare with the device histogram
                 std::vector<uint32_t> h(n_bins);
                 VSC_TRY(hipMemcpyAsync(h.data(), a.hist, n_bins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -944,7 +1023,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         sa.n_contigs = genome->n_contigs;
         sa.counters = (unsigned long long *)ctx->counters.p;
         uint32_t groups_per_cu = kSlicedWavesPerSimd;  // resident groups (of four waves) per CU: registers / LDS of the kernel
-        if (const char *o = std::getenv("VSC_SEED_GROUPS_PER_CU")) groups_per_cu = (uint32_t)std::max(1, std::atoi(o));
+        if (ctx->dbg.seed_groups_per_cu) groups_per_cu = ctx->dbg.seed_groups_per_cu;
         const uint32_t n_waves_max = (uint32_t)ctx->n_cus * groups_per_cu * kWavesPerGroup;
         const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, (sa.n_chunks + kSlicedGrab - 1) / kSlicedGrab));
         n_groups = (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
@@ -953,7 +1032,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         // and read by the sort)
         const uint64_t per_wave = cap / ((uint64_t)n_groups * kWavesPerGroup * 8 * n_parts);
         uint32_t want_reserve = (uint32_t)std::min<uint64_t>(n_parts > 8 ? 128 : 1024, std::max<uint64_t>(kWave, per_wave));
-        if (const char *o = std::getenv("VSC_SEED_RESERVE")) want_reserve = (uint32_t)std::min(1024, std::max((int)kWave, std::atoi(o)));
+        if (ctx->dbg.seed_reserve) want_reserve = std::min<uint32_t>(1024, std::max<uint32_t>(kWave, ctx->dbg.seed_reserve));
         sa.reserve_log2 = 6;
         while ((2u << sa.reserve_log2) <= want_reserve) ++sa.reserve_log2;
         sa.reserve = 1u << sa.reserve_log2;
@@ -1333,11 +1412,11 @@ namespace {
 
 // Rows of scratch a scoring call gets: as many as fit.  Halves the request until the device has room (down
 // to 64 Ki rows), so that a result larger than the free memory is scored in several passes over the same
-// scratch buffers.  VSC_SCORE_CHUNK=n (tests) forces passes of at most n rows.
+// scratch buffers.  vsc_debug_params.score_chunk (tests) forces passes of at most that many rows.
 hipError_t score_scratch(vsc_ctx *ctx, uint64_t count, size_t mit_bytes, size_t flag_bytes, size_t feat_bytes, uint64_t *rows_out)
 {
     uint64_t rows = count;
-    if (const char *o = std::getenv("VSC_SCORE_CHUNK")) rows = std::min<uint64_t>(rows, (uint64_t)std::max(1, std::atoi(o)));
+    if (ctx->dbg.score_chunk) rows = std::min<uint64_t>(rows, ctx->dbg.score_chunk);
     for (;;) {
         hipError_t e = hipSuccess;
         if (mit_bytes) e = ctx->score_mit.ensure(rows * mit_bytes);
@@ -1497,8 +1576,8 @@ int vsc_score_hits_packed(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits
         uint32_t kSliceShift = 28;  // 2^28 positions = 64 MB of interleaved planes
         const uint64_t positions = genome->dev_words * 32;
         bool scheduled = m >= (1u << 22) && positions > (3ull << kSliceShift);
-        if (const char *o = std::getenv("VSC_SCORE_SLICES")) scheduled = o[0] == '1';  // tests / experiments
-        if (const char *o = std::getenv("VSC_SCORE_SLICE_SHIFT")) kSliceShift = (uint32_t)std::min(31, std::max(8, std::atoi(o)));
+        if (ctx->dbg.score_slices >= 0) scheduled = ctx->dbg.score_slices == 1;  // tests / experiments
+        if (ctx->dbg.score_slice_shift) kSliceShift = std::min<uint32_t>(31, std::max<uint32_t>(8, ctx->dbg.score_slice_shift));
         if (scheduled) {
             uint32_t g_edge[2] = {0, 0};
             VSC_HIP(ctx, hipMemcpyAsync(&g_edge[0], &s.hits[0].guide, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1562,8 +1641,10 @@ int rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *dense, co
         d.column = 0;
         if (d.status != 1) continue;
         const uint16_t f = model->feature[i];
-        if (f > VSC_N_FEATURES || d.left == 0 || d.right == 0 || d.left > model->n_nodes || d.right > model->n_nodes)
-            return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": malformed forest (feature or daughter index out of range)").c_str());
+        // randomForest numbers the daughters of a node behind it: a daughter at or before its parent is a cycle
+        const uint32_t own = (uint32_t)(i % model->n_nodes) + 1;  // 1-based index of this node in its tree
+        if (f > VSC_N_FEATURES || d.left <= own || d.right <= own || d.left > model->n_nodes || d.right > model->n_nodes)
+            return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": malformed forest (feature or daughter index out of range, or a daughter that does not lie behind its parent)").c_str());
         if (f == VSC_N_FEATURES) {
             d.column = kRfActivity;
         } else {

@@ -31,7 +31,9 @@ __device__ __forceinline__ void wave_sync()
 // missing from a histogram).  With the explicit wait every barrier is safe; use this instead of __syncthreads().
 __device__ __forceinline__ void block_sync()
 {
+#ifndef VSC_PLAIN_SYNCTHREADS  // (defined only by tools/isa_barrier_excerpt.sh, which compiles - never runs - the plain form)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
 }
 

@@ -254,6 +254,9 @@ hipError_t launch_score_schedule(const ScoreArgs &args, uint32_t g_lo, uint32_t 
                                  uint64_t *bounds, uint64_t *seg_start, uint64_t *seg_prefix, hipStream_t stream);
 hipError_t launch_score_pairs(const uint2 *on, const uint2 *off, const uint32_t *masks, uint64_t n, double *mit,
                               uint8_t *mit_flags, uint8_t *features, hipStream_t stream);
+// *out += fingerprint of words [0, n_words) of the three planes (zero *out first)
+hipError_t launch_plane_hash(const uint32_t *hi, const uint32_t *lo, const uint32_t *nm, uint64_t n_words, unsigned long long *out,
+                             hipStream_t stream);
 hipError_t sort32_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
 hipError_t launch_sort32(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
                          const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream);

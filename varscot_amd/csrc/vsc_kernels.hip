@@ -373,6 +373,48 @@ hipError_t launch_merge(const vsc_hit *in, const uint64_t *shard_off_dev, uint32
     return hipGetLastError();
 }
 
+// Fingerprint of the resident planes (index files name the genome they belong to): the sum, over all words of all
+// three planes, of a 64-bit mix of (word, plane, index) - commutative, so that the order in which workgroups add
+// their partial sums does not matter, and sensitive to every bit and to where it stands.
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void plane_hash_kernel(const uint32_t *hi, const uint32_t *lo, const uint32_t *nm, uint64_t n_words,
+                                                         unsigned long long *out)
+{
+    __shared__ unsigned long long partial[256 / kWave];
+    uint64_t sum = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t n = nm[i];
+        // the base planes only count where the position is a base: what lies under an N is not part of the genome
+        sum += mix64(((uint64_t)(hi[i] & ~(uint32_t)n) << 32 | (lo[i] & ~(uint32_t)n)) + 0x9e3779b97f4a7c15ull * (3 * i + 1));
+        sum += mix64(n + 0x9e3779b97f4a7c15ull * (3 * i + 2));
+    }
+    for (int d = kWave / 2; d > 0; d >>= 1) sum += (uint64_t)__shfl_down((unsigned long long)sum, d, kWave);
+    if (threadIdx.x % kWave == 0) partial[threadIdx.x / kWave] = sum;
+    block_sync();
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (int w = 0; w < 256 / kWave; ++w) s += partial[w];
+        atomicAdd(out, s);
+    }
+}
+
+hipError_t launch_plane_hash(const uint32_t *hi, const uint32_t *lo, const uint32_t *nm, uint64_t n_words, unsigned long long *out,
+                             hipStream_t stream)
+{
+    if (n_words == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n_words + 255) / 256, 4096);
+    hipLaunchKernelGGL(plane_hash_kernel, dim3(blocks), dim3(256), 0, stream, hi, lo, nm, n_words, out);
+    return hipGetLastError();
+}
+
 // 32-bit (key, value) sorts of the one-off index build and of the per-search read lists (a few million pairs): rocPRIM
 hipError_t sort32_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes)
 {
@@ -825,7 +867,9 @@ __global__ __launch_bounds__(kRfRows) void rf_predict_kernel(const RfArgs a)
         for (uint32_t k = 0; k < nt; ++k) {
             const RfNode *tree = tile + (size_t)k * a.n_nodes;
             RfNode nd = tree[0];
-            while (nd.status != -1) {
+            // (daughters lie behind their parent - the host checks - so a walk ends within n_nodes steps; the
+            // bound only keeps a forest that slipped past the check from hanging the device)
+            for (uint32_t step = 0; nd.status != -1 && step < a.n_nodes; ++step) {
                 const double v = nd.column == kRfActivity ? act : (double)s_x[nd.column][t];
                 nd = tree[(v <= nd.split ? nd.left : nd.right) - 1u];
             }

@@ -32,6 +32,7 @@ struct Rccl {
     void *lib = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;  // optional
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -39,20 +40,25 @@ struct Rccl {
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 
-    bool load(std::string *why)
+    // `only` (tests): the one library name to try instead of the usual two
+    bool load(std::string *why, const char *only = nullptr)
     {
         if (lib) return true;
-        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        std::string last;
+        for (const char *name : {only ? only : "librccl.so.1", only ? only : "librccl.so"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (lib) break;
+            const char *e = dlerror();  // (one call: dlerror() clears the state it reports)
+            last = e ? e : "dlopen failed";
         }
         if (!lib) {
-            *why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+            *why = "RCCL not found: " + last;
             return false;
         }
         auto sym = [&](const char *n) { return dlsym(lib, n); };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         Send = (decltype(Send))sym("ncclSend");
@@ -115,7 +121,9 @@ template <class F> void on_all(size_t n, F &&body)
 
 extern "C" {
 
-int vsc_multi_create(const int *device_ids, int n, vsc_multi **out)
+int vsc_multi_create(const int *device_ids, int n, vsc_multi **out) { return vsc_multi_create_debug(device_ids, n, nullptr, out); }
+
+int vsc_multi_create_debug(const int *device_ids, int n, const vsc_multi_debug_params *params, vsc_multi **out)
 {
     if (!out) return VSC_ERR_INVALID;
     *out = nullptr;
@@ -139,15 +147,15 @@ int vsc_multi_create(const int *device_ids, int n, vsc_multi **out)
         }
     }
     // RCCL needs one communicator rank per DISTINCT device; a list with repeats (tests, rehearsals) exchanges by
-    // device copies.  VSC_MULTI_RCCL=0 forces copies, =1 insists on RCCL (an error if it cannot be set up).
+    // device copies.  Hooks (varscot_hip_debug.h): rccl = 0 forces copies, 1 insists on RCCL (an error if it
+    // cannot be set up).
     std::vector<int> sorted(m->device);
     std::sort(sorted.begin(), sorted.end());
     const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
-    const char *knob = std::getenv("VSC_MULTI_RCCL");
-    const bool forced = knob && knob[0] == '1', off = knob && knob[0] == '0';
-    if (distinct && !off && (n > 1 || forced)) {
+    const bool forced = params && params->rccl == 1, off = params && params->rccl == 0, attempt = params && params->rccl == 2;
+    if (distinct && !off && (n > 1 || forced || attempt)) {
         std::string why;
-        bool ok = m->rccl.load(&why);
+        bool ok = m->rccl.load(&why, params ? params->rccl_library : nullptr);
         if (ok) {
             m->comm.assign(n, nullptr);
             const ncclResult_t r = m->rccl.CommInitAll(m->comm.data(), n, m->device.data());
@@ -163,8 +171,9 @@ int vsc_multi_create(const int *device_ids, int n, vsc_multi **out)
             return VSC_ERR_DEVICE;
         }
         m->use_rccl = ok;  // not forced and unavailable: peer copies carry the records instead
+        if (!ok) m->err = why;  // (vsc_multi_last_error says why the copies are in use)
     } else if (forced) {
-        std::fprintf(stderr, "vsc_multi_create: VSC_MULTI_RCCL=1 needs distinct devices\n");
+        std::fprintf(stderr, "vsc_multi_create: RCCL was asked for but needs distinct devices\n");
         vsc_multi_destroy(m);
         return VSC_ERR_INVALID;
     }
@@ -325,10 +334,28 @@ int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *gu
             VSC_M(hipSetDevice(m->device[r]));
             VSC_M(hipMemcpyAsync(m->d_count[r], &count[r], sizeof(uint64_t), hipMemcpyHostToDevice, m->xstream[r]));
         }
+        // Inside a group nothing may return early: an open group makes every later RCCL call on these communicators
+        // queue forever.  The first failure is kept, the group is closed, and the communicators are given up
+        // (a half-issued send / receive pairing cannot be repaired): later searches use device copies.
+        ncclResult_t bad = ncclSuccess;
+        auto in_group = [&](ncclResult_t r) {
+            if (bad == ncclSuccess && r != ncclSuccess) bad = r;
+        };
+        auto give_up_rccl = [&](const char *where) {
+            for (ncclComm_t &c : m->comm) {
+                if (c && m->rccl.CommAbort) (void)m->rccl.CommAbort(c);
+                c = nullptr;
+            }
+            m->comm.clear();
+            m->use_rccl = false;
+            drop_parts();
+            return mfail(m, VSC_ERR_DEVICE, std::string(where) + ": " + m->rccl.GetErrorString(bad) + " (RCCL given up, later searches copy)");
+        };
         VSC_N(m->rccl.GroupStart());
-        for (size_t r = 0; r < n; ++r)
-            VSC_N(m->rccl.AllGather(m->d_count[r], m->d_count[r] + 1, 1, ncclUint64, m->comm[r], m->xstream[r]));
-        VSC_N(m->rccl.GroupEnd());
+        for (size_t r = 0; r < n && bad == ncclSuccess; ++r)
+            in_group(m->rccl.AllGather(m->d_count[r], m->d_count[r] + 1, 1, ncclUint64, m->comm[r], m->xstream[r]));
+        in_group(m->rccl.GroupEnd());
+        if (bad != ncclSuccess) return give_up_rccl("all-gather of the hit counts");
         std::vector<uint64_t> seen(n, 0);
         VSC_M(hipSetDevice(m->device[0]));
         VSC_M(hipMemcpyAsync(seen.data(), m->d_count[0] + 1, n * sizeof(uint64_t), hipMemcpyDeviceToHost, m->xstream[0]));
@@ -338,12 +365,13 @@ int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *gu
             return mfail(m, VSC_ERR_DEVICE, "vsc_multi_search: the all-gathered hit counts differ from the shards' counts");
         }
         VSC_N(m->rccl.GroupStart());
-        for (size_t r = 0; r < n; ++r) {
+        for (size_t r = 0; r < n && bad == ncclSuccess; ++r) {
             if (!count[r]) continue;
-            VSC_N(m->rccl.Recv(dst + off[r] * sizeof(vsc_hit), count[r] * sizeof(vsc_hit), ncclUint8, (int)r, m->comm[0], m->xstream[0]));
-            VSC_N(m->rccl.Send(vsc_hits_data_dev(part[r]), count[r] * sizeof(vsc_hit), ncclUint8, 0, m->comm[r], m->xstream[r]));
+            in_group(m->rccl.Recv(dst + off[r] * sizeof(vsc_hit), count[r] * sizeof(vsc_hit), ncclUint8, (int)r, m->comm[0], m->xstream[0]));
+            in_group(m->rccl.Send(vsc_hits_data_dev(part[r]), count[r] * sizeof(vsc_hit), ncclUint8, 0, m->comm[r], m->xstream[r]));
         }
-        VSC_N(m->rccl.GroupEnd());
+        in_group(m->rccl.GroupEnd());
+        if (bad != ncclSuccess) return give_up_rccl("send / receive of the hit records");
         for (size_t r = 0; r < n; ++r) {
             VSC_M(hipSetDevice(m->device[r]));
             VSC_M(hipStreamSynchronize(m->xstream[r]));
@@ -365,6 +393,8 @@ int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *gu
     const auto t2 = clock::now();
     // ---- merge on the first device: shards partition the positions in ascending order ------------------------
     const int mrc = vsc_hits_merge(m->ctx[0], dst, 1, count.data(), (uint32_t)n, n_guides, out);
+    // (the gathered records are not kept beside the merged result: the first device would hold the result twice)
+    if (total * sizeof(vsc_hit) > (64u << 20)) m->gather.release();
     if (mrc != VSC_OK) return mfail(m, mrc, std::string("merge: ") + vsc_last_error(m->ctx[0]));
     const auto t3 = clock::now();
     auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 
+#include "varscot_hip_debug.h"
 #include "vsc_internal.h"
 
 namespace vsc {
@@ -38,6 +39,19 @@ struct DeviceBuf {
     }
 };
 
+inline vsc_debug_params default_debug_params()
+{
+    vsc_debug_params d{};
+    d.sort_xcd = -1;
+    d.sort_optimistic = -1;
+    d.score_slices = -1;
+    d.seed_shared = -1;
+    return d;
+}
+
+// process-wide: host-side lap times on stderr (vsc_debug_set_host_timing)
+bool host_timing_on();
+
 }  // namespace vsc
 
 struct vsc_ctx {
@@ -48,6 +62,7 @@ struct vsc_ctx {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;
     vsc_timing timing{};
+    vsc_debug_params dbg = vsc::default_debug_params();  // test / experiment hooks (include/varscot_hip_debug.h)
     // keys_a / keys_b: the two record buffers the bin sort alternates between (keys_a + vals_a: the scan's (key, value) pairs)
     vsc::DeviceBuf counters, guides, keys_a, keys_b, vals_a, sort_temp, score_mit, score_flags, score_feat;
     vsc::DeviceBuf sort_segs, sort_tabs, sort_over, score_sched;

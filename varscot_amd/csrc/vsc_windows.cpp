@@ -22,6 +22,10 @@
 #include "tools/vcf_expand.hpp"
 #include "varscot_hip.h"
 
+namespace vsc {
+bool host_timing_on();  // vsc_api.cpp (vsc_debug_set_host_timing)
+}
+
 namespace {
 
 using namespace vsc_vcf;
@@ -258,7 +262,7 @@ template <class F> void run_parallel(unsigned threads, size_t n_items, F &&body,
 // One VCF sample column -> chromosomes with their records, parsed on all threads (line order preserved).
 std::vector<Chromosome> read_vcf_parallel(const std::string &path, unsigned sample, unsigned threads)
 {
-    const bool timing = std::getenv("VSC_DEBUG_TIMING") != nullptr;
+    const bool timing = vsc::host_timing_on();
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -397,7 +401,7 @@ int vsc_windows_build(const char *vcf_path, uint32_t sample, uint32_t seq_len, u
         return fail(VSC_ERR_INVALID, "vsc_windows_build: null or empty argument");
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
     threads = std::min(threads, 256u);
-    const bool timing = std::getenv("VSC_DEBUG_TIMING") != nullptr;
+    const bool timing = vsc::host_timing_on();
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
