@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the off-target search hot path (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python bench.py --gpus N --steps K --warmup W            (any N: for N > 1 without a launcher's environment it starts
+                                                              torch.distributed.run itself, as a child process, before
+                                                              anything touches a GPU, and relays the child's JSON line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of synthetic input: all reads of the workload
 searched (both strands) against the resident synthetic 3 Gbp genome - search kernel, bin sort of the
-hits, record assembly - and, for N > 1, the RCCL gather of the hit records to rank 0 plus the merge
-there.  Inputs (packed genome planes) are resident in HBM before the timed region starts; results
+hits, record assembly - and, for N > 1, ONE exchange of 8-byte hit records over RCCL plus the merge:
+both shapes are timed and reported (`exchanges`): "root" = the single gather to rank 0 (north star), "reads" =
+every rank gathers and merges its read range (result stays distributed); `value` is the one --exchange names.  Inputs (packed genome planes) are resident in HBM before the timed region starts; results
 stay in HBM.  The genome is sharded by position range across ranks (total work fixed => strong
 scaling).  Rank 0 prints ONE JSON line.
 """
@@ -63,7 +66,35 @@ def parse():
                     help="multi-rank exchange of the hit records: 'reads' = every rank gathers and merges its read "
                          "range (all-to-all, result stays distributed), 'root' = everything to rank 0")
     ap.add_argument("--cpu-sample-bases", type=int, default=192_000_000)
+    ap.add_argument("--master-port", type=int, default=None, help="rendezvous port when bench.py starts the ranks itself")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch check without a GPU: the ranks form the process group (gloo with --rehearse), all-reduce "
+                         "once, rank 0 prints a JSON line saying what the communicator reported")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start one rank per GPU with
+    torch.distributed.run as a CHILD process (this process has not touched a GPU and never will), relay the child's
+    JSON line and exit with its code."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if port is None:
+        with socket.socket() as sck:
+            sck.bind(("127.0.0.1", 0))
+            port = sck.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [l for l in child.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1])
+    sys.stdout.flush()
+    raise SystemExit(child.returncode if child.returncode or lines else 1)
 
 
 def cpu_baseline(total_bases, max_mm, sample_bases, target_s=7.0):
@@ -145,6 +176,8 @@ def sort_roofline(timing_sums, steps):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     # stdout carries exactly one line, the JSON result: everything else that might write to fd 1
     # (RCCL prints a banner there) is sent to stderr
     sys.stdout.flush()
@@ -158,6 +191,18 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.dry_run:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("gloo" if args.rehearse or not torch.cuda.is_available() else "nccl", rank=rank, world_size=world)
+        one = torch.ones(1, dtype=torch.float64, device="cuda:%d" % local_rank if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(one)
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"dry_run": True, "n_gpus": args.gpus, "rccl_ranks": dist.get_world_size(),
+                                           "backend": dist.get_backend(), "ranks_seen": int(one.item())}) + "\n").encode())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     import varscot_amd as va
     from varscot_amd import synth
     from varscot_amd import dist as vdist
@@ -253,13 +298,20 @@ def main():
         for k in T_MAX:
             acc[k] = max(acc[k], t[k])
 
+    mode = {"exchange": args.exchange}   # which exchange the step functions use (both are timed when N > 1)
+    X_KEYS = ("search_ms", "pack_ms", "exchange_ms", "merge_ms", "sent_bytes", "received_bytes")
+    xacc = dict.fromkeys(X_KEYS, 0.0)    # host wall times / bytes of this rank's exchanges, summed over the timed steps
+
     def search_batch(batch_codes, acc):
         if not use_dist:
             h = genome.search(batch_codes, max_mm, algorithm=algorithm)
             add_timing(acc, ctx.timing())
             return h, None
+        st = {}
         merged, local = vdist.sharded_search(ctx, genome, batch_codes, max_mm, device=xdev, algorithm=algorithm,
-                                             exchange=args.exchange)
+                                             exchange=mode["exchange"], stats=st)
+        for k in X_KEYS:
+            xacc[k] += st[k]
         add_timing(acc, ctx.timing())
         return local, merged
 
@@ -295,15 +347,16 @@ def main():
             local, merged = search_batch(codes[b:b + args.batch], acc)
             local.packed_features(to_host=False, mit=False)
             acc["score_ms"] += ctx.timing()["score_ms"]
-            total += len(merged)
+            total += len(merged) if merged is not None else 0
             local.close()
-            merged.close()
+            if merged is not None:
+                merged.close()
         return [], total, acc
 
     def step():
         if args.workload == "c4":
             return step_c4()
-        if pipelined:
+        if pipelined and mode.get("pipelined"):
             return step_pipelined()
         if streamed:
             return step_streamed()
@@ -311,27 +364,62 @@ def main():
         h, m = search_batch(codes, acc)
         return [x for x in (h, m) if x is not None], len(m) if m is not None else len(h), acc
 
-    for i in range(args.warmup):
-        objs, _, _ = step()
-        for o in objs:
-            o.close()
-    barrier()
-    sums = new_acc()
-    total_hits = 0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        objs, total_hits, acc = step()
-        add_timing(sums, acc, score=True)
-        for o in objs:
-            o.close()
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed_run():
+        """W untimed steps, then exactly K steps between barriers; max over ranks."""
+        for i in range(args.warmup):
+            objs, _, _ = step()
+            for o in objs:
+                o.close()
+        barrier()
+        for k in X_KEYS:
+            xacc[k] = 0.0
+        sums, total_hits = new_acc(), 0
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            objs, total_hits, acc = step()
+            add_timing(sums, acc, score=True)
+            for o in objs:
+                o.close()
+        barrier()
+        dt = time.perf_counter() - t0
+        x = dict(xacc)
+        if use_dist:
+            tt = torch.tensor([dt] + [x[k] for k in X_KEYS[:4]], dtype=torch.float64, device=xdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            bb = torch.tensor([x["sent_bytes"], x["received_bytes"]], dtype=torch.float64, device=xdev)
+            dist.all_reduce(bb, op=dist.ReduceOp.SUM)
+            dt = float(tt[0].item())
+            for i, k in enumerate(X_KEYS[:4]):
+                x[k] = float(tt[1 + i].item())
+            x["sent_bytes"], x["received_bytes"] = float(bb[0].item()), float(bb[1].item())
+        return dt, sums, total_hits, x
+
+    exchanges = None
+    if use_dist:
+        # both shapes of the one exchange, K steps each (plain: search, pack, exchange, merge, one after the other)
+        exchanges = {}
+        for ex in (("root", "reads") if args.exchange == "reads" else ("reads", "root")):
+            mode.update(exchange=ex, pipelined=False)
+            dt_x, sums_x, hits_x, x = timed_run()
+            exchanges[ex] = {
+                "value": n_guides * args.steps / dt_x, "unit": "guides/s", "ms_per_step": dt_x / args.steps * 1e3,
+                "search_wall_ms": x["search_ms"] / args.steps, "pack_ms": x["pack_ms"] / args.steps,
+                "exchange_ms": x["exchange_ms"] / args.steps, "merge_ms": x["merge_ms"] / args.steps,
+                "exchanged_bytes": x["sent_bytes"] / args.steps,
+                "record_bytes": vdist.XREC_BYTES,
+                "result": "all records on rank 0" if ex == "root" else "every rank holds the merged records of its read range",
+                "note": "host wall times per step, max over ranks; exchanged_bytes = bytes that left a rank, summed over ranks"}
+            keep = (dt_x, sums_x, hits_x)
+        mode.update(exchange=args.exchange, pipelined=True)
+        if pipelined:
+            dt, sums, total_hits, _ = timed_run()   # the headline: --exchange reads with the exchange of one piece
+        else:                                       # hidden behind the search of the next
+            dt, sums, total_hits = keep             # (the last plain run was --exchange's)
+    else:
+        dt, sums, total_hits, _ = timed_run()
     hits_local, sites_local, passes = sums["hits"] // args.steps, sums["sites"], sums["passes"]
     pairs_local, stream_bytes = sums["pairs"] // args.steps, sums["genome_bytes"] // args.steps
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
         # every rank holds a part of the result (exchange = reads) or rank 0 holds it all (root): sum of the shard hits
         agg = torch.tensor([float(sites_local), float(hits_local)], dtype=torch.float64, device=xdev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
@@ -383,6 +471,8 @@ def main():
                        "max_mismatches": max_mm, "parallelism": "genome-shard x%d" % world, "algorithm": algorithm,
                        "multi_gpu_path": ("torch.distributed (RCCL) one process per GPU: varscot_amd/dist.py" if use_dist else None),
                        "exchange": (args.exchange if use_dist else None), "sub_batches": (sub_batches if pipelined else 1),
+                       "rccl_ranks": (dist.get_world_size() if use_dist else None),
+                       "backend": (dist.get_backend() if use_dist else None),
                        "hits_per_step": int(total_hits), "candidate_sites_per_s": total_hits * args.steps / dt,
                        "pam_valid_sites": int(total_sites), "search_launches": passes, "read_passes": read_passes,
                        "batch": args.batch if streamed else n_guides, "variant_genome": snp_info},
@@ -406,6 +496,10 @@ def main():
                            "score": (sums["score_ms"] / args.steps) if streamed else None},
             "setup": {"genome_generate_s": t_gen, "genome_hbm_bytes": genome.device_bytes, "index_build_ms": index_ms},
         }
+        if exchanges is not None:
+            out["exchanges"] = exchanges
+            out["exchange_ms"] = exchanges[args.exchange]["exchange_ms"]
+            out["exchanged_bytes"] = exchanges[args.exchange]["exchanged_bytes"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(total_bases, max_mm, args.cpu_sample_bases)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

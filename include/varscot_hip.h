@@ -225,6 +225,24 @@ int vsc_hits_copy(vsc_hits *hits, void *dst, int dst_is_device);
  */
 int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, const uint64_t *shard_counts,
                    uint32_t n_shards, uint32_t n_guides, vsc_hits **out);
+/*
+ * The same merge over the 8-byte EXCHANGE RECORDS - what the multi-GPU drivers send over xGMI instead of the
+ * 16-byte vsc_hit: bits 0..22 mismatch mask | bits 23..54 global position (contig offset + pos).  Guide and strand
+ * are not sent: a shard's records are sorted by key = guide << 1 | strand, so 4 bytes per key (key_counts) say which
+ * records belong to which key; NM is the popcount of the mask; the contig follows from the global position.
+ *   vsc_hits_pack_exchange  writes vsc_hits_count(hits) records (device memory when records_on_device != 0, e.g. a
+ *                           tensor handed to RCCL) and the 2 * n_guides per-key record counts (host memory).
+ *   vsc_hits_merge_packed   records = the exchange records of shard 0, shard 1, ... concatenated, each shard's for the
+ *                           keys [first_key, first_key + n_keys) only (a receiver may collect just its read range);
+ *                           key_counts[s * n_keys + k] = records of shard s with key first_key + k.  The result holds
+ *                           ordinary vsc_hit records (guide = key >> 1), sorted as vsc_search sorts them; `genome`
+ *                           (any shard of the genome on this context) supplies the contig table.
+ */
+#define VSC_XREC_BYTES 8
+int vsc_hits_pack_exchange(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, uint32_t n_guides, void *records,
+                           int records_on_device, uint32_t *key_counts);
+int vsc_hits_merge_packed(vsc_ctx *ctx, const vsc_genome *genome, const void *records, int records_on_device,
+                          const uint32_t *key_counts, uint32_t n_shards, uint32_t first_key, uint32_t n_keys, vsc_hits **out);
 int vsc_hits_free(vsc_hits *hits);
 
 /*
@@ -276,8 +294,9 @@ int vsc_score_pairs(vsc_ctx *ctx, const uint64_t *on_targets, const uint64_t *of
  * the 8 GPUs of one node by genome shard with a single RCCL gather of candidate hits"): one vsc_ctx per
  * entry of device_ids, the planes cut into n tile-aligned position ranges (+ a one-word halo; a window
  * belongs to the shard that holds its first base), every device searching ALL reads on its shard from its own
- * host thread, then one exchange - the hit counts by ncclAllGather, the records by one grouped
- * ncclSend / ncclRecv per shard to the first device, over xGMI - and vsc_hits_merge there.  The result is an
+ * host thread, then one exchange - the hit counts by ncclAllGather, the records (8-byte exchange records,
+ * vsc_hits_pack_exchange) by one grouped ncclSend / ncclRecv per shard to the first device, over xGMI - and
+ * vsc_hits_merge_packed there.  The result is an
  * ordinary vsc_hits of the first context (vsc_multi_ctx(m, 0)): same records, same order as one device gives.
  * This replaces, inside the bidir_mapping process, the OpenMP loop over reads and the concatenation of the
  * per-thread output buffers (read_mapping/bidir_mapping.cpp:285-295,307-308): the parallel axis is the genome.

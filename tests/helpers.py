@@ -156,3 +156,38 @@ def plant_reference_sites(rows):
         contigs.append("TTTT" + (revcomp(site) if s else site) + ("AAAA" if s else "TTTT"))
         strands.append(s)
     return contigs, strands
+
+
+# ---- the 8-byte exchange record of the multi-GPU drivers (include/varscot_hip.h: vsc_hits_pack_exchange) in numpy:
+# what the GPU kernels xpack_kernel / merge_packed_kernel do, restated for the CPU-only tests of the exchange code
+def xpack(hits, contig_offsets, n_reads):
+    """(uint64 records: mask | global position << 23, uint32[2 * n_reads] per-key counts) of sorted vsc_hit records."""
+    gpos = contig_offsets[hits["contig"]].astype(np.uint64) + hits["pos"].astype(np.uint64)
+    rec = (gpos << np.uint64(23)) | (hits["info"] & np.uint32(0x7FFFFF)).astype(np.uint64)
+    key = (hits["guide"].astype(np.int64) << 1) | (hits["info"] >> 31)
+    return rec, np.bincount(key, minlength=2 * n_reads).astype(np.uint32)
+
+
+def xmerge(records, key_counts, first_key, contig_offsets):
+    """vsc_hit records from the concatenated exchange records of all shards (key_counts: [n_shards, n_keys])."""
+    HIT = np.dtype([("guide", "<u4"), ("contig", "<u4"), ("pos", "<u4"), ("info", "<u4")])
+    n_shards, n_keys = key_counts.shape
+    starts = np.concatenate([[0], np.cumsum(key_counts.astype(np.int64).ravel())])  # shard-major, key-minor
+    out = np.zeros(len(records), dtype=HIT)
+    at = 0
+    for k in range(n_keys):
+        for s in range(n_shards):
+            a = starts[s * n_keys + k]
+            n = int(key_counts[s, k])
+            r = records[a:a + n]
+            gpos = (r >> np.uint64(23)).astype(np.int64)
+            mask = (r & np.uint64(0x7FFFFF)).astype(np.uint32)
+            c = np.searchsorted(contig_offsets.astype(np.int64), gpos, side="right") - 1
+            key = first_key + k
+            out["guide"][at:at + n] = key >> 1
+            out["contig"][at:at + n] = c
+            out["pos"][at:at + n] = gpos - contig_offsets.astype(np.int64)[c]
+            nm = np.array([bin(int(m)).count("1") for m in mask], dtype=np.uint32)
+            out["info"][at:at + n] = ((key & 1) << 31) | (nm << 23) | mask
+            at += n
+    return out

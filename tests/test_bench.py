@@ -1,0 +1,59 @@
+"""bench.py's launch path: `python bench.py --gpus N` started bare (no launcher environment) brings up the N ranks
+itself - torch.distributed.run as a child process, before anything touches a GPU - and relays rank 0's JSON line.
+CPU: the gloo dry run (process group + one all-reduce).  GPU box: the whole multi-rank step on the one GPU
+(--rehearse: gloo, records through host memory) with both exchanges reported."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=timeout,
+                       env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bare_start_brings_up_the_ranks(n):
+    r, line = _bench("--gpus", str(n), "--rehearse", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line == {"dry_run": True, "n_gpus": n, "rccl_ranks": n, "backend": "gloo", "ranks_seen": n}
+    assert r.stdout.count("{") == 1  # ONE JSON line on stdout
+
+
+def test_a_launchers_environment_is_respected():
+    """Under torch.distributed.run (WORLD_SIZE set) bench.py does not start ranks of its own; a wrong --gpus is an error."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_report_both_exchanges():
+    r, line = _bench("--gpus", "2", "--rehearse", "--workload", "c1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["backend"] == "gloo"
+    ex = line["exchanges"]
+    assert set(ex) == {"root", "reads"}
+    for k in ("root", "reads"):
+        assert ex[k]["value"] > 0 and ex[k]["exchange_ms"] >= 0 and ex[k]["record_bytes"] == 8
+    assert ex["root"]["exchanged_bytes"] > 0 and line["exchange_ms"] == ex[line["config"]["exchange"]]["exchange_ms"]
+    assert line["config"]["hits_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_one_gpu_line_has_the_contract_fields():
+    r, line = _bench("--workload", "c1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-3000:]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in line
+    assert line["n_gpus"] == 1 and "exchanges" not in line

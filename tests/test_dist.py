@@ -42,71 +42,79 @@ def _worker(rank, world, port, seed, q, mode="root"):
     try:
         import varscot_amd as va
         from varscot_amd import dist as vdist
-        from helpers import make_genome, random_guides
+        from helpers import make_genome, random_guides, xpack
         rng = np.random.default_rng(seed)
         guides = random_guides(rng, 12)
         contigs = make_genome(seed, [40000, 15000, 9000, 50], guides, 6, n_plant=300, n_runs=4)
         packed = va.PackedGenome.from_sequences(contigs)
         assert vdist.shard_words(packed.n_words, rank, world) == packed.shard_words(rank, world)
         mine = _shard_hits(contigs, guides, 6, packed, rank, world)
-        local = torch.from_numpy(mine.view(np.uint8).copy())
-        if mode == "reads":
-            received, counts = vdist.exchange_by_reads(local, len(guides))
-            q.put((rank, received.numpy().tobytes(), counts))
-        elif mode == "async":
-            # two exchanges in flight one after the other without waiting in between (what the pipelined
-            # search does): the second is issued while the first may still be travelling
-            r1, c1, q1 = vdist.start_exchange_by_reads(local, len(guides))
-            for req in q1:
-                req.wait()
-            r2, c2, q2 = vdist.start_exchange_by_reads(local, len(guides))
-            for req in q2:
-                req.wait()
-            assert c1 == c2 and r1.numpy().tobytes() == r2.numpy().tobytes()
-            q.put((rank, r2.numpy().tobytes(), c2))
+        # the 8-byte exchange records + per-key counts (on the GPU: vsc_hits_pack_exchange)
+        rec, counts = xpack(mine, packed.contigs["offset"], len(guides))
+        local = torch.from_numpy(rec.view(np.uint8).copy())
+        all_counts = vdist.all_gather_key_counts(counts, None)
+        assert all_counts.shape == (world, 2 * len(guides)) and np.array_equal(all_counts[rank], counts)
+        if mode in ("reads", "async"):
+            # "async": two exchanges one after the other without a barrier in between (what the pipelined search does)
+            for _ in range(2 if mode == "async" else 1):
+                recv, part_counts, k0, reqs = vdist.start_exchange_by_reads(local, all_counts, len(guides))
+                for req in reqs:
+                    req.wait()
+            q.put((rank, recv.numpy().tobytes(), part_counts, k0))
         else:
-            gathered, counts = vdist.gather_records(local)
+            recv, reqs = vdist.start_gather_to_root(local, all_counts)
+            for req in reqs:
+                req.wait()
             if rank == 0:
-                got = gathered.numpy().view(va.HIT_DTYPE)
-                q.put((got.tobytes(), counts))
+                q.put((recv.numpy().tobytes(), all_counts))
             else:
-                assert gathered is None
+                assert recv is None
                 q.put(None)
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gather_records_over_gloo(world, oracle):
+def _case(seed):
     from helpers import make_genome, random_guides
     import varscot_amd as va
-    seed = 900 + world
+    rng = np.random.default_rng(seed)
+    guides = random_guides(rng, 12)
+    contigs = make_genome(seed, [40000, 15000, 9000, 50], guides, 6, n_plant=300, n_runs=4)
+    return guides, contigs, va.PackedGenome.from_sequences(contigs)
+
+
+def _run(world, seed, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    payload = [r for r in results if r is not None]
+    return results
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_to_root_over_gloo(world, oracle):
+    """exchange="root" (the north star's single gather): rank 0 receives every shard's 8-byte exchange records in
+    shard order; rebuilding the 16-byte records from them and the all-gathered per-key counts (what
+    vsc_hits_merge_packed does on the GPU, restated in helpers.xmerge) gives the global result."""
+    from helpers import xmerge
+    seed = 900 + world
+    payload = [r for r in _run(world, seed, "root") if r is not None]
     assert len(payload) == 1
-    blob, counts = payload[0]
-    got = np.frombuffer(blob, dtype=va.HIT_DTYPE)
-    # expected: shard lists concatenated in rank order; a stable sort on (guide, strand) of that
-    # concatenation (what vsc_hits_merge does on the GPU) must give the global result order
-    rng = np.random.default_rng(seed)
-    guides = random_guides(rng, 12)
-    contigs = make_genome(seed, [40000, 15000, 9000, 50], guides, 6, n_plant=300, n_runs=4)
-    packed = va.PackedGenome.from_sequences(contigs)
+    blob, all_counts = payload[0]
+    guides, contigs, packed = _case(seed)
     shards = [_shard_hits(contigs, guides, 6, packed, r, world) for r in range(world)]
-    assert counts == [len(s) for s in shards] and sum(counts) > 50 and min(counts) > 0
-    assert got.tobytes() == np.concatenate(shards).tobytes()
-    key = (got["guide"].astype(np.int64) << 1) | (got["info"] >> 31)
-    merged = got[np.argsort(key, kind="stable")]
+    totals = all_counts.astype(np.int64).sum(axis=1)
+    assert list(totals) == [len(s) for s in shards] and totals.sum() > 50 and totals.min() > 0
+    got = np.frombuffer(blob, dtype=np.uint64)
+    assert len(got) * 8 == 8 * totals.sum()  # half of what 16-byte records would have cost
+    merged = xmerge(got, all_counts, 0, packed.contigs["offset"])
     whole = oracle.search_fast(contigs, guides, 6)
     assert merged.tobytes() == whole.tobytes()
 
@@ -114,36 +122,22 @@ def test_gather_records_over_gloo(world, oracle):
 @pytest.mark.parametrize("mode", ["reads", "async"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_exchange_by_reads_over_gloo(world, oracle, mode):
-    """exchange="reads": every rank ends up with the records of its read range from all genome shards, in
+    """exchange="reads": every rank ends up with the exchange records of its read range from all genome shards, in
     shard order; merging each rank's part and concatenating the ranks gives the global result."""
-    from helpers import make_genome, random_guides
-    import varscot_amd as va
+    from helpers import xmerge
     from varscot_amd import dist as vdist
     seed = 950 + world
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, q, mode)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = sorted(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    rng = np.random.default_rng(seed)
-    guides = random_guides(rng, 12)
-    contigs = make_genome(seed, [40000, 15000, 9000, 50], guides, 6, n_plant=300, n_runs=4)
-    packed = va.PackedGenome.from_sequences(contigs)
-    shards = [_shard_hits(contigs, guides, 6, packed, r, world) for r in range(world)]
-    parts = []
-    for rank, blob, counts in results:
-        got = np.frombuffer(blob, dtype=va.HIT_DTYPE)
-        b, e = vdist.read_range(len(guides), rank, world)
-        want = [s[(s["guide"] >= b) & (s["guide"] < e)] for s in shards]
-        assert counts == [len(x) for x in want]
-        assert got.tobytes() == np.concatenate(want).tobytes()
-        key = (got["guide"].astype(np.int64) << 1) | (got["info"] >> 31)
-        parts.append(got[np.argsort(key, kind="stable")])  # what vsc_hits_merge does on the GPU
+    results = sorted(_run(world, seed, mode), key=lambda r: r[0])
+    guides, contigs, packed = _case(seed)
     whole = oracle.search_fast(contigs, guides, 6)
     assert len(whole) > 50
+    parts = []
+    for rank, blob, part_counts, k0 in results:
+        b, e = vdist.read_range(len(guides), rank, world)
+        assert k0 == 2 * b and part_counts.shape == (world, 2 * (e - b))
+        got = np.frombuffer(blob, dtype=np.uint64)
+        merged = xmerge(got, part_counts, k0, packed.contigs["offset"])
+        want = whole[(whole["guide"] >= b) & (whole["guide"] < e)]
+        assert merged.tobytes() == want.tobytes()
+        parts.append(merged)
     assert np.concatenate(parts).tobytes() == whole.tobytes()

@@ -9,7 +9,7 @@ import torch
 
 import varscot_amd as va
 from varscot_amd import synth
-from varscot_amd.dist import _DeviceAlias
+from varscot_amd.dist import DeviceAlias as _DeviceAlias
 
 pytestmark = pytest.mark.gpu
 

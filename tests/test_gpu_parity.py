@@ -511,6 +511,63 @@ def test_shard_merge_kernels(ctx, oracle, world):
     assert got.tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_exchange_records_pack_and_merge(ctx, oracle, world):
+    """vsc_hits_pack_exchange / vsc_hits_merge_packed (what both multi-GPU drivers send and rebuild): every shard's
+    result packed to 8-byte records + per-key counts (device and host destinations agree with the numpy restatement),
+    then merged - whole key range on one receiver (exchange="root"), and per read range (exchange="reads") - with an
+    empty shard, reads without hits and many keys; > 1 contig so that the contig is recovered from the position."""
+    import torch
+    from helpers import xpack
+    from varscot_amd.api import merge_packed_records
+    rng = np.random.default_rng(160 + world)
+    guides = random_guides(rng, 40)
+    contigs = make_genome(160 + world, [60000, 20000, 33, 5000], guides[:25], 6, n_plant=300, n_runs=3)
+    packed = va.PackedGenome.from_sequences(contigs)
+    recs, counts, any_shard = [], [], None
+    for rank in range(world):
+        b, e = packed.shard_words(rank, world)
+        if e <= b:
+            recs.append(np.zeros(0, dtype=np.uint64))
+            counts.append(np.zeros(2 * len(guides), dtype=np.uint32))
+            continue
+        gen = ctx.load_genome(packed, rank, world)
+        h = gen.search(guides, 6)
+        host = np.zeros(len(h), dtype=np.uint64)
+        c_host = h.pack_exchange(host.ctypes.data if len(h) else 0, False)
+        dev = torch.empty(max(len(h), 1) * 8, dtype=torch.uint8, device="cuda")
+        c_dev = h.pack_exchange(dev.data_ptr(), True)
+        want_rec, want_counts = xpack(h.to_numpy(), packed.contigs["offset"], len(guides))
+        assert np.array_equal(c_host, want_counts) and np.array_equal(c_dev, want_counts)
+        assert np.array_equal(host, want_rec) and np.array_equal(dev.cpu().numpy().view(np.uint64)[:len(h)], want_rec)
+        recs.append(host)
+        counts.append(c_host)
+        h.close()
+        if any_shard is None:
+            any_shard = gen
+        else:
+            gen.close()
+    recs.insert(1, np.zeros(0, dtype=np.uint64))  # an empty shard in the middle
+    counts.insert(1, np.zeros(2 * len(guides), dtype=np.uint32))
+    want = oracle.search_fast(contigs, guides, 6)
+    assert len(want) > 200 and len(set(want["contig"])) > 1
+    cat = np.ascontiguousarray(np.concatenate(recs))
+    all_counts = np.stack(counts)
+    merged = merge_packed_records(ctx, any_shard, cat.ctypes.data, False, all_counts)
+    assert merged.to_numpy().tobytes() == want.tobytes()
+    merged.close()
+    # a receiver that collects only the reads [11, 29): the slices of every shard for those keys
+    k0, k1 = 22, 58
+    prefix = np.concatenate([np.zeros((len(recs), 1), dtype=np.int64), np.cumsum(all_counts.astype(np.int64), axis=1)], axis=1)
+    part = np.ascontiguousarray(np.concatenate([r[prefix[s, k0]:prefix[s, k1]] for s, r in enumerate(recs)]))
+    dev = torch.from_numpy(part.view(np.uint8).copy()).cuda()
+    merged = merge_packed_records(ctx, any_shard, dev.data_ptr(), True, all_counts[:, k0:k1], first_key=k0)
+    sel = want[(want["guide"] >= 11) & (want["guide"] < 29)]
+    assert merged.to_numpy().tobytes() == sel.tobytes()
+    merged.close()
+    any_shard.close()
+
+
 @pytest.fixture
 def hooks(ctx):
     """ctx.set_debug(...) for one test (include/varscot_hip_debug.h); the defaults come back afterwards."""

@@ -297,6 +297,15 @@ class Hits:
         """Copy the records to caller memory (e.g. the data_ptr() of a uint8 tensor handed to RCCL)."""
         check(lib().vsc_hits_copy(self._h, C.c_void_p(dst_ptr), int(bool(dst_is_device))), self.ctx._h)
 
+    def pack_exchange(self, dst_ptr, dst_is_device):
+        """vsc_hits_pack_exchange: the records as 8-byte exchange records into caller memory (len(self) * 8 bytes,
+        e.g. the data_ptr() of a uint8 tensor handed to RCCL); returns the per-key record counts
+        (uint32[2 * reads], key = read << 1 | strand)."""
+        counts = np.zeros(2 * len(self.codes), dtype=np.uint32)
+        check(lib().vsc_hits_pack_exchange(self.ctx._h, self.genome._h, self._h, len(self.codes), C.c_void_p(dst_ptr),
+                                           int(bool(dst_is_device)), ptr(counts)), self.ctx._h)
+        return counts
+
     def scores(self, first=0, count=None, mit=True, features=False):
         """(mit float64[count] | None, mit_flags uint8[count] | None, features uint8[count,442] | None)."""
         count = len(self) - first if count is None else count
@@ -358,6 +367,18 @@ def merge_shard_records(ctx, records_ptr, on_device, shard_counts, n_guides):
     h = C.c_void_p()
     check(lib().vsc_hits_merge(ctx._h, C.c_void_p(records_ptr), int(bool(on_device)), ptr(counts), len(counts), n_guides,
                                C.byref(h)), ctx._h)
+    return MergedHits(ctx, h)
+
+
+def merge_packed_records(ctx, genome, records_ptr, on_device, key_counts, first_key=0):
+    """vsc_hits_merge_packed: records_ptr = the 8-byte exchange records of all shards concatenated in shard order,
+    key_counts = uint32[n_shards, n_keys] (records of shard s with key first_key + k); `genome` = any shard of the
+    genome on `ctx` (contig table).  Returns the merged vsc_hit records (guide = key >> 1)."""
+    kc = np.ascontiguousarray(key_counts, dtype=np.uint32)
+    assert kc.ndim == 2
+    h = C.c_void_p()
+    check(lib().vsc_hits_merge_packed(ctx._h, genome._h, C.c_void_p(records_ptr), int(bool(on_device)), ptr(kc), kc.shape[0],
+                                      int(first_key), kc.shape[1], C.byref(h)), ctx._h)
     return MergedHits(ctx, h)
 
 

@@ -297,6 +297,38 @@ int vsc_genome_load(vsc_ctx *ctx, const uint32_t *hi, const uint32_t *lo, const 
     return VSC_OK;
 }
 
+}  // extern "C"
+
+int vsc::genome_table_only(vsc_ctx *ctx, const vsc_contig *contigs, uint32_t n_contigs, vsc_genome **out)
+{
+    if (!ctx || !out || !contigs || n_contigs == 0) return VSC_ERR_INVALID;
+    *out = nullptr;
+    std::vector<uint32_t> off(n_contigs), end(n_contigs);
+    for (uint32_t c = 0; c < n_contigs; ++c) {
+        off[c] = (uint32_t)contigs[c].offset;
+        end[c] = (uint32_t)(contigs[c].offset + contigs[c].length);
+    }
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    vsc_genome *g = new (std::nothrow) vsc_genome();
+    if (!g) return fail(ctx, VSC_ERR_NOMEM, "out of host memory");
+    g->ctx = ctx;
+    g->n_contigs = n_contigs;
+    const size_t cb = (size_t)n_contigs * sizeof(uint32_t);
+    hipError_t e = hipMalloc((void **)&g->d_contig_off, cb);
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_contig_end, cb);
+    if (e == hipSuccess) e = hipMemcpy(g->d_contig_off, off.data(), cb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->d_contig_end, end.data(), cb, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        vsc_genome_free(g);
+        return fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, "contig table upload", e);
+    }
+    g->device_bytes = 2 * cb;
+    *out = g;
+    return VSC_OK;
+}
+
+extern "C" {
+
 int vsc_genome_free(vsc_genome *g)
 {
     if (!g) return VSC_OK;
@@ -1384,6 +1416,116 @@ int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, con
     if (e != hipSuccess) {
         vsc_hits_free(hits);
         return fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, "vsc_hits_merge", e);
+    }
+    *out = hits;
+    return VSC_OK;
+}
+
+int vsc_hits_pack_exchange(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, uint32_t n_guides, void *records,
+                           int records_on_device, uint32_t *key_counts)
+{
+    if (!ctx) return VSC_ERR_INVALID;
+    ctx->err.clear();
+    if (!genome || !hits || genome->ctx != ctx || hits->ctx != ctx || (n_guides && !key_counts) || (hits->n && !records))
+        return fail(ctx, VSC_ERR_INVALID, "vsc_hits_pack_exchange: null argument or object of another context");
+    if (n_guides >= (1u << 30)) return fail(ctx, VSC_ERR_RANGE, "vsc_hits_pack_exchange: too many reads");
+    const uint32_t K = 2 * n_guides;
+    const uint64_t n = hits->n;
+    if (n == 0) {
+        std::fill(key_counts, key_counts + K, 0u);
+        return VSC_OK;
+    }
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    VSC_HIP(ctx, ctx->sort_tabs.ensure(((size_t)K + 1 + 2) * sizeof(uint64_t)));
+    uint64_t *d_bound = (uint64_t *)ctx->sort_tabs.p, *d_range = d_bound + K + 1;
+    const uint64_t range[2] = {0, n};
+    VSC_HIP(ctx, hipMemcpyAsync(d_range, range, sizeof range, hipMemcpyHostToDevice, ctx->stream));
+    VSC_HIP(ctx, launch_key_bounds(hits->d_records, d_range, K, d_bound, ctx->stream));
+    uint64_t *dst = (uint64_t *)records;
+    if (!records_on_device) {
+        VSC_HIP(ctx, ctx->score_feat.ensure(n * sizeof(uint64_t)));
+        dst = (uint64_t *)ctx->score_feat.p;
+    }
+    VSC_HIP(ctx, launch_xpack(hits->d_records, n, genome->d_contig_off, dst, ctx->stream));
+    std::vector<uint64_t> bound((size_t)K + 1);
+    VSC_HIP(ctx, hipMemcpyAsync(bound.data(), d_bound, bound.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (!records_on_device) VSC_HIP(ctx, hipMemcpyAsync(records, dst, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bound[0] != 0 || bound[K] != n) return fail(ctx, VSC_ERR_INVALID, "vsc_hits_pack_exchange: the result holds reads beyond n_guides");
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint64_t c = bound[k + 1] - bound[k];
+        if (c >= (1ull << 32)) return fail(ctx, VSC_ERR_RANGE, "vsc_hits_pack_exchange: more than 2^32 hits of one read and strand");
+        key_counts[k] = (uint32_t)c;
+    }
+    return VSC_OK;
+}
+
+int vsc_hits_merge_packed(vsc_ctx *ctx, const vsc_genome *genome, const void *records, int records_on_device, const uint32_t *key_counts,
+                          uint32_t n_shards, uint32_t first_key, uint32_t n_keys, vsc_hits **out)
+{
+    if (!ctx || !out) return VSC_ERR_INVALID;
+    *out = nullptr;
+    ctx->err.clear();
+    if (!genome || genome->ctx != ctx || n_shards == 0 || (n_keys && !key_counts))
+        return fail(ctx, VSC_ERR_INVALID, "vsc_hits_merge_packed: null argument or genome of another context");
+    if ((uint64_t)first_key + n_keys > (1ull << 31) || (uint64_t)n_keys * n_shards >= (1ull << 31))
+        return fail(ctx, VSC_ERR_RANGE, "vsc_hits_merge_packed: too many keys");
+    // where every (key, shard) segment lies in the concatenation of the shards' records, and where it goes
+    const size_t n_segs = (size_t)n_keys * n_shards;
+    std::vector<uint64_t> seg_src(n_segs), seg_dst(n_segs);
+    std::vector<uint32_t> seg_n(n_segs);
+    uint64_t at = 0;
+    for (uint32_t s = 0; s < n_shards; ++s)
+        for (uint32_t k = 0; k < n_keys; ++k) {
+            seg_src[(size_t)k * n_shards + s] = at;
+            at += key_counts[(size_t)s * n_keys + k];
+        }
+    const uint64_t n = at;
+    at = 0;
+    for (uint32_t k = 0; k < n_keys; ++k)
+        for (uint32_t s = 0; s < n_shards; ++s) {
+            const size_t seg = (size_t)k * n_shards + s;
+            seg_n[seg] = key_counts[(size_t)s * n_keys + k];
+            seg_dst[seg] = at;
+            at += seg_n[seg];
+        }
+    if (n && !records) return fail(ctx, VSC_ERR_INVALID, "vsc_hits_merge_packed: null records");
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    vsc_hits *hits = new (std::nothrow) vsc_hits();
+    if (!hits) return fail(ctx, VSC_ERR_NOMEM, "vsc_hits_merge_packed: out of host memory");
+    hits->ctx = ctx;
+    hits->n = n;
+    if (n == 0) {
+        hits->host_valid = true;
+        *out = hits;
+        return VSC_OK;
+    }
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+    };
+    const size_t tab_bytes = n_segs * (2 * sizeof(uint64_t) + sizeof(uint32_t));
+    step(ctx->keys_b.ensure(tab_bytes));
+    step(take_records(ctx, hits, n));
+    const uint64_t *records_dev = (const uint64_t *)records;
+    if (!records_on_device) {
+        step(ctx->score_feat.ensure(n * sizeof(uint64_t)));  // staging buffer for host input
+        if (e == hipSuccess) step(hipMemcpyAsync(ctx->score_feat.p, records, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        records_dev = (const uint64_t *)ctx->score_feat.p;
+    }
+    uint64_t *d_src = (uint64_t *)ctx->keys_b.p, *d_dst = d_src + n_segs;
+    uint32_t *d_n = (uint32_t *)(d_dst + n_segs);
+    if (e == hipSuccess) {
+        step(hipMemcpyAsync(d_src, seg_src.data(), n_segs * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        step(hipMemcpyAsync(d_dst, seg_dst.data(), n_segs * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        step(hipMemcpyAsync(d_n, seg_n.data(), n_segs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        step(launch_merge_packed(records_dev, d_src, d_dst, d_n, (uint32_t)n_segs, n_shards, first_key, genome->d_contig_off,
+                                 genome->n_contigs, hits->d_records, ctx->stream));
+        step(hipStreamSynchronize(ctx->stream));  // (the host tables go out of scope)
+    }
+    if (e != hipSuccess) {
+        vsc_hits_free(hits);
+        return fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, "vsc_hits_merge_packed", e);
     }
     *out = hits;
     return VSC_OK;

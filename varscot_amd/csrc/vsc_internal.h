@@ -254,6 +254,13 @@ hipError_t launch_score_schedule(const ScoreArgs &args, uint32_t g_lo, uint32_t 
                                  uint64_t *bounds, uint64_t *seg_start, uint64_t *seg_prefix, hipStream_t stream);
 hipError_t launch_score_pairs(const uint2 *on, const uint2 *off, const uint32_t *masks, uint64_t n, double *mit,
                               uint8_t *mit_flags, uint8_t *features, hipStream_t stream);
+// 8-byte exchange records (vsc_hits_pack_exchange / vsc_hits_merge_packed)
+hipError_t launch_xpack(const vsc_hit *in, uint64_t n, const uint32_t *contig_off, uint64_t *out, hipStream_t stream);
+// bound[k] = first record of in[range_dev[0] .. range_dev[1]) whose key (guide << 1 | strand) is >= k, k = 0 .. K
+hipError_t launch_key_bounds(const vsc_hit *in, const uint64_t *range_dev, uint32_t K, uint64_t *bound, hipStream_t stream);
+hipError_t launch_merge_packed(const uint64_t *in, const uint64_t *seg_src, const uint64_t *seg_dst, const uint32_t *seg_n,
+                               uint32_t n_segs, uint32_t n_shards, uint32_t first_key, const uint32_t *contig_off, uint32_t n_contigs,
+                               vsc_hit *out, hipStream_t stream);
 // *out += fingerprint of words [0, n_words) of the three planes (zero *out first)
 hipError_t launch_plane_hash(const uint32_t *hi, const uint32_t *lo, const uint32_t *nm, uint64_t n_words, unsigned long long *out,
                              hipStream_t stream);

@@ -373,6 +373,66 @@ hipError_t launch_merge(const vsc_hit *in, const uint64_t *shard_off_dev, uint32
     return hipGetLastError();
 }
 
+// ---- the 8-byte exchange record (multi-GPU) -------------------------------------------------------------------
+// What crosses xGMI per hit: mask (bits 0..22) | global position = contig offset + pos (bits 23..54).  Guide and strand
+// are not sent: the sender's records are sorted by (guide, strand), so one count per key (guide << 1 | strand) -
+// 8 bytes per read instead of 8 bytes per hit - says which records belong to which key; NM is the popcount of the
+// mask; the contig follows from the global position.  The receiver's merge kernel rebuilds the 16-byte vsc_hit.
+__global__ __launch_bounds__(256) void xpack_kernel(const vsc_hit *in, uint64_t n, const uint32_t *contig_off, uint64_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 r = ((const uint4 *)in)[i];  // {guide, contig, pos, info}
+    out[i] = ((uint64_t)(contig_off[r.y] + r.z) << kRecPosShift) | VSC_HIT_MASK(r.w);
+}
+
+// one workgroup per (key, shard) segment: seg = k * n_shards + s; records [seg_src, seg_src + seg_n) of `in` become
+// vsc_hit records [seg_dst, ...) of `out` with guide / strand of key first_key + k
+__global__ __launch_bounds__(256) void merge_packed_kernel(const uint64_t *in, const uint64_t *seg_src, const uint64_t *seg_dst,
+                                                           const uint32_t *seg_n, uint32_t n_shards, uint32_t first_key,
+                                                           const uint32_t *contig_off, uint32_t n_contigs, vsc_hit *out)
+{
+    const uint32_t seg = blockIdx.x;
+    const uint32_t n = seg_n[seg];
+    if (n == 0) return;
+    const uint32_t key = first_key + seg / n_shards;
+    const uint64_t src = seg_src[seg], dst = seg_dst[seg];
+    uint4 *o = (uint4 *)out;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t x = in[src + i];
+        const uint32_t gpos = (uint32_t)(x >> kRecPosShift), mask = (uint32_t)x & kMask23;
+        uint32_t lo = 0, hi = n_contigs;  // last contig that starts at or before gpos
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (contig_off[mid] <= gpos) lo = mid; else hi = mid;
+        }
+        o[dst + i] = make_uint4(key >> 1, lo, gpos - contig_off[lo], ((key & 1u) << 31) | ((uint32_t)__popc(mask) << 23) | mask);
+    }
+}
+
+hipError_t launch_xpack(const vsc_hit *in, uint64_t n, const uint32_t *contig_off, uint64_t *out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(xpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, n, contig_off, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_key_bounds(const vsc_hit *in, const uint64_t *range_dev, uint32_t K, uint64_t *bound, hipStream_t stream)
+{
+    hipLaunchKernelGGL(merge_bounds_kernel, dim3((unsigned)((K + 1 + 255) / 256)), dim3(256), 0, stream, in, range_dev, 1u, K, bound);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_packed(const uint64_t *in, const uint64_t *seg_src, const uint64_t *seg_dst, const uint32_t *seg_n,
+                               uint32_t n_segs, uint32_t n_shards, uint32_t first_key, const uint32_t *contig_off, uint32_t n_contigs,
+                               vsc_hit *out, hipStream_t stream)
+{
+    if (n_segs == 0) return hipSuccess;
+    hipLaunchKernelGGL(merge_packed_kernel, dim3(n_segs), dim3(256), 0, stream, in, seg_src, seg_dst, seg_n, n_shards, first_key,
+                       contig_off, n_contigs, out);
+    return hipGetLastError();
+}
+
 // Fingerprint of the resident planes (index files name the genome they belong to): the sum, over all words of all
 // three planes, of a 64-bit mix of (word, plane, index) - commutative, so that the order in which workgroups add
 // their partial sums does not matter, and sensitive to every bit and to where it stands.

@@ -83,7 +83,8 @@ struct vsc_multi {
     bool use_rccl = false;
     Rccl rccl;
     std::vector<ncclComm_t> comm;
-    DeviceBuf gather;                   // on device[0]: the records of all shards in shard order
+    DeviceBuf gather;                   // on device[0]: the exchange records of all shards in shard order
+    std::vector<DeviceBuf> xbuf;        // per context: its shard's 8-byte exchange records
     std::string err;
     vsc_multi_timing timing{};
 };
@@ -91,6 +92,7 @@ struct vsc_multi {
 struct vsc_multi_genome {
     vsc_multi *multi = nullptr;
     std::vector<vsc_genome *> shard;    // null: the shard owns no words of this (small) genome
+    vsc_genome *table0 = nullptr;       // the contig table on the first device when shard[0] is null (for the merge)
 };
 
 namespace {
@@ -134,6 +136,7 @@ int vsc_multi_create_debug(const int *device_ids, int n, const vsc_multi_debug_p
     m->ctx.assign(n, nullptr);
     m->xstream.assign(n, nullptr);
     m->d_count.assign(n, nullptr);
+    m->xbuf.assign(n, DeviceBuf{});
     for (int i = 0; i < n; ++i) {
         const int rc = vsc_ctx_create(device_ids[i], &m->ctx[i]);
         if (rc != VSC_OK) {
@@ -194,6 +197,7 @@ int vsc_multi_destroy(vsc_multi *m)
     for (size_t i = 0; i < m->ctx.size(); ++i) {
         (void)hipSetDevice(m->device[i]);
         if (m->d_count[i]) (void)hipFree(m->d_count[i]);
+        if (i < m->xbuf.size()) m->xbuf[i].release();
         if (m->xstream[i]) (void)hipStreamDestroy(m->xstream[i]);
         if (m->ctx[i]) vsc_ctx_destroy(m->ctx[i]);
     }
@@ -240,6 +244,14 @@ int vsc_multi_genome_load(vsc_multi *m, const uint32_t *hi, const uint32_t *lo, 
             vsc_multi_genome_free(g);
             return mfail(m, rc[r], "shard " + std::to_string(r) + ": " + why);
         }
+    if (!g->shard[0]) {
+        const int trc = genome_table_only(m->ctx[0], contigs, n_contigs, &g->table0);
+        if (trc != VSC_OK) {
+            const std::string why = vsc_last_error(m->ctx[0]);
+            vsc_multi_genome_free(g);
+            return mfail(m, trc, "contig table on the first device: " + why);
+        }
+    }
     *out = g;
     return VSC_OK;
 }
@@ -249,6 +261,7 @@ int vsc_multi_genome_free(vsc_multi_genome *g)
     if (!g) return VSC_OK;
     for (vsc_genome *s : g->shard)
         if (s) vsc_genome_free(s);
+    if (g->table0) vsc_genome_free(g->table0);
     delete g;
     return VSC_OK;
 }
@@ -277,55 +290,53 @@ int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *gu
     const size_t n = m->ctx.size();
     using clock = std::chrono::steady_clock;
     const auto t0 = clock::now();
-    // ---- every device searches all reads on its shard ----------------------------------------------------
-    std::vector<vsc_hits *> part(n, nullptr);
-    std::vector<int> rc(n, VSC_OK);
-    on_all(n, [&](size_t r) {
-        if (g->shard[r]) rc[r] = vsc_search(m->ctx[r], g->shard[r], guides, n_guides, params, &part[r]);
-    });
-    auto drop_parts = [&]() {
-        for (vsc_hits *h : part)
-            if (h) vsc_hits_free(h);
-    };
-    for (size_t r = 0; r < n; ++r)
-        if (rc[r] != VSC_OK) {
-            const std::string why = vsc_last_error(m->ctx[r]);
-            drop_parts();
-            return mfail(m, rc[r], "shard " + std::to_string(r) + ": " + why);
-        }
-    const auto t1 = clock::now();
+    // ---- every device searches all reads on its shard and packs its records for the exchange ---------------------
+    const uint32_t K = 2 * n_guides;
     std::vector<uint64_t> count(n, 0), off(n + 1, 0);
+    std::vector<uint32_t> key_counts((size_t)n * K, 0);
+    std::vector<int> rc(n, VSC_OK);
+    std::vector<vsc_timing> st(n);
+    on_all(n, [&](size_t r) {
+        if (!g->shard[r]) return;
+        vsc_hits *part = nullptr;
+        rc[r] = vsc_search(m->ctx[r], g->shard[r], guides, n_guides, params, &part);
+        if (rc[r] != VSC_OK) return;
+        (void)vsc_ctx_timing(m->ctx[r], &st[r]);
+        count[r] = vsc_hits_count(part);
+        if (hipSetDevice(m->device[r]) != hipSuccess || m->xbuf[r].ensure(std::max<uint64_t>(count[r], 1) * VSC_XREC_BYTES) != hipSuccess) {
+            m->ctx[r]->err = "exchange buffer allocation failed";
+            rc[r] = VSC_ERR_NOMEM;
+        } else {
+            rc[r] = vsc_hits_pack_exchange(m->ctx[r], g->shard[r], part, n_guides, m->xbuf[r].p, 1, key_counts.data() + r * K);
+        }
+        vsc_hits_free(part);  // the 8-byte records carry everything the merge needs
+    });
+    for (size_t r = 0; r < n; ++r)
+        if (rc[r] != VSC_OK) return mfail(m, rc[r], "shard " + std::to_string(r) + ": " + vsc_last_error(m->ctx[r]));
+    const auto t1 = clock::now();
     vsc_multi_timing mt{};
     for (size_t r = 0; r < n; ++r) {
-        count[r] = part[r] ? vsc_hits_count(part[r]) : 0;
         off[r + 1] = off[r] + count[r];
-        if (part[r]) {
-            vsc_timing t{};
-            (void)vsc_ctx_timing(m->ctx[r], &t);
-            mt.search_ms_max = std::max(mt.search_ms_max, t.total_ms);
-            mt.hits += t.hits;
+        if (g->shard[r]) {
+            mt.search_ms_max = std::max(mt.search_ms_max, st[r].total_ms);
+            mt.hits += st[r].hits;
         }
     }
     const uint64_t total = off[n];
 #define VSC_M(call)                                                                                                  \
     do {                                                                                                             \
         const hipError_t e_ = (call);                                                                                \
-        if (e_ != hipSuccess) {                                                                                      \
-            drop_parts();                                                                                            \
+        if (e_ != hipSuccess)                                                                                        \
             return mfail(m, e_ == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
-        }                                                                                                            \
     } while (0)
 #define VSC_N(call)                                                                                       \
     do {                                                                                                  \
         const ncclResult_t r_ = (call);                                                                   \
-        if (r_ != ncclSuccess) {                                                                          \
-            drop_parts();                                                                                 \
-            return mfail(m, VSC_ERR_DEVICE, std::string(#call) + ": " + m->rccl.GetErrorString(r_));      \
-        }                                                                                                 \
+        if (r_ != ncclSuccess) return mfail(m, VSC_ERR_DEVICE, std::string(#call) + ": " + m->rccl.GetErrorString(r_)); \
     } while (0)
     // ---- the one exchange: all records to the first device ------------------------------------------------
     VSC_M(hipSetDevice(m->device[0]));
-    VSC_M(m->gather.ensure(std::max<uint64_t>(total, 1) * sizeof(vsc_hit)));
+    VSC_M(m->gather.ensure(std::max<uint64_t>(total, 1) * VSC_XREC_BYTES));
     char *const dst = (char *)m->gather.p;
     if (m->use_rccl) {
         // hit counts by all-gather (one 64-bit word per rank), checked against what this process already knows;
@@ -348,7 +359,6 @@ int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *gu
             }
             m->comm.clear();
             m->use_rccl = false;
-            drop_parts();
             return mfail(m, VSC_ERR_DEVICE, std::string(where) + ": " + m->rccl.GetErrorString(bad) + " (RCCL given up, later searches copy)");
         };
         VSC_N(m->rccl.GroupStart());
@@ -360,15 +370,12 @@ int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *gu
         VSC_M(hipSetDevice(m->device[0]));
         VSC_M(hipMemcpyAsync(seen.data(), m->d_count[0] + 1, n * sizeof(uint64_t), hipMemcpyDeviceToHost, m->xstream[0]));
         VSC_M(hipStreamSynchronize(m->xstream[0]));
-        if (seen != count) {
-            drop_parts();
-            return mfail(m, VSC_ERR_DEVICE, "vsc_multi_search: the all-gathered hit counts differ from the shards' counts");
-        }
+        if (seen != count) return mfail(m, VSC_ERR_DEVICE, "vsc_multi_search: the all-gathered hit counts differ from the shards' counts");
         VSC_N(m->rccl.GroupStart());
         for (size_t r = 0; r < n && bad == ncclSuccess; ++r) {
             if (!count[r]) continue;
-            in_group(m->rccl.Recv(dst + off[r] * sizeof(vsc_hit), count[r] * sizeof(vsc_hit), ncclUint8, (int)r, m->comm[0], m->xstream[0]));
-            in_group(m->rccl.Send(vsc_hits_data_dev(part[r]), count[r] * sizeof(vsc_hit), ncclUint8, 0, m->comm[r], m->xstream[r]));
+            in_group(m->rccl.Recv(dst + off[r] * VSC_XREC_BYTES, count[r] * VSC_XREC_BYTES, ncclUint8, (int)r, m->comm[0], m->xstream[0]));
+            in_group(m->rccl.Send(m->xbuf[r].p, count[r] * VSC_XREC_BYTES, ncclUint8, 0, m->comm[r], m->xstream[r]));
         }
         in_group(m->rccl.GroupEnd());
         if (bad != ncclSuccess) return give_up_rccl("send / receive of the hit records");
@@ -381,20 +388,22 @@ int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *gu
         for (size_t r = 0; r < n; ++r) {
             if (!count[r]) continue;
             if (m->device[r] == m->device[0])
-                VSC_M(hipMemcpyAsync(dst + off[r] * sizeof(vsc_hit), vsc_hits_data_dev(part[r]), count[r] * sizeof(vsc_hit),
-                                     hipMemcpyDeviceToDevice, m->xstream[0]));
+                VSC_M(hipMemcpyAsync(dst + off[r] * VSC_XREC_BYTES, m->xbuf[r].p, count[r] * VSC_XREC_BYTES, hipMemcpyDeviceToDevice, m->xstream[0]));
             else
-                VSC_M(hipMemcpyPeerAsync(dst + off[r] * sizeof(vsc_hit), m->device[0], vsc_hits_data_dev(part[r]), m->device[r],
-                                         count[r] * sizeof(vsc_hit), m->xstream[0]));
+                VSC_M(hipMemcpyPeerAsync(dst + off[r] * VSC_XREC_BYTES, m->device[0], m->xbuf[r].p, m->device[r], count[r] * VSC_XREC_BYTES,
+                                         m->xstream[0]));
         }
         VSC_M(hipStreamSynchronize(m->xstream[0]));
     }
-    drop_parts();
     const auto t2 = clock::now();
     // ---- merge on the first device: shards partition the positions in ascending order ------------------------
-    const int mrc = vsc_hits_merge(m->ctx[0], dst, 1, count.data(), (uint32_t)n, n_guides, out);
-    // (the gathered records are not kept beside the merged result: the first device would hold the result twice)
-    if (total * sizeof(vsc_hit) > (64u << 20)) m->gather.release();
+    const vsc_genome *table = g->shard[0] ? g->shard[0] : g->table0;
+    const int mrc = vsc_hits_merge_packed(m->ctx[0], table, dst, 1, key_counts.data(), (uint32_t)n, 0, K, out);
+    // (the gathered records are not kept beside the merged result)
+    if (total * VSC_XREC_BYTES > (64u << 20)) {
+        (void)hipSetDevice(m->device[0]);
+        m->gather.release();
+    }
     if (mrc != VSC_OK) return mfail(m, mrc, std::string("merge: ") + vsc_last_error(m->ctx[0]));
     const auto t3 = clock::now();
     auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -402,7 +411,7 @@ int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *gu
     mt.exchange_ms = ms(t1, t2);
     mt.merge_ms = ms(t2, t3);
     mt.total_ms = ms(t0, t3);
-    mt.exchanged_bytes = (total - count[0]) * sizeof(vsc_hit);
+    mt.exchanged_bytes = (total - count[0]) * VSC_XREC_BYTES + (uint64_t)(n - 1) * K * sizeof(uint32_t);
     mt.n_devices = (uint32_t)n;
     mt.used_rccl = m->use_rccl;
     m->timing = mt;

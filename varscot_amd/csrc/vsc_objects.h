@@ -111,3 +111,9 @@ struct vsc_hits {
     bool host_valid = false;
 };
 
+
+namespace vsc {
+// A genome object that only carries the contig table (no planes, nothing to search): what vsc_hits_merge_packed
+// needs on a device whose shard of a tiny genome is empty (vsc_multi.cpp).  Freed with vsc_genome_free.
+int genome_table_only(vsc_ctx *ctx, const vsc_contig *contigs, uint32_t n_contigs, vsc_genome **out);
+}  // namespace vsc

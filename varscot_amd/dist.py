@@ -2,21 +2,29 @@
 genome sharded by tile-aligned plane ranges, every rank searching all reads on its shard, and ONE
 exchange of hit records per search over xGMI:
 
-  exchange="root"   the gather of all records to rank 0 (one consumer; rank 0's links carry everything:
+  exchange="root"   the gather of all records to rank 0 (the north star's single gather; rank 0's links carry
                     (N-1)/N of the result over N-1 links)
   exchange="reads"  every rank gathers the hits of ITS read range from all genome shards (N gathers at
                     once = an all-to-all; each link carries 1/N^2 of the result) and merges them; the
                     result stays distributed, sorted, in read-range order
 
+What travels is the 8-byte EXCHANGE RECORD (mask | global position << 23, include/varscot_hip.h:
+vsc_hits_pack_exchange) - half of a vsc_hit.  Guide and strand are implied by the per-key record counts
+(key = read << 1 | strand, 4 bytes per key) that every rank all-gathers first; those counts are also all the
+receiver needs to place every (key, shard) segment, so nothing is searched or sorted after the exchange
+(vsc_hits_merge_packed rebuilds the 16-byte records).
+
 torch is used for the process group and the device buffers that RCCL moves - nothing else.
 """
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from .api import TILE_WORDS, HIT_DTYPE, merge_shard_records
+from .api import TILE_WORDS, merge_packed_records
 
-RECORD_BYTES = HIT_DTYPE.itemsize
+XREC_BYTES = 8
 
 
 def shard_words(n_words_total, rank, world):
@@ -28,122 +36,128 @@ def shard_words(n_words_total, rank, world):
     return min(b, n_words_total), min(e, n_words_total)
 
 
-def gather_records(local, group=None, dst=0):
-    """local: 1-D uint8 tensor holding this rank's records (device tensor for nccl, CPU for gloo).
-
-    Returns (on dst) a uint8 tensor with the records of rank 0, 1, ... concatenated in rank order and
-    the per-rank record counts; (None, counts) elsewhere.  One all_gather of the counts (8 bytes per
-    rank) + one grouped send/recv of the variable-length payloads straight into their final place.
-    """
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    n_local = torch.tensor([local.numel() // RECORD_BYTES], dtype=torch.int64, device=local.device)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
-    if rank == dst:
-        out = torch.empty(sum(counts) * RECORD_BYTES, dtype=torch.uint8, device=local.device)
-        offs = np.concatenate([[0], np.cumsum(counts)]) * RECORD_BYTES
-        out[offs[dst]:offs[dst + 1]] = local
-        ops = [dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], r, group)
-               for r in range(world) if r != dst and counts[r] > 0]
-    else:
-        out = None
-        ops = [dist.P2POp(dist.isend, local, dst, group)] if counts[rank] > 0 else []
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    return out, counts
-
-
 def read_range(n_reads, rank, world):
     """Reads [begin, end) whose hits `rank` collects under exchange="reads"."""
     return n_reads * rank // world, n_reads * (rank + 1) // world
 
 
-def start_exchange_by_reads(local, n_reads, group=None):
-    """Issues the exchange of exchange_by_reads and returns without waiting for the payloads:
-    (receive buffer, per-source counts, outstanding requests)."""
+def all_gather_key_counts(key_counts, device, group=None):
+    """key_counts: this rank's uint32[K] per-key record counts.  Returns uint32[world, K] (every rank's counts, on
+    the host) - ONE all_gather of K * 4 bytes per rank, the only metadata of the exchange."""
+    world = dist.get_world_size(group)
+    mine = torch.from_numpy(key_counts.astype(np.int32, copy=False).view(np.int32)).to(device if device is not None else "cpu")
+    rows = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine, group=group)
+    return torch.stack(rows).cpu().numpy().view(np.uint32)
+
+
+def start_gather_to_root(local, all_counts, group=None, dst=0):
+    """Issues the root gather of the exchange records: returns (receive buffer on dst | None, requests).
+    local: this rank's records (uint8 tensor, 8 bytes per record); all_counts: uint32[world, K]."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    rec = local.view(torch.int32).view(-1, 4)
-    bounds = torch.tensor([read_range(n_reads, d, world)[0] for d in range(world)] + [n_reads], dtype=torch.int32,
-                          device=local.device)
-    cut = torch.searchsorted(rec[:, 0].contiguous(), bounds)  # first record of every destination's read range
-    send = (cut[1:] - cut[:-1]).to(torch.int64)
-    rows = [torch.zeros_like(send) for _ in range(world)]
-    dist.all_gather(rows, send, group=group)
-    matrix = torch.stack(rows).cpu().numpy()  # matrix[s][d] = records s sends to d
-    cut = cut.cpu().numpy().astype(np.int64) * RECORD_BYTES
-    counts = [int(matrix[s][rank]) for s in range(world)]
-    out = torch.empty(sum(counts) * RECORD_BYTES, dtype=torch.uint8, device=local.device)
-    offs = np.concatenate([[0], np.cumsum(counts)]) * RECORD_BYTES
-    out[offs[rank]:offs[rank + 1]] = local[cut[rank]:cut[rank + 1]]
+    totals = all_counts.astype(np.int64).sum(axis=1)
+    if rank == dst:
+        out = torch.empty(int(totals.sum()) * XREC_BYTES, dtype=torch.uint8, device=local.device)
+        offs = np.concatenate([[0], np.cumsum(totals)]) * XREC_BYTES
+        out[offs[dst]:offs[dst + 1]] = local
+        ops = [dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], r, group) for r in range(world) if r != dst and totals[r] > 0]
+    else:
+        out = None
+        ops = [dist.P2POp(dist.isend, local, dst, group)] if totals[rank] > 0 else []
+    return out, (dist.batch_isend_irecv(ops) if ops else [])
+
+
+def start_exchange_by_reads(local, all_counts, n_reads, group=None):
+    """Issues the all-to-all by read range: rank d receives, from every rank, the records of the keys of ITS reads.
+    Returns (receive buffer, uint32[world, keys of this rank] counts of what arrives, first key, requests).
+    The cut points come from the counts alone - nothing is searched in the records."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    prefix = np.concatenate([np.zeros((world, 1), dtype=np.int64), np.cumsum(all_counts.astype(np.int64), axis=1)], axis=1)
+    key_cut = [2 * read_range(n_reads, d, world)[0] for d in range(world)] + [2 * n_reads]
+    k0, k1 = key_cut[rank], key_cut[rank + 1]
+    incoming = prefix[:, k1] - prefix[:, k0]                       # records rank s sends to this rank
+    out = torch.empty(int(incoming.sum()) * XREC_BYTES, dtype=torch.uint8, device=local.device)
+    offs = np.concatenate([[0], np.cumsum(incoming)]) * XREC_BYTES
+    send_cut = prefix[rank, key_cut] * XREC_BYTES                   # this rank's records, cut by destination
+    out[offs[rank]:offs[rank + 1]] = local[send_cut[rank]:send_cut[rank + 1]]
     ops = []
     for peer in range(world):
         if peer == rank:
             continue
-        if matrix[rank][peer] > 0:
-            ops.append(dist.P2POp(dist.isend, local[cut[peer]:cut[peer + 1]], peer, group))
-        if counts[peer] > 0:
+        if send_cut[peer + 1] > send_cut[peer]:
+            ops.append(dist.P2POp(dist.isend, local[send_cut[peer]:send_cut[peer + 1]], peer, group))
+        if incoming[peer] > 0:
             ops.append(dist.P2POp(dist.irecv, out[offs[peer]:offs[peer + 1]], peer, group))
     reqs = dist.batch_isend_irecv(ops) if ops else []
-    return out, counts, reqs
+    return out, np.ascontiguousarray(all_counts[:, k0:k1]), k0, reqs
 
 
-def exchange_by_reads(local, n_reads, group=None):
-    """local: 1-D uint8 tensor with this rank's records, sorted by (read, strand, contig, pos).
-
-    Every rank receives, from every rank, the records of its own read range (read_range); returns the
-    received records concatenated in source-rank order (= genome-shard order, what vsc_hits_merge
-    expects) and the per-source counts.  One all_gather of the world x world count matrix + one
-    grouped send/recv of the payloads straight into their final place."""
-    out, counts, reqs = start_exchange_by_reads(local, n_reads, group)
+def _wait(reqs, buf):
     for req in reqs:
         req.wait()
-    return out, counts
+    if buf is not None and buf.is_cuda:
+        torch.cuda.current_stream(buf.device).synchronize()
 
 
-class _DeviceAlias:
-    """Zero-copy view of library-owned device memory for torch (the records of a vsc_hits)."""
+class DeviceAlias:
+    """Zero-copy view of library-owned device memory for torch (e.g. the records of a vsc_hits)."""
 
     def __init__(self, ptr, nbytes):
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def _records_tensor(hits, device):
-    """The records of `hits` as a uint8 tensor on `device` (a CPU copy for gloo, an alias for nccl)."""
+def packed_records(hits, device):
+    """The records of `hits` as 8-byte exchange records in a uint8 tensor on `device` (None: host memory, for gloo)
+    and the per-key counts."""
     n = len(hits)
-    if device is not None and torch.device(device).type == "cuda" and n:
-        try:
-            return torch.as_tensor(_DeviceAlias(hits.device_ptr, n * RECORD_BYTES), device=device)
-        except (TypeError, RuntimeError, ValueError):
-            pass  # a torch build without __cuda_array_interface__ import: stage a copy instead
-    local = torch.empty(n * RECORD_BYTES, dtype=torch.uint8, device=device)
-    if n:
-        hits.copy_to(local.data_ptr(), local.is_cuda)
-    return local
+    on_device = device is not None and torch.device(device).type == "cuda"
+    local = torch.empty(n * XREC_BYTES, dtype=torch.uint8, device=device if on_device else "cpu")
+    counts = hits.pack_exchange(local.data_ptr() if n else 0, on_device)
+    return local, counts
 
 
 def sharded_search(ctx, genome_shard, codes, max_mismatches, extra_pam=None, group=None, device=None,
-                   algorithm="auto", exchange="root"):
+                   algorithm="auto", exchange="root", stats=None):
     """Search all reads on this rank's shard, exchange the hit records once, merge.
 
     exchange="root":  returns (merged hits of all reads on rank 0 | None elsewhere, local Hits)
-    exchange="reads": returns (merged hits of this rank's read range, local Hits)"""
+    exchange="reads": returns (merged hits of this rank's read range, local Hits)
+    stats (a dict, optional) receives the host wall times of the phases (search_ms, pack_ms, exchange_ms, merge_ms)
+    and the bytes this rank sent and received."""
+    t0 = time.perf_counter()
     hits = genome_shard.search(codes, max_mismatches, extra_pam, algorithm=algorithm)
-    local = _records_tensor(hits, device)
+    t1 = time.perf_counter()
+    local, counts = packed_records(hits, device)
+    t2 = time.perf_counter()
+    all_counts = all_gather_key_counts(counts, device, group)
+    rank = dist.get_rank(group)
+    merged = None
     if exchange == "reads":
-        gathered, counts = exchange_by_reads(local, len(codes), group)
+        recv, part_counts, k0, reqs = start_exchange_by_reads(local, all_counts, len(codes), group)
+        _wait(reqs, recv)
+        t3 = time.perf_counter()
+        merged = merge_packed_records(ctx, genome_shard, recv.data_ptr(), recv.is_cuda, part_counts, k0)
+        received = int(part_counts.astype(np.int64).sum() - part_counts[rank].astype(np.int64).sum())
+        sent = int(all_counts[rank].astype(np.int64).sum() - part_counts[rank].astype(np.int64).sum())
     elif exchange == "root":
-        gathered, counts = gather_records(local, group)
+        recv, reqs = start_gather_to_root(local, all_counts, group)
+        _wait(reqs, recv)
+        t3 = time.perf_counter()
+        own = int(all_counts[rank].astype(np.int64).sum())
+        if recv is not None:
+            merged = merge_packed_records(ctx, genome_shard, recv.data_ptr(), recv.is_cuda, all_counts, 0)
+            received, sent = int(all_counts.astype(np.int64).sum()) - own, 0
+        else:
+            received, sent = 0, own
     else:
         raise ValueError("exchange must be 'root' or 'reads'")
-    merged = None
-    if gathered is not None:
-        if gathered.is_cuda:
-            torch.cuda.current_stream(gathered.device).synchronize()
-        merged = merge_shard_records(ctx, gathered.data_ptr(), gathered.is_cuda, counts, len(codes))
+    t4 = time.perf_counter()
+    if stats is not None:
+        meta = all_counts.shape[1] * 4 * (dist.get_world_size(group) - 1)
+        stats.update(search_ms=(t1 - t0) * 1e3, pack_ms=(t2 - t1) * 1e3, exchange_ms=(t3 - t2) * 1e3, merge_ms=(t4 - t3) * 1e3,
+                     sent_bytes=sent * XREC_BYTES + meta, received_bytes=received * XREC_BYTES + meta)
     return merged, hits
 
 
@@ -163,13 +177,9 @@ def sharded_search_pipelined(ctx, genome_shard, codes, max_mismatches, extra_pam
     pending = None
 
     def finish(p):
-        first, n_reads, hits, local, recv, counts, reqs = p
-        for req in reqs:
-            req.wait()
-        if recv.is_cuda:
-            torch.cuda.current_stream(recv.device).synchronize()
-        out.append((first, merge_shard_records(ctx, recv.data_ptr(), recv.is_cuda, counts, n_reads)))
-        hits.close()  # the send buffers alias its records: only now
+        first, local, recv, part_counts, k0, reqs = p
+        _wait(reqs, recv)
+        out.append((first, merge_packed_records(ctx, genome_shard, recv.data_ptr(), recv.is_cuda, part_counts, k0)))
 
     for first, part in pieces:
         hits = genome_shard.search(part, max_mismatches, extra_pam, algorithm=algorithm)  # overlaps the pending exchange
@@ -177,9 +187,11 @@ def sharded_search_pipelined(ctx, genome_shard, codes, max_mismatches, extra_pam
             timings.append(dict(ctx.timing()))
         if pending is not None:
             finish(pending)
-        local = _records_tensor(hits, device)
-        recv, counts, reqs = start_exchange_by_reads(local, len(part), group)
-        pending = (first, len(part), hits, local, recv, counts, reqs)
+        local, counts = packed_records(hits, device)
+        hits.close()  # the exchange records are a copy: the 16-byte records can go
+        all_counts = all_gather_key_counts(counts, device, group)
+        recv, part_counts, k0, reqs = start_exchange_by_reads(local, all_counts, len(part), group)
+        pending = (first, local, recv, part_counts, k0, reqs)
     if pending is not None:
         finish(pending)
     return out
