@@ -67,6 +67,9 @@ def parse():
                          "range (all-to-all, result stays distributed), 'root' = everything to rank 0")
     ap.add_argument("--cpu-sample-bases", type=int, default=192_000_000)
     ap.add_argument("--master-port", type=int, default=None, help="rendezvous port when bench.py starts the ranks itself")
+    ap.add_argument("--classify", action="store_true",
+                    help="workload c5: score -> classify fused (vsc_score_classify_hits: the reference's forest walked per hit, "
+                         "2 bytes of votes per hit out) instead of writing the 64-byte packed feature rows")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch check without a GPU: the ranks form the process group (gloo with --rehearse), all-reduce "
                          "once, rank 0 prints a JSON line saying what the communicator reported")
@@ -277,6 +280,21 @@ def main():
         torch.cuda.synchronize()
 
     streamed = args.workload == "c5"
+    forest, guide_activity = None, None
+    if args.classify:
+        from varscot_amd.classifier import Forest
+        forest = Forest()
+        # synthetic on-target activities in the range of the reference's TUSCAN scores (workflow/guideseq-data/
+        # guideseqOntargetActivity.txt: 0.2 .. 1.8), one per read, seeded
+        guide_activity = np.random.default_rng(0x5EED0004).uniform(0.2, 1.8, size=n_guides)
+
+    def score_batch(h, first, count):
+        if forest is not None:
+            # (a streamed batch numbers its reads globally; a per-batch search of the multi-rank path from 0)
+            act = guide_activity if len(h.codes) == n_guides else guide_activity[first:first + count]
+            forest.classify_hits(h, act, to_host=False)
+        else:
+            h.packed_features(to_host=False, mit=False)
 
     # more pieces = more of the exchange hidden, but every piece visits all site chunks again (c3 on one GPU:
     # 102 ms in one piece, 116 ms in four): 4 pieces at 2 ranks (13 GB over one link), 2 at 4, 1 at 8
@@ -338,14 +356,13 @@ def main():
         (vsc_search_stream, scoring from the batch callback)."""
         acc = new_acc()
         if not use_dist:
-            genome.search_streamed(codes, max_mm, lambda h, first, count: h.packed_features(to_host=False, mit=False),
-                                   batch=args.batch, algorithm=algorithm)
+            genome.search_streamed(codes, max_mm, score_batch, batch=args.batch, algorithm=algorithm)
             add_timing(acc, ctx.timing(), score=True)
             return [], acc["hits"], acc
         total = 0
         for b in range(0, n_guides, args.batch):
             local, merged = search_batch(codes[b:b + args.batch], acc)
-            local.packed_features(to_host=False, mit=False)
+            score_batch(local, b, len(codes[b:b + args.batch]))
             acc["score_ms"] += ctx.timing()["score_ms"]
             total += len(merged) if merged is not None else 0
             local.close()
@@ -475,7 +492,10 @@ def main():
                        "backend": (dist.get_backend() if use_dist else None),
                        "hits_per_step": int(total_hits), "candidate_sites_per_s": total_hits * args.steps / dt,
                        "pam_valid_sites": int(total_sites), "search_launches": passes, "read_passes": read_passes,
-                       "batch": args.batch if streamed else n_guides, "variant_genome": snp_info},
+                       "batch": args.batch if streamed else n_guides, "variant_genome": snp_info,
+                       "per_hit_scoring": (None if not streamed else
+                                           "score -> classify fused: rfClassifier (1000 trees) walked per hit, 2 B of votes per hit"
+                                           if forest is not None else "64-byte packed feature rows (442 features) per hit")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "launch_ms": scan_avg_ms, "algorithmic_bytes": survey_bytes,

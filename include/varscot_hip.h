@@ -391,6 +391,23 @@ int vsc_rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *featu
 int vsc_rf_predict_packed(vsc_ctx *ctx, const vsc_rf_model *model, const void *packed_rows, int rows_on_device,
                           const double *activity, uint64_t n, double *prob, uint8_t *cls, uint8_t *tie);
 
+/*
+ * Score -> classify in one kernel, for results whose feature rows should never exist in memory (100 000 reads at 8
+ * mismatches are 1.6e10 hits = 1 TB of packed rows): for rows [first, first + count) of a search result the kernel
+ * computes the hit's feature row in registers (as vsc_score_hits_packed would write it), walks the forest and writes
+ * the number of trees voting class "1" - 2 bytes per hit (prob = votes / n_trees, class = 2 * votes > n_trees,
+ * tie = 2 * votes == n_trees), and optionally the MIT score.  guide_activity[g] = the on-target activity of read g
+ * (the column classification/classificationPipeline.R:21-25 reads from the feature file, constant per target;
+ * variant_processing/merge_output_bam.h:401,708 appends it to every row).  Identical, hit for hit, to
+ * vsc_score_hits_packed followed by vsc_rf_predict_packed.  votes_dev (device, count * 2 bytes) and votes_host are
+ * optional destinations; with neither the votes stay in library scratch (timing runs).
+ * Replaces, for a streamed search: variant_processing/merge_output_bam.h:696-708 (feature rows as text) +
+ * classification/classificationPipeline.R:21-49 (read them back, predict).
+ */
+int vsc_score_classify_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, const uint64_t *guides, uint32_t n_guides,
+                            const double *guide_activity, const vsc_rf_model *model, uint64_t first, uint64_t count, void *votes_dev,
+                            uint16_t *votes_host, double *mit_host);
+
 /* ---- host-side formatting helpers (no device needed) ------------------------------------------ */
 /*
  * Order in which read_mapping/bidir_mapping.cpp:167-187 writes the records of one search result

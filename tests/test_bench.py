@@ -38,7 +38,8 @@ def test_a_launchers_environment_is_respected():
 
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_report_both_exchanges():
-    r, line = _bench("--gpus", "2", "--rehearse", "--workload", "c1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    r, line = _bench("--gpus", "2", "--rehearse", "--workload", "c1", "--mismatches", "8", "--steps", "2", "--warmup", "1",
+                     "--no-cpu-baseline")
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["backend"] == "gloo"
     ex = line["exchanges"]

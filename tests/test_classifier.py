@@ -53,7 +53,7 @@ def test_rf_predict_from_packed_rows_on_host_and_device():
     """vsc_rf_predict_packed decodes the columns the forest tests straight from the 64-byte packed rows - no
     442-byte expansion: same votes as the dense entry point, for rows passed from the host and for rows left in
     device memory by vsc_score_hits_packed; few rows (the trees are split over workgroups, votes meet in an
-    atomic) and many rows (one workgroup walks all trees of its 256 rows)."""
+    atomic) and many rows (one workgroup walks all trees of its 512 rows)."""
     import torch
     from helpers import make_genome, random_guides
     rng = np.random.default_rng(77)
@@ -79,6 +79,40 @@ def test_rf_predict_from_packed_rows_on_host_and_device():
     big = 300_000 // n + 1  # many rows: every workgroup walks the whole forest
     many = forest.predict_packed(ctx, np.tile(rows, (big, 1)), np.tile(act, big))
     assert all(np.array_equal(np.tile(a, big), b) for a, b in zip(want, many))
+    h.close()
+    gen.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_fused_score_classify_equals_score_then_predict(golden_dir):
+    """vsc_score_classify_hits (rows never leave the registers, 2 bytes per hit out) against the two-step path it
+    replaces on a streamed search - vsc_score_hits_packed + vsc_rf_predict_packed on the same hits: identical
+    votes, hit for hit; the MIT scores equal vsc_score_hits'.  Both strands, several reads with their own
+    activities (values around the forest's activity thresholds), a row range, device and host destinations."""
+    import torch
+    from helpers import make_genome, real_guides
+    names, guides, acts = real_guides(golden_dir)  # the reference's own targets and TUSCAN activities
+    rng = np.random.default_rng(31)
+    contigs = make_genome(31, [150000, 40000], guides, 7, n_plant=900, n_runs=2)
+    ctx = va.Context(0)
+    gen = ctx.load_genome(va.PackedGenome.from_sequences(contigs))
+    h = gen.search(guides, 7)
+    rec = h.to_numpy()
+    n = len(h)
+    assert n > 1500 and len(set(rec["guide"])) > 8
+    forest = Forest(MODEL)
+    act = np.array(acts, dtype=np.float64)
+    act[3] = float(np.unique(forest.split[(forest.status == 1) & (forest.feature == 442)])[7])  # exactly ON a threshold (<=)
+    rows, mit = h.packed_features(mit=True)
+    want_prob, want_cls, want_tie = forest.predict_packed(ctx, rows, act[rec["guide"]])
+    votes, mit2 = forest.classify_hits(h, act, mit=True)
+    assert np.array_equal(votes / 1000.0, want_prob) and np.array_equal(2 * votes.astype(int) > 1000, want_cls.astype(bool))
+    assert np.array_equal(2 * votes.astype(int) == 1000, want_tie.astype(bool)) and np.array_equal(mit2, mit)
+    assert 0 < want_cls.mean() < 1
+    dev = torch.zeros(n - 100, dtype=torch.int16, device="cuda:0")
+    forest.classify_hits(h, act, first=37, count=n - 100, to_host=False, dev_ptr=dev.data_ptr())
+    assert np.array_equal(dev.cpu().numpy().view(np.uint16), votes[37:n - 63])
     h.close()
     gen.close()
     ctx.close()

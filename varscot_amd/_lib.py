@@ -137,6 +137,7 @@ SYMBOLS = [
     ("vsc_windows_free", None, [_vp]),
     ("vsc_rf_predict", C.c_int, [_vp, C.POINTER(RfModel), _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     ("vsc_rf_predict_packed", C.c_int, [_vp, C.POINTER(RfModel), _vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),
+    ("vsc_score_classify_hits", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _vp, C.POINTER(RfModel), C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
     ("vsc_sam_order", None, [_vp, C.c_uint64, _vp, _vp]),
 ]
 # include/varscot_hip_debug.h (test / experiment hooks, not part of the drop-in boundary)

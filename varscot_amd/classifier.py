@@ -77,3 +77,20 @@ class Forest:
         check(lib().vsc_rf_predict_packed(ctx._h, C.byref(m), src, int(dev_ptr is not None), ptr(activity), n, ptr(prob),
                                           ptr(cls), ptr(tie)), ctx._h)
         return prob, cls, tie
+
+    def classify_hits(self, hits, guide_activity, first=0, count=None, to_host=True, mit=False, dev_ptr=None):
+        """vsc_score_classify_hits: score -> classify fused - the hits' feature rows are computed in registers and
+        walked through the forest, 2 bytes (the votes for class "1") per hit leave the kernel.
+        guide_activity: float64 per read of the search.  Returns (votes uint16[count] | None, mit | None);
+        prob = votes / n_trees, class = 2 * votes > n_trees, tie = 2 * votes == n_trees."""
+        count = len(hits) - first if count is None else count
+        act = np.ascontiguousarray(guide_activity, dtype=np.float64)
+        assert len(act) == len(hits.codes)
+        m = RfModel(self.n_trees, self.n_nodes, ptr(self.status), ptr(self.feature), ptr(self.left), ptr(self.right),
+                    ptr(self.split), ptr(self.node_class))
+        votes = np.empty(count, dtype=np.uint16) if to_host else None
+        ms = np.empty(count, dtype=np.float64) if mit else None
+        ctx = hits.genome.ctx
+        check(lib().vsc_score_classify_hits(ctx._h, hits.genome._h, hits._h, ptr(hits.codes), len(hits.codes), ptr(act), C.byref(m),
+                                            first, count, C.c_void_p(dev_ptr) if dev_ptr else None, ptr(votes), ptr(ms)), ctx._h)
+        return votes, ms

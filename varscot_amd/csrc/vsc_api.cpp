@@ -189,6 +189,8 @@ int vsc_ctx_destroy(vsc_ctx *ctx)
                          &ctx->seed_poff, &ctx->seed_lrest})
         b->release();
     for (auto &b : ctx->spare_records) b.release();
+    ctx->forest.nodes.release();
+    ctx->forest.ranks.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1756,66 +1758,132 @@ int vsc_score_hits_packed(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits
 
 namespace {
 
-// vsc_rf_predict / vsc_rf_predict_packed: the forest as 16-byte nodes over its own (compact) column numbering,
-// the rows from the host (dense) or from host / device memory (packed)
-int rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *dense, const void *packed, int packed_on_device,
-               const double *activity, uint64_t n, double *prob, uint8_t *cls, uint8_t *tie, const char *who)
+// The forest on the device (vsc_rf_predict*, vsc_score_classify_hits): 8-byte integer nodes over the forest's own
+// compact column numbering + the sorted distinct activity thresholds.  Kept on the context until a call brings
+// another forest (fingerprint of the model's arrays): a streamed search classifies batch after batch.
+uint64_t fnv(const void *p, size_t n, uint64_t h)
 {
-    ctx->err.clear();
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+    return h;
+}
+
+int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
+{
     if (!model || !model->node_status || !model->feature || !model->left || !model->right || !model->split ||
-        !model->node_class || model->n_trees == 0 || model->n_nodes == 0 || (n && ((!dense && !packed) || !activity)))
-        return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": null or empty argument").c_str());
-    if (n == 0) return VSC_OK;
+        !model->node_class || model->n_trees == 0 || model->n_nodes == 0)
+        return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": null or empty forest").c_str());
     const size_t nn = (size_t)model->n_trees * model->n_nodes;
-    if ((size_t)model->n_nodes * sizeof(RfNode) > (size_t)kRfTileBytes)
+    if (model->n_nodes > (uint32_t)kRfMaxNodes || model->n_nodes > 65535u)
         return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": a tree has more nodes than the kernel stages at once").c_str());
+    if (model->n_trees > 65535u) return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": more than 65 535 trees").c_str());
+    uint64_t h = 0xcbf29ce484222325ull ^ ((uint64_t)model->n_trees << 32 | model->n_nodes);
+    h = fnv(model->node_status, nn, h);
+    h = fnv(model->feature, nn * 2, h);
+    h = fnv(model->left, nn * 2, h);
+    h = fnv(model->right, nn * 2, h);
+    h = fnv(model->split, nn * 8, h);
+    h = fnv(model->node_class, nn, h);
+    vsc_ctx::Forest &f = ctx->forest;
+    if (f.nodes.p && f.fingerprint == h && f.n_trees == model->n_trees && f.n_nodes == model->n_nodes) return VSC_OK;
+    f.fingerprint = 0;
+    // distinct activity thresholds, ascending: `activity <= T_j` <=> `rank(activity) <= j`
+    std::vector<double> thr;
+    for (size_t i = 0; i < nn; ++i)
+        if (model->node_status[i] == 1 && model->feature[i] == VSC_N_FEATURES) thr.push_back(model->split[i]);
+    std::sort(thr.begin(), thr.end());
+    thr.erase(std::unique(thr.begin(), thr.end()), thr.end());
+    if (thr.size() > 255) return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": the forest splits the on-target activity at more than 255 values").c_str());
     std::vector<RfNode> nodes(nn);
     std::vector<int> slot(VSC_N_FEATURES, -1);
     std::vector<uint16_t> columns;
     for (size_t i = 0; i < nn; ++i) {
         RfNode &d = nodes[i];
-        d.split = model->split[i];
         d.left = model->left[i];
         d.right = model->right[i];
         d.status = model->node_status[i] == 1 ? 1 : -1;  // unused slots behind a tree's last node are never reached
         d.node_class = model->node_class[i];
-        d.pad = 0;
         d.column = 0;
+        d.thr = 0;
         if (d.status != 1) continue;
-        const uint16_t f = model->feature[i];
+        const uint16_t ft = model->feature[i];
         // randomForest numbers the daughters of a node behind it: a daughter at or before its parent is a cycle
         const uint32_t own = (uint32_t)(i % model->n_nodes) + 1;  // 1-based index of this node in its tree
-        if (f > VSC_N_FEATURES || d.left <= own || d.right <= own || d.left > model->n_nodes || d.right > model->n_nodes)
+        if (ft > VSC_N_FEATURES || d.left <= own || d.right <= own || d.left > model->n_nodes || d.right > model->n_nodes)
             return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": malformed forest (feature or daughter index out of range, or a daughter that does not lie behind its parent)").c_str());
-        if (f == VSC_N_FEATURES) {
-            d.column = kRfActivity;
+        const double sp = model->split[i];
+        if (!(sp == sp)) return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": malformed forest (NaN split)").c_str());
+        if (ft == VSC_N_FEATURES) {
+            d.column = 0xFF;  // patched to the activity slot below
+            d.thr = (uint8_t)(std::lower_bound(thr.begin(), thr.end(), sp) - thr.begin());
         } else {
-            if (slot[f] < 0) {
+            if (slot[ft] < 0) {
                 if (columns.size() == (size_t)kRfMaxColumns)
                     return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": the forest tests more than 128 distinct feature columns").c_str());
-                slot[f] = (int)columns.size();
-                columns.push_back(f);
+                slot[ft] = (int)columns.size();
+                columns.push_back(ft);
             }
-            d.column = (uint8_t)slot[f];
+            d.column = (uint8_t)slot[ft];
+            // the predictors are integers 0..255: x <= split  <=>  x <= floor(split); a negative split is never met
+            if (sp < 0) {
+                std::swap(d.left, d.right);
+                d.thr = 255;
+            } else {
+                d.thr = (uint8_t)std::min(255.0, std::floor(sp));
+            }
         }
     }
+    for (RfNode &d : nodes)
+        if (d.status == 1 && d.column == 0xFF) d.column = (uint8_t)columns.size();
     VSC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t node_bytes = (nn * sizeof(RfNode) + 255) / 256 * 256;
-    VSC_HIP(ctx, ctx->guides.ensure(node_bytes + std::max<size_t>(columns.size(), 1) * sizeof(uint16_t)));
-    VSC_HIP(ctx, hipMemcpyAsync(ctx->guides.p, nodes.data(), nn * sizeof(RfNode), hipMemcpyHostToDevice, ctx->stream));
-    uint16_t *d_columns = (uint16_t *)((char *)ctx->guides.p + node_bytes);
+    VSC_HIP(ctx, f.nodes.ensure(node_bytes + std::max<size_t>(columns.size(), 1) * sizeof(uint16_t)));
+    VSC_HIP(ctx, hipMemcpyAsync(f.nodes.p, nodes.data(), nn * sizeof(RfNode), hipMemcpyHostToDevice, ctx->stream));
     if (!columns.empty())
-        VSC_HIP(ctx, hipMemcpyAsync(d_columns, columns.data(), columns.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
-    VSC_HIP(ctx, ctx->score_mit.ensure(n * sizeof(double)));
+        VSC_HIP(ctx, hipMemcpyAsync((char *)f.nodes.p + node_bytes, columns.data(), columns.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the host vectors go out of scope)
+    f.columns_at = node_bytes;
+    f.n_columns = (uint32_t)columns.size();
+    f.n_trees = model->n_trees;
+    f.n_nodes = model->n_nodes;
+    f.thresholds = thr;
+    f.fingerprint = h;
+    return VSC_OK;
+}
+
+void fill_forest(RfArgs &a, const vsc_ctx *ctx)
+{
+    const vsc_ctx::Forest &f = ctx->forest;
+    a.nodes = (const RfNode *)f.nodes.p;
+    a.n_trees = f.n_trees;
+    a.n_nodes = f.n_nodes;
+    a.columns = (const uint16_t *)((const char *)f.nodes.p + f.columns_at);
+    a.n_columns = f.n_columns;
+}
+
+uint8_t activity_rank(const std::vector<double> &thr, double activity)
+{
+    return (uint8_t)(std::lower_bound(thr.begin(), thr.end(), activity) - thr.begin());  // thresholds strictly below
+}
+
+// vsc_rf_predict / vsc_rf_predict_packed: the rows from the host (dense) or from host / device memory (packed)
+int rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *dense, const void *packed, int packed_on_device,
+               const double *activity, uint64_t n, double *prob, uint8_t *cls, uint8_t *tie, const char *who)
+{
+    ctx->err.clear();
+    if (n && ((!dense && !packed) || !activity)) return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": null or empty argument").c_str());
+    const int frc = prepare_forest(ctx, model, who);
+    if (frc != VSC_OK) return frc;
+    if (n == 0) return VSC_OK;
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint8_t> ranks(n);
+    for (uint64_t i = 0; i < n; ++i) ranks[i] = activity_rank(ctx->forest.thresholds, activity[i]);
+    VSC_HIP(ctx, ctx->score_mit.ensure(n));
     VSC_HIP(ctx, ctx->score_flags.ensure(n * sizeof(uint32_t)));
-    VSC_HIP(ctx, hipMemcpyAsync(ctx->score_mit.p, activity, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VSC_HIP(ctx, hipMemcpyAsync(ctx->score_mit.p, ranks.data(), n, hipMemcpyHostToDevice, ctx->stream));
     RfArgs a{};
-    a.nodes = (const RfNode *)ctx->guides.p;
-    a.n_trees = model->n_trees;
-    a.n_nodes = model->n_nodes;
-    a.columns = d_columns;
-    a.n_columns = (uint32_t)columns.size();
-    a.activity = (const double *)ctx->score_mit.p;
+    fill_forest(a, ctx);
+    a.act_rank = (const uint8_t *)ctx->score_mit.p;
     a.n = n;
     a.votes = (uint32_t *)ctx->score_flags.p;
     if (dense) {
@@ -1831,7 +1899,7 @@ int rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *dense, co
     }
     // few rows: split the trees over several workgroups per row tile so that the device is filled
     const uint64_t tiles = (n + kRfRows - 1) / kRfRows;
-    a.tree_splits = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)4 * ctx->n_cus / tiles, 32, model->n_trees}));
+    a.tree_splits = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)2 * ctx->n_cus / tiles, 32, model->n_trees}));
     if (a.tree_splits > 1) VSC_HIP(ctx, hipMemsetAsync(a.votes, 0, n * sizeof(uint32_t), ctx->stream));
     VSC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     VSC_HIP(ctx, launch_rf_predict(a, ctx->stream));
@@ -1866,6 +1934,56 @@ int vsc_rf_predict_packed(vsc_ctx *ctx, const vsc_rf_model *model, const void *p
 {
     if (!ctx) return VSC_ERR_INVALID;
     return rf_predict(ctx, model, nullptr, packed_rows, rows_on_device, activity, n, prob, cls, tie, "vsc_rf_predict_packed");
+}
+
+int vsc_score_classify_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, const uint64_t *guides, uint32_t n_guides,
+                            const double *guide_activity, const vsc_rf_model *model, uint64_t first, uint64_t count, void *votes_dev,
+                            uint16_t *votes_host, double *mit_host)
+{
+    if (!ctx) return VSC_ERR_INVALID;
+    ctx->err.clear();
+    if (!genome || !hits || (n_guides && (!guides || !guide_activity)))
+        return fail(ctx, VSC_ERR_INVALID, "vsc_score_classify_hits: null argument");
+    if (first > hits->n || count > hits->n - first) return fail(ctx, VSC_ERR_INVALID, "vsc_score_classify_hits: row range outside the result");
+    const int frc = prepare_forest(ctx, model, "vsc_score_classify_hits");
+    if (frc != VSC_OK) return frc;
+    ctx->timing.score_ms = 0;
+    if (count == 0) return VSC_OK;
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    VSC_HIP(ctx, upload_read_planes(ctx, guides, n_guides));
+    VSC_HIP(ctx, ensure_hl(ctx, genome));
+    std::vector<uint8_t> ranks(std::max<uint32_t>(n_guides, 1));
+    for (uint32_t g = 0; g < n_guides; ++g) ranks[g] = activity_rank(ctx->forest.thresholds, guide_activity[g]);
+    VSC_HIP(ctx, ctx->forest.ranks.ensure(ranks.size()));
+    VSC_HIP(ctx, hipMemcpyAsync(ctx->forest.ranks.p, ranks.data(), ranks.size(), hipMemcpyHostToDevice, ctx->stream));
+    // 2 bytes (+ 8 with the MIT score) per hit of scratch: one pass for any result that fits the device at all
+    uint64_t rows = 0;
+    VSC_HIP(ctx, score_scratch(ctx, count, mit_host ? sizeof(double) : 0, votes_dev ? 0 : sizeof(uint16_t), 0, &rows));
+    double total_ms = 0;
+    for (uint64_t done = 0; done < count; done += rows) {
+        const uint64_t m = std::min(rows, count - done);
+        RfArgs a{};
+        fill_forest(a, ctx);
+        fill_score_args(a.score, ctx, genome);
+        a.score.hits = hits->d_records + first + done;
+        a.score.n = m;
+        if (mit_host) a.score.mit = (double *)ctx->score_mit.p;
+        a.act_rank = (const uint8_t *)ctx->forest.ranks.p;
+        a.n = m;
+        a.votes16 = votes_dev ? (uint16_t *)votes_dev + done : (uint16_t *)ctx->score_flags.p;
+        a.tree_splits = 1;
+        VSC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+        VSC_HIP(ctx, launch_rf_predict(a, ctx->stream));
+        VSC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+        if (votes_host) VSC_HIP(ctx, hipMemcpyAsync(votes_host + done, a.votes16, m * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (mit_host) VSC_HIP(ctx, hipMemcpyAsync(mit_host + done, a.score.mit, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        float ms = 0;
+        VSC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        total_ms += ms;
+    }
+    ctx->timing.score_ms = total_ms;
+    return VSC_OK;
 }
 
 }  // extern "C"

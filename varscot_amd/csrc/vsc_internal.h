@@ -209,31 +209,38 @@ struct SeedArgs {
     unsigned long long *counters;  // kCntPart + 4 p + {0,1,2}, kCntSites (= pairs compared), kCntVisited, kCntOverflow, cursors
 };
 
-// One node of a random-forest tree, 16 bytes: a node visit is one LDS read.
+// One node of a random-forest tree, 8 bytes, integer compare: every predictor of the feature matrix is a small
+// non-negative integer, so `x <= split` is `x <= floor(split)`; the on-target activity (a double, constant per read)
+// enters as its rank among the forest's distinct activity thresholds (rank = thresholds strictly below it), which
+// turns `activity <= T_j` into `rank <= j` exactly.  A node visit is one 8-byte LDS read + one byte.
 struct RfNode {
-    double split;
-    uint16_t left, right;  // 1-based daughters
-    uint8_t column;        // which of the forest's (at most kRfMaxColumns) predictor columns; kRfActivity = the on-target activity
+    uint16_t left, right;  // 1-based daughters (x <= thr goes left)
+    uint8_t column;        // slot of the predictor in the workgroup's column table; slot n_columns = the activity rank
+    uint8_t thr;
     int8_t status;         // 1 split, -1 terminal
     uint8_t node_class;    // terminal: 1 = class "0", 2 = class "1"
-    uint8_t pad;
 };
-constexpr int kRfRows = 256;          // feature rows per workgroup (one thread each)
+static_assert(sizeof(RfNode) == 8, "RfNode layout");
+constexpr int kRfRows = 512;          // feature rows per workgroup (one thread each)
 constexpr int kRfMaxColumns = 128;    // distinct feature columns a forest may test (rfClassifier: 79 + the activity)
-constexpr int kRfActivity = 255;
-constexpr int kRfTileBytes = 48 * 1024;  // whole trees staged in LDS per step
+constexpr int kRfTileBytes = 32 * 1024;  // whole trees staged in LDS per step
+constexpr int kRfMaxNodes = kRfTileBytes / (int)sizeof(RfNode);  // nodes of one tree (rfClassifier: 275)
 
 struct RfArgs {
     const RfNode *nodes;        // [n_trees * n_nodes], tree-major
     uint32_t n_trees, n_nodes;
     const uint16_t *columns;    // [n_columns] dense feature columns (0..441) the forest tests
     uint32_t n_columns;
-    const uint8_t *dense;       // n rows of 442 bytes, or null:
-    const uint4 *packed;        // n rows of 64 bytes (vsc_score_hits_packed)
-    const double *activity;     // [n]
+    // the rows: dense (n x 442 bytes), packed (n x 64 bytes), or - both null - computed in the kernel from `score`'s
+    // hits (the fused score -> classify path: the feature rows never exist in memory)
+    const uint8_t *dense;
+    const uint4 *packed;
+    const uint8_t *act_rank;    // activity rank per row (dense / packed) or per read (fused)
     uint64_t n;
-    uint32_t *votes;            // [n] trees voting class "1" (zeroed before the launch when tree_splits > 1)
+    uint32_t *votes;            // [n] trees voting class "1" (zeroed before the launch when tree_splits > 1) ...
+    uint16_t *votes16;          // ... or 16-bit (fused path; tree_splits == 1)
     uint32_t tree_splits;       // gridDim.y: every workgroup row walks n_trees / tree_splits trees
+    ScoreArgs score;            // fused path: hits, planes, reads (+ optional MIT output)
 };
 
 // Launch wrappers implemented in vsc_kernels.hip.  They only enqueue work on `stream`.

@@ -891,53 +891,81 @@ __device__ __forceinline__ uint32_t packed_column(const uint32_t (&w)[16], uint3
     return col == 440 ? (w[0] >> 26) & 31u : (w[1] >> 22) & 15u;  // adjacentMismatches, seedMismatches
 }
 
-__global__ __launch_bounds__(kRfRows) void rf_predict_kernel(const RfArgs a)
+// kMode 0: dense rows, 1: packed rows, 2: rows computed here from the hits of a.score (score -> classify fused)
+template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kernel(const RfArgs a)
 {
-    __shared__ uint8_t s_x[kRfMaxColumns][kRfRows];  // column-major: the threads of a wave read neighbouring bytes
-    __shared__ uint4 s_nodes[kRfTileBytes / sizeof(uint4)];
+    extern __shared__ uint4 s_dyn[];
+    // s_x[slot][thread], column-major: the threads of a wave read neighbouring bytes; slot n_columns = activity rank
+    uint8_t *const s_x = (uint8_t *)s_dyn;
+    RfNode *const s_nodes = (RfNode *)((uint8_t *)s_dyn + (((size_t)(a.n_columns + 1) * kRfRows + 15) & ~(size_t)15));
     const uint32_t t = threadIdx.x;
     const uint64_t row = (uint64_t)blockIdx.x * kRfRows + t;
     const bool live = row < a.n;
-    if (a.dense) {
-        for (uint32_t c = 0; c < a.n_columns; ++c) s_x[c][t] = live ? a.dense[row * VSC_N_FEATURES + a.columns[c]] : 0;
+    uint32_t rank = 0;
+    if (kMode == 0) {
+        for (uint32_t c = 0; c < a.n_columns; ++c) s_x[c * kRfRows + t] = live ? a.dense[row * VSC_N_FEATURES + a.columns[c]] : 0;
+        if (live) rank = a.act_rank[row];
     } else {
         uint32_t w[16] = {};
         if (live) {
+            if (kMode == 1) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 v = a.packed[row * 4 + q];
-                w[4 * q] = v.x, w[4 * q + 1] = v.y, w[4 * q + 2] = v.z, w[4 * q + 3] = v.w;
+                for (int q = 0; q < 4; ++q) {
+                    const uint4 v = a.packed[row * 4 + q];
+                    w[4 * q] = v.x, w[4 * q + 1] = v.y, w[4 * q + 2] = v.z, w[4 * q + 3] = v.w;
+                }
+                rank = a.act_rank[row];
+            } else {
+                // the row of hit `row`, as score_packed_kernel computes it - kept in registers, never stored
+                const vsc_hit h = a.score.hits[row];
+                uint32_t oh, ol;
+                site_planes(a.score, h, oh, ol);
+                const uint2 g = a.score.guides[h.guide];
+                feature_row_packed(g.x, g.y, oh, ol, w);
+                rank = a.act_rank[h.guide];
+                if (a.score.mit) {
+                    int ub;
+                    a.score.mit[row] = mit_score(VSC_HIT_MASK(h.info), &ub);
+                    if (a.score.mit_flags) a.score.mit_flags[row] = (uint8_t)ub;
+                }
             }
         }
-        for (uint32_t c = 0; c < a.n_columns; ++c) s_x[c][t] = (uint8_t)packed_column(w, a.columns[c]);
+        for (uint32_t c = 0; c < a.n_columns; ++c) s_x[c * kRfRows + t] = (uint8_t)packed_column(w, a.columns[c]);
     }
-    const double act = live ? a.activity[row] : 0.0;
+    s_x[a.n_columns * kRfRows + t] = (uint8_t)rank;
     // this workgroup's share of the trees
     const uint32_t per_split = (a.n_trees + a.tree_splits - 1) / a.tree_splits;
     const uint32_t tree_begin = blockIdx.y * per_split, tree_end = min(tree_begin + per_split, a.n_trees);
-    const uint32_t tile_trees = max(1u, (uint32_t)(kRfTileBytes / sizeof(RfNode)) / a.n_nodes);
+    const uint32_t tile_trees = max(1u, (uint32_t)kRfMaxNodes / a.n_nodes);
+    const uint8_t *const xt = s_x + t;
     uint32_t ones = 0;
     for (uint32_t t0 = tree_begin; t0 < tree_end; t0 += tile_trees) {
         const uint32_t nt = min(tile_trees, tree_end - t0);
         block_sync();  // the previous tile is done with (first round: the feature columns are in place)
-        const uint4 *src = (const uint4 *)(a.nodes + (size_t)t0 * a.n_nodes);
-        for (uint32_t i = t; i < nt * a.n_nodes; i += kRfRows) s_nodes[i] = src[i];
+        const uint2 *src = (const uint2 *)(a.nodes + (size_t)t0 * a.n_nodes);
+        for (uint32_t i = t; i < nt * a.n_nodes; i += kRfRows) ((uint2 *)s_nodes)[i] = src[i];
         block_sync();
-        const RfNode *tile = (const RfNode *)s_nodes;
-        for (uint32_t k = 0; k < nt; ++k) {
-            const RfNode *tree = tile + (size_t)k * a.n_nodes;
-            RfNode nd = tree[0];
+        // two trees in flight per thread: a walk is a chain of dependent LDS reads, two chains overlap their latencies
+        for (uint32_t k = 0; k < nt; k += 2) {
+            const RfNode *const tree0 = s_nodes + (size_t)k * a.n_nodes;
+            const RfNode *const tree1 = s_nodes + (size_t)min(k + 1, nt - 1) * a.n_nodes;
+            RfNode n0 = tree0[0], n1 = tree1[0];
             // (daughters lie behind their parent - the host checks - so a walk ends within n_nodes steps; the
             // bound only keeps a forest that slipped past the check from hanging the device)
-            for (uint32_t step = 0; nd.status != -1 && step < a.n_nodes; ++step) {
-                const double v = nd.column == kRfActivity ? act : (double)s_x[nd.column][t];
-                nd = tree[(v <= nd.split ? nd.left : nd.right) - 1u];
+            for (uint32_t step = 0; step < a.n_nodes; ++step) {
+                const bool go0 = n0.status == 1, go1 = n1.status == 1;
+                if (!(go0 | go1)) break;
+                if (go0) n0 = tree0[(xt[(uint32_t)n0.column * kRfRows] <= n0.thr ? n0.left : n0.right) - 1u];
+                if (go1) n1 = tree1[(xt[(uint32_t)n1.column * kRfRows] <= n1.thr ? n1.left : n1.right) - 1u];
             }
-            ones += nd.node_class == 2;
+            ones += n0.node_class == 2;
+            if (k + 1 < nt) ones += n1.node_class == 2;
         }
     }
     if (!live) return;
-    if (a.tree_splits > 1)
+    if (kMode == 2)
+        a.votes16[row] = (uint16_t)ones;
+    else if (a.tree_splits > 1)
         atomicAdd(&a.votes[row], ones);
     else
         a.votes[row] = ones;
@@ -946,11 +974,21 @@ __global__ __launch_bounds__(kRfRows) void rf_predict_kernel(const RfArgs a)
 hipError_t launch_rf_predict(const RfArgs &args, hipStream_t stream)
 {
     if (args.n == 0) return hipSuccess;
-    if (args.n_columns > (uint32_t)kRfMaxColumns || (size_t)args.n_nodes * sizeof(RfNode) > (size_t)kRfTileBytes) return hipErrorInvalidValue;
+    if (args.n_columns > (uint32_t)kRfMaxColumns || args.n_nodes > (uint32_t)kRfMaxNodes || args.n_nodes == 0) return hipErrorInvalidValue;
     const uint64_t tiles = (args.n + kRfRows - 1) / kRfRows;
     if (tiles >= (1ull << 31)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rf_predict_kernel, dim3((unsigned)tiles, args.tree_splits), dim3(kRfRows), 0, stream, args);
-    return hipGetLastError();
+    const size_t lds = ((((size_t)(args.n_columns + 1) * kRfRows + 15) & ~(size_t)15)) + (size_t)kRfTileBytes;
+    const int mode = args.dense ? 0 : (args.packed ? 1 : 2);
+    if (mode == 2 && args.tree_splits != 1) return hipErrorInvalidValue;
+    auto go = [&](auto kernel) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)tiles, args.tree_splits), dim3(kRfRows), lds, stream, args);
+        return hipGetLastError();
+    };
+    if (mode == 0) return go(rf_predict_kernel<0>);
+    if (mode == 1) return go(rf_predict_kernel<1>);
+    return go(rf_predict_kernel<2>);
 }
 
 }  // namespace vsc

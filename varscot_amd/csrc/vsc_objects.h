@@ -70,6 +70,14 @@ struct vsc_ctx {
     std::vector<vsc::SortSeg> host_segs;
     std::vector<uint32_t> host_tile0;  // bin sort: segment table + tile starts, per-bin tables, oversize list + counter
     vsc::DeviceBuf seed_k1, seed_k2, seed_v1, seed_v2, seed_off, seed_poff, seed_lrest;  // per-search read lists
+    // the forest of the last classification call, as the kernels read it (prepare_forest in vsc_api.cpp)
+    struct Forest {
+        vsc::DeviceBuf nodes, ranks;   // nodes + column table; activity ranks of the reads of a fused call
+        size_t columns_at = 0;
+        uint32_t n_columns = 0, n_trees = 0, n_nodes = 0;
+        std::vector<double> thresholds;  // distinct activity splits, ascending
+        uint64_t fingerprint = 0;
+    } forest;
     // record buffers of freed results, kept for the next search: hipMalloc / hipFree of tens of GB
     // cost hundreds of milliseconds each
     std::vector<vsc::DeviceBuf> spare_records;
