@@ -150,6 +150,66 @@ def test_c5_streamed_batches_with_packed_scoring(big):
     assert t["read_passes"] == 2 and t["hits"] == want[0] and t["score_ms"] > 0
 
 
+def test_c5_all_100000_reads_streamed(big):
+    """BASELINE.json configs[4] at its stated size on one GPU: all 100 000 reads streamed in 10 batches of 10 000 at
+    <= 8 mismatches (1.6e10 records in total), every batch scored from the callback (packed feature rows, dropped).
+    Per batch: strictly ascending records, NM <= 8, reads inside the batch's range, NM = popcount(mask) on a
+    sample; the batch counts add up to the library's hit total; batch 0 (= the c3 read set) has the c3 digest; ONE
+    batch (reads 30 000 .. 39 999) is compared record for record with the streaming scan of the same reads - the
+    other search algorithm over the other data structure; and on a slice of that batch the fused
+    score -> classify path equals packed scoring followed by the forest."""
+    from varscot_amd.classifier import Forest
+    ctx, packed, genome, guides10k, planted = big
+    ids, guides = synth.synthetic_guides(100_000)
+    assert guides[:10_000] == guides10k
+    seen, kept = [], {}
+    forest = Forest()
+    act = np.random.default_rng(5).uniform(0.2, 1.8, size=len(guides))
+
+    def on_batch(h, first, count):
+        n, ascending, max_nm, sums = _digest(h)
+        rec = _device_records(h)
+        in_range = int(rec[:, 0].min()) >= first and int(rec[:, 0].max()) < first + count
+        sample = rec[:: max(1, n // 100_000), 3].to(torch.int64)
+        pop = torch.zeros_like(sample)
+        for bit in range(23):
+            pop += (sample >> bit) & 1
+        nm_ok = bool((pop == ((sample >> 23) & 31)).all())
+        h.packed_features(to_host=False, mit=False)  # the c5 scoring, rows dropped
+        if first == 30_000:
+            kept["records"] = rec.clone()
+            # fused score -> classify on a slice against the two-step path (rows to device memory, then the forest)
+            k0, kn = n // 3, 200_000
+            rows = torch.empty((kn, 16), dtype=torch.int32, device="cuda:0")
+            h.packed_features(first=k0, count=kn, to_host=False, dev_ptr=rows.data_ptr())
+            g = rec[k0:k0 + kn, 0].cpu().numpy()
+            prob, _, _ = forest.predict_packed(ctx, kn, act[g], dev_ptr=rows.data_ptr())
+            votes, _ = forest.classify_hits(h, act, first=k0, count=kn)
+            kept["fused_ok"] = bool(np.array_equal(votes / 1000.0, prob)) and 0 < (votes > 500).mean() < 1
+            del rows
+        seen.append((first, count, n, ascending, max_nm, sums, in_range and nm_ok))
+        torch.cuda.empty_cache()
+
+    genome.search_streamed(guides, 8, on_batch, batch=10_000, algorithm="seed")
+    t = ctx.timing()
+    assert [(f, c) for f, c, *_ in seen] == [(10_000 * i, 10_000) for i in range(10)]
+    assert all(asc and nm <= 8 and ok for _, _, _, asc, nm, _, ok in seen), seen
+    total = sum(s[2] for s in seen)
+    assert total > 15_000_000_000 and t["hits"] == total and t["read_passes"] == 10 and t["score_ms"] > 0
+    counts = [s[2] for s in seen]
+    assert max(counts) < 1.02 * min(counts)  # uniform reads on a uniform genome: every batch is another c3
+    assert kept["fused_ok"]
+    # batch 3 against the streaming scan of the same reads
+    h_scan = genome.search(guides[30_000:40_000], 8, algorithm="scan")
+    scan = _device_records(h_scan)
+    a = kept.pop("records")
+    assert a.shape == scan.shape
+    assert bool((a[:, 1:] == scan[:, 1:]).all()) and bool(((a[:, 0] - scan[:, 0]) == 30_000).all())
+    h_scan.close()
+    del a, scan
+    torch.cuda.empty_cache()
+
+
 def test_c4_variant_windows_at_full_size(big, tmp_path):
     """BASELINE.json configs[3]: ~5 M SNPs on the 3 Gbp genome -> 8.9 M alt-allele windows built straight from
     the packed planes (vsc_windows_build) and searched as a second genome with millions of contigs (contig ids
