@@ -124,6 +124,10 @@ int vsc_device_count(void);
 int vsc_ctx_create(int device_id, vsc_ctx **out);
 /* Genomes and results created on a context must be freed before it. */
 int vsc_ctx_destroy(vsc_ctx *ctx);
+/* Gives the context's pooled device memory back (search / sort / scoring scratch, record buffers of freed results -
+ * tens of GB after a large search; they are kept because hipMalloc / hipFree of such sizes cost hundreds of
+ * milliseconds).  Genomes and live results are untouched; the next call allocates what it needs again. */
+int vsc_ctx_release_scratch(vsc_ctx *ctx);
 /* Run on a caller-owned hipStream_t (e.g. the framework's current stream) instead of the context's own. */
 int vsc_ctx_set_stream(vsc_ctx *ctx, void *hip_stream);
 /* Text of the last error on this context ("" if none).  Valid until the next call on ctx. */

@@ -199,14 +199,19 @@ def test_c5_all_100000_reads_streamed(big):
     counts = [s[2] for s in seen]
     assert max(counts) < 1.02 * min(counts)  # uniform reads on a uniform genome: every batch is another c3
     assert kept["fused_ok"]
-    # batch 3 against the streaming scan of the same reads
+    # batch 3 against the streaming scan of the same reads (the stream's pooled scratch - 104 GB of packed rows
+    # among it - goes back to the device first)
+    ctx.release_scratch()
     h_scan = genome.search(guides[30_000:40_000], 8, algorithm="scan")
     scan = _device_records(h_scan)
     a = kept.pop("records")
     assert a.shape == scan.shape
-    assert bool((a[:, 1:] == scan[:, 1:]).all()) and bool(((a[:, 0] - scan[:, 0]) == 30_000).all())
+    ctx.release_scratch()
+    for b in range(0, a.shape[0], 1 << 26):
+        x, y = a[b:b + (1 << 26)], scan[b:b + (1 << 26)]
+        assert bool((x[:, 1:] == y[:, 1:]).all()) and bool(((x[:, 0] - y[:, 0]) == 30_000).all())
     h_scan.close()
-    del a, scan
+    del a, scan, x, y
     torch.cuda.empty_cache()
 
 

@@ -86,6 +86,7 @@ SYMBOLS = [
     ("vsc_device_count", C.c_int, []),
     ("vsc_ctx_create", C.c_int, [C.c_int, C.POINTER(_vp)]),
     ("vsc_ctx_destroy", C.c_int, [_vp]),
+    ("vsc_ctx_release_scratch", C.c_int, [_vp]),
     ("vsc_ctx_set_stream", C.c_int, [_vp, _vp]),
     ("vsc_last_error", C.c_char_p, [_vp]),
     ("vsc_ctx_timing", C.c_int, [_vp, C.POINTER(Timing)]),

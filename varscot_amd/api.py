@@ -127,6 +127,10 @@ class Context:
         check(lib().vsc_ctx_timing(self._h, C.byref(t)), self._h)
         return t.as_dict()
 
+    def release_scratch(self):
+        """vsc_ctx_release_scratch: give the pooled scratch and record buffers back to the device."""
+        check(lib().vsc_ctx_release_scratch(self._h), self._h)
+
     def set_debug(self, **hooks):
         """Test / experiment hooks of include/varscot_hip_debug.h (vsc_ctx_set_debug_params): e.g.
         set_debug(sort_cap=16) forces many sort levels on a few thousand records.  No arguments: back to the

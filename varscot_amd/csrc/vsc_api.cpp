@@ -178,9 +178,9 @@ int vsc_ctx_create(int device_id, vsc_ctx **out)
     return VSC_OK;
 }
 
-int vsc_ctx_destroy(vsc_ctx *ctx)
+int vsc_ctx_release_scratch(vsc_ctx *ctx)
 {
-    if (!ctx) return VSC_OK;
+    if (!ctx) return VSC_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->sort_temp,
@@ -189,8 +189,17 @@ int vsc_ctx_destroy(vsc_ctx *ctx)
                          &ctx->seed_poff, &ctx->seed_lrest})
         b->release();
     for (auto &b : ctx->spare_records) b.release();
+    ctx->spare_records.clear();
     ctx->forest.nodes.release();
     ctx->forest.ranks.release();
+    ctx->forest.fingerprint = 0;
+    return VSC_OK;
+}
+
+int vsc_ctx_destroy(vsc_ctx *ctx)
+{
+    if (!ctx) return VSC_OK;
+    (void)vsc_ctx_release_scratch(ctx);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
