@@ -183,9 +183,9 @@ int vsc_ctx_release_scratch(vsc_ctx *ctx)
     if (!ctx) return VSC_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->sort_temp,
+    for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a,
                          &ctx->score_mit, &ctx->score_flags, &ctx->score_feat, &ctx->score_sched, &ctx->sort_segs, &ctx->sort_tabs,
-                         &ctx->sort_over, &ctx->seed_k1, &ctx->seed_k2, &ctx->seed_v1, &ctx->seed_v2, &ctx->seed_off,
+                         &ctx->sort_over, &ctx->seed_off,
                          &ctx->seed_poff, &ctx->seed_lrest})
         b->release();
     for (auto &b : ctx->spare_records) b.release();
@@ -1030,26 +1030,17 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         t.genome_bytes += (uint64_t)genome->n_tiles * kTileWords * 3 * sizeof(uint32_t);
         VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
     } else {
-        // ---- per-bucket read lists: neighbourhood enumeration -> sort by bucket -> padded lists ------
+        // ---- per-bucket read lists: a counting sort of the reads' segment neighbourhoods over the buckets ------
         const uint32_t k_seg = params->max_mismatches / kSegments;
         const uint32_t n_nbr = k_seg == 0 ? 1u : (k_seg == 1 ? 22u : 211u);
         const uint64_t n_pairs = (uint64_t)n_guides * kSegments * n_nbr;
         const uint64_t list_cap = n_pairs + (uint64_t)kBuckets * (kGuideUnroll - 1) + 2 * kGuideUnroll;
-        size_t temp_bytes = 0;
-        VSC_HIP_H(sort32_temp_bytes(n_pairs, 16, &temp_bytes));
-        VSC_HIP_H(ctx->sort_temp.ensure(std::max<size_t>(temp_bytes, 16)));
-        for (DeviceBuf *b : {&ctx->seed_k1, &ctx->seed_k2, &ctx->seed_v1, &ctx->seed_v2}) VSC_HIP_H(b->ensure(n_pairs * sizeof(uint32_t)));
         VSC_HIP_H(ctx->seed_off.ensure((kBuckets + 1) * sizeof(uint32_t)));
         VSC_HIP_H(ctx->seed_poff.ensure((kBuckets + 1) * sizeof(uint32_t)));
         VSC_HIP_H(ctx->seed_lrest.ensure(list_cap * sizeof(uint4)));
         VSC_HIP_H(hipMemsetAsync(ctx->seed_lrest.p, 0xFF, list_cap * sizeof(uint4), ctx->stream));  // padding: y = ~0, skipped
-        VSC_HIP_H(launch_seed_enum((const uint2 *)ctx->guides.p, n_guides, n_nbr, (uint32_t *)ctx->seed_k1.p,
-                                   (uint32_t *)ctx->seed_v1.p, ctx->stream));
-        VSC_HIP_H(launch_sort32(ctx->sort_temp.p, temp_bytes, (const uint32_t *)ctx->seed_k1.p, (uint32_t *)ctx->seed_k2.p,
-                                (const uint32_t *)ctx->seed_v1.p, (uint32_t *)ctx->seed_v2.p, n_pairs, 16, ctx->stream));
-        VSC_HIP_H(launch_seed_lists((const uint32_t *)ctx->seed_k2.p, (const uint32_t *)ctx->seed_v2.p, n_pairs,
-                                    (uint32_t *)ctx->seed_off.p, (uint32_t *)ctx->seed_poff.p, (const uint2 *)ctx->guides.p,
-                                    (uint4 *)ctx->seed_lrest.p, ctx->stream));
+        VSC_HIP_H(launch_seed_lists((const uint2 *)ctx->guides.p, n_guides, n_nbr, (uint32_t *)ctx->seed_off.p,
+                                    (uint32_t *)ctx->seed_poff.p, (uint4 *)ctx->seed_lrest.p, ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
         sa.chunk_tab = genome->d_ix_chunk_tab;
         sa.n_chunks = genome->ix_chunks;

@@ -278,10 +278,8 @@ hipError_t launch_sort32(void *temp, size_t temp_bytes, const uint32_t *keys_in,
 hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint32_t *keys, uint32_t *idx, hipStream_t stream);
 hipError_t launch_lower_bound(const uint32_t *sorted_keys, uint64_t n, uint32_t n_buckets, uint32_t key_offset,
                               uint32_t base, uint32_t *out, hipStream_t stream);
-hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *keys, uint32_t *gids,
-                            hipStream_t stream);
-hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted_gids, uint64_t n_pairs, uint32_t *off,
-                             uint32_t *poff, const uint2 *guides, uint4 *list_rest, hipStream_t stream);
+hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *count, uint32_t *poff,
+                             uint4 *list_rest, hipStream_t stream);
 hipError_t launch_seed_pack16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, uint64_t n, uint4 *rec, hipStream_t stream);
 hipError_t launch_seed_gather16(const uint4 *rec, const uint32_t *idx, uint64_t n, uint4 *out, hipStream_t stream);
 hipError_t launch_seed_compact(const uint4 *sites16, uint64_t n_per_table, uint64_t n, uint2 *sites8, uint32_t *edge_bits,

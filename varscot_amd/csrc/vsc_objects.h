@@ -64,12 +64,12 @@ struct vsc_ctx {
     vsc_timing timing{};
     vsc_debug_params dbg = vsc::default_debug_params();  // test / experiment hooks (include/varscot_hip_debug.h)
     // keys_a / keys_b: the two record buffers the bin sort alternates between (keys_a + vals_a: the scan's (key, value) pairs)
-    vsc::DeviceBuf counters, guides, keys_a, keys_b, vals_a, sort_temp, score_mit, score_flags, score_feat;
+    vsc::DeviceBuf counters, guides, keys_a, keys_b, vals_a, score_mit, score_flags, score_feat;
     vsc::DeviceBuf sort_segs, sort_tabs, sort_over, score_sched;
     // host staging of the sort's segment tables: uploaded with hipMemcpyAsync, so they must outlive the call that enqueues them
     std::vector<vsc::SortSeg> host_segs;
     std::vector<uint32_t> host_tile0;  // bin sort: segment table + tile starts, per-bin tables, oversize list + counter
-    vsc::DeviceBuf seed_k1, seed_k2, seed_v1, seed_v2, seed_off, seed_poff, seed_lrest;  // per-search read lists
+    vsc::DeviceBuf seed_off, seed_poff, seed_lrest;  // per-search read lists: bucket counts, padded list starts, entries
     // the forest of the last classification call, as the kernels read it (prepare_forest in vsc_api.cpp)
     struct Forest {
         vsc::DeviceBuf nodes, ranks;   // nodes + column table; activity ranks of the reads of a fused call

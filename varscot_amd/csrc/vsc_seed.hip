@@ -170,19 +170,17 @@ __device__ __forceinline__ void substitute(uint32_t &h, uint32_t &l, uint32_t p,
     l = (l & ~(1u << p)) | ((d & 1u) << p);
 }
 
-// One thread per (read, segment, neighbour): the bucket of the neighbour 7-mer.
+// The per-bucket read lists are a counting sort over the 49 152 buckets, done by two passes of the same
+// enumeration: pass 1 counts the entries of every bucket, a one-workgroup scan turns the counts into padded list
+// starts, pass 2 recomputes every entry and drops it into its bucket's next free slot.  (Rounds 1-2 materialised
+// (bucket, read) pairs and sorted them with rocPRIM: three launches x seven digit passes inside the timed step.)
+// The order of the entries INSIDE a bucket's list is the order in which pass 2's atomics land - it decides nothing:
+// every read of a list is compared with every site of the bucket, and the result is sorted afterwards.
+//
 // Neighbour numbering: 0 = the segment itself; 1..21 = one substitution (position * 3 + alt);
 // 22..210 = two substitutions (pair * 9 + alt1 * 3 + alt2).  n_nbr = 1, 22 or 211 for k = 0, 1, 2.
-__global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr,
-                                                        uint32_t *keys, uint32_t *gids)
+__device__ __forceinline__ uint32_t seed_neighbour(const uint2 gp, uint32_t s, uint32_t n, uint32_t *dist)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t total = (uint64_t)n_guides * kSegments * n_nbr;
-    if (i >= total) return;
-    const uint32_t n = (uint32_t)(i % n_nbr);
-    const uint32_t s = (uint32_t)((i / n_nbr) % kSegments);
-    const uint32_t g = (uint32_t)(i / ((uint64_t)n_nbr * kSegments));
-    const uint2 gp = guides[g];
     uint32_t h = (gp.x >> (kSegBases * s)) & 0x7Fu, l = (gp.y >> (kSegBases * s)) & 0x7Fu;
     if (n >= 22) {
         const uint32_t e = n - 22, pi = e / 9, alts = e % 9;
@@ -192,24 +190,49 @@ __global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uin
         const uint32_t e = n - 1;
         substitute(h, l, e / 3, e % 3 + 1);
     }
-    keys[i] = s * kBucketsPerSeg + ((h << kSegBases) | l);
     // substitutions always change the base, so the read's own segment differs from this neighbour in
     // exactly d = 0 / 1 / 2 positions: the seed distance of every site filed under the neighbour's bucket
-    const uint32_t d = n >= 22 ? 2u : (n >= 1 ? 1u : 0u);
-    gids[i] = g | (d << kListDistShift);
+    *dist = n >= 22 ? 2u : (n >= 1 ? 1u : 0u);
+    return s * kBucketsPerSeg + ((h << kSegBases) | l);
 }
 
-// poff[b] = sum over b' < b of roundup4(off[b'+1] - off[b']); one workgroup, kBuckets + 1 outputs
-__global__ __launch_bounds__(1024) void seed_pad_scan_kernel(const uint32_t *off, uint32_t *poff)
+// The 16 read positions outside segment `seg`, packed in ascending order ("rest" of a 23-bit plane).
+__device__ __forceinline__ uint32_t rest_of(uint32_t v, uint32_t seg)
+{
+    v &= kMask23;
+    if (seg == 0) return v >> kSegBases;
+    if (seg == 1) return (v & 0x7Fu) | ((v >> (2 * kSegBases)) << kSegBases);
+    return (v & 0x3FFFu) | ((v >> (3 * kSegBases)) << (2 * kSegBases));
+}
+
+// One thread per (read, segment, neighbour).  kScatter = false: count[bucket]++.  kScatter = true: the list entry
+// goes to poff[bucket] + (cursor[bucket]++) - x = rest(hi) | rest(lo) << 16, y = read index | seed distance << 30,
+// z / w = the full hi / lo planes.
+template <bool kScatter>
+__global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *count,
+                                                        const uint32_t *poff, uint4 *list_rest)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = (uint64_t)n_guides * kSegments * n_nbr;
+    if (i >= total) return;
+    const uint32_t n = (uint32_t)(i % n_nbr);
+    const uint32_t s = (uint32_t)((i / n_nbr) % kSegments);
+    const uint32_t g = (uint32_t)(i / ((uint64_t)n_nbr * kSegments));
+    const uint2 gp = guides[g];
+    uint32_t d;
+    const uint32_t b = seed_neighbour(gp, s, n, &d);
+    const uint32_t at = atomicAdd(&count[b], 1u);
+    if (kScatter) list_rest[poff[b] + at] = make_uint4(rest_of(gp.x, s) | (rest_of(gp.y, s) << 16), g | (d << kListDistShift), gp.x, gp.y);
+}
+
+// poff[b] = sum over b' < b of roundup4(count[b']); the counts are cleared for pass 2; one workgroup, kBuckets + 1 outputs
+__global__ __launch_bounds__(1024) void seed_pad_scan_kernel(uint32_t *count, uint32_t *poff)
 {
     __shared__ uint32_t partial[1024];
     constexpr uint32_t per = kBuckets / 1024;  // 48
     const uint32_t t = threadIdx.x;
     uint32_t sum = 0;
-    for (uint32_t i = 0; i < per; ++i) {
-        const uint32_t b = t * per + i;
-        sum += (off[b + 1] - off[b] + (kGuideUnroll - 1)) & ~(uint32_t)(kGuideUnroll - 1);
-    }
+    for (uint32_t i = 0; i < per; ++i) sum += (count[t * per + i] + (kGuideUnroll - 1)) & ~(uint32_t)(kGuideUnroll - 1);
     partial[t] = sum;
     block_sync();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -222,57 +245,24 @@ __global__ __launch_bounds__(1024) void seed_pad_scan_kernel(const uint32_t *off
     for (uint32_t i = 0; i < per; ++i) {
         const uint32_t b = t * per + i;
         poff[b] = run;
-        run += (off[b + 1] - off[b] + (kGuideUnroll - 1)) & ~(uint32_t)(kGuideUnroll - 1);
+        run += (count[b] + (kGuideUnroll - 1)) & ~(uint32_t)(kGuideUnroll - 1);
+        count[b] = 0;
     }
     if (t == 1023) poff[kBuckets] = run;
 }
 
-// Scatters the sorted (bucket, read) pairs into the padded per-bucket lists.
-// The 16 read positions outside segment `seg`, packed in ascending order ("rest" of a 23-bit plane).
-__device__ __forceinline__ uint32_t rest_of(uint32_t v, uint32_t seg)
-{
-    v &= kMask23;
-    if (seg == 0) return v >> kSegBases;
-    if (seg == 1) return (v & 0x7Fu) | ((v >> (2 * kSegBases)) << kSegBases);
-    return (v & 0x3FFFu) | ((v >> (3 * kSegBases)) << (2 * kSegBases));
-}
-
-// list_rest: x = rest(hi) | rest(lo) << 16, y = read index | seed distance << 30, z / w = the full hi / lo planes
-// (for the hit path).
-__global__ __launch_bounds__(256) void seed_list_kernel(const uint32_t *sorted_keys, const uint32_t *sorted_gids,
-                                                        uint64_t n_pairs, const uint32_t *off, const uint32_t *poff,
-                                                        const uint2 *guides, uint4 *list_rest)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pairs) return;
-    const uint32_t b = sorted_keys[i], v = sorted_gids[i];
-    const uint32_t g = v & ((1u << kListDistShift) - 1u);
-    const uint32_t dst = poff[b] + ((uint32_t)i - off[b]);
-    const uint2 gp = guides[g];
-    const uint32_t seg = b / (uint32_t)kBucketsPerSeg;
-    list_rest[dst] = make_uint4(rest_of(gp.x, seg) | (rest_of(gp.y, seg) << 16), v, gp.x, gp.y);
-}
-
-hipError_t launch_seed_enum(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *keys, uint32_t *gids,
-                            hipStream_t stream)
+// count: kBuckets words of scratch; poff: kBuckets + 1 list starts (multiples of kGuideUnroll); list_rest: the lists,
+// pre-filled with the padding pattern (y = ~0) by the caller
+hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *count, uint32_t *poff,
+                             uint4 *list_rest, hipStream_t stream)
 {
     const uint64_t total = (uint64_t)n_guides * kSegments * n_nbr;
-    if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(seed_enum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, guides, n_guides, n_nbr,
-                       keys, gids);
-    return hipGetLastError();
-}
-
-hipError_t launch_seed_lists(const uint32_t *sorted_keys, const uint32_t *sorted_gids, uint64_t n_pairs, uint32_t *off,
-                             uint32_t *poff, const uint2 *guides, uint4 *list_rest, hipStream_t stream)
-{
-    hipError_t e = launch_lower_bound(sorted_keys, n_pairs, kBuckets, 0, 0, off, stream);
+    hipError_t e = hipMemsetAsync(count, 0, (size_t)kBuckets * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(seed_pad_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)off, poff);
-    e = hipGetLastError();
-    if (e != hipSuccess || n_pairs == 0) return e;
-    hipLaunchKernelGGL(seed_list_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, sorted_keys,
-                       sorted_gids, n_pairs, (const uint32_t *)off, (const uint32_t *)poff, guides, list_rest);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (total) hipLaunchKernelGGL(seed_enum_kernel<false>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, n_nbr, count, (const uint32_t *)nullptr, (uint4 *)nullptr);
+    hipLaunchKernelGGL(seed_pad_scan_kernel, dim3(1), dim3(1024), 0, stream, count, poff);
+    if (total) hipLaunchKernelGGL(seed_enum_kernel<true>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, n_nbr, count, (const uint32_t *)poff, list_rest);
     return hipGetLastError();
 }
 
