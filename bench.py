@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--classify", action="store_true",
                     help="workload c5: score -> classify fused (vsc_score_classify_hits: the reference's forest walked per hit, "
                          "2 bytes of votes per hit out) instead of writing the 64-byte packed feature rows")
+    ap.add_argument("--hook", action="append", default=[], metavar="NAME=VALUE",
+                    help="experiment hook of include/varscot_hip_debug.h (e.g. seed_groups_per_cu=2); the defaults are what "
+                         "every reported number uses")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch check without a GPU: the ranks form the process group (gloo with --rehearse), all-reduce "
                          "once, rank 0 prints a JSON line saying what the communicator reported")
@@ -240,6 +243,9 @@ def main():
     hi, lo, nm, _, _, _ = synth.synthetic_planes(total_bases, wb, min(we + 1, n_words_total))
     t_gen = time.perf_counter() - t_gen
     ctx = va.Context(local_rank)
+    hooks = {h.split("=", 1)[0]: int(h.split("=", 1)[1]) for h in args.hook}
+    if hooks:
+        ctx.set_debug(**hooks)
     genome = va.Genome.from_shard(ctx, hi, lo, nm, wb, we - wb, table)
     del hi, lo, nm
     ids, seqs = synth.synthetic_guides(n_guides)
@@ -488,6 +494,7 @@ def main():
                        "max_mismatches": max_mm, "parallelism": "genome-shard x%d" % world, "algorithm": algorithm,
                        "multi_gpu_path": ("torch.distributed (RCCL) one process per GPU: varscot_amd/dist.py" if use_dist else None),
                        "exchange": (args.exchange if use_dist else None), "sub_batches": (sub_batches if pipelined else 1),
+                       "hooks": (hooks or None),
                        "rccl_ranks": (dist.get_world_size() if use_dist else None),
                        "backend": (dist.get_backend() if use_dist else None),
                        "hits_per_step": int(total_hits), "candidate_sites_per_s": total_hits * args.steps / dt,

@@ -6,7 +6,7 @@
 #   gpurun -- 'bash tools/gpu.sh bench c3 [bench.py args]'                      one bench line -> gpurun_out/<tag>/
 #   gpurun -- 'bash tools/gpu.sh ab c3 libA.so libB.so [reps]'                  alternate two builds (VSC_LIB_PATH)
 #   gpurun -- 'bash tools/gpu.sh stats c3'                                      rocprofv3 --kernel-trace --stats
-#   gpurun -- 'bash tools/gpu.sh pmc c3 "FETCH_SIZE" [kernel name parts]'      one counter group, one pass
+#   gpurun -- 'bash tools/gpu.sh pmc c3 "FETCH_SIZE" ["kernel name parts" [bench.py args]]'   one counter group, one pass
 #   gpurun -- 'bash tools/gpu.sh collect r03'                                   tools/collect_profiles.sh
 #   gpurun -- 'bash tools/gpu.sh bw'                                            fill / read / copy rates of the part
 # TAG (environment) names the directory under gpurun_out/ (default: the subcommand).  Steps are joined so that a
@@ -40,11 +40,11 @@ stats)
     find "$OUT" -name '*kernel_trace.csv' -delete
     cut -d, -f1-4 "$OUT"/stats_$W/*/*kernel_stats.csv "$OUT"/stats_$W/*kernel_stats.csv 2> /dev/null | grep -E "vsc::" | head -16;;
 pmc)
-    W=${1:?workload}; CTR=${2:?counters}; shift; shift; export PMC_KERNELS="${*:-seed_sliced_kernel}"
+    W=${1:?workload}; CTR=${2:?counters}; export PMC_KERNELS="${3:-seed_sliced_kernel}"; shift; shift; shift || true
     # TA_* counters are refused: the one pass that used them on this pool (round 1) never returned; cause undetermined
     case " $CTR " in *" TA_"*) echo "gpu.sh: TA_* counters are refused on this pool" >&2; exit 2;; esac
     rm -rf "$OUT/pmc"; cd /tmp && export TMPDIR=/tmp
-    timeout -k 10 500 rocprofv3 --pmc $CTR -d "$OUT/pmc" -o run --output-format csv -- python3 "$ROOT/bench.py" --workload "$W" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_bench.json" 2> "$OUT/pmc.err" || { tail -5 "$OUT/pmc.err"; exit 1; }
+    timeout -k 10 500 rocprofv3 --pmc $CTR -d "$OUT/pmc" -o run --output-format csv -- python3 "$ROOT/bench.py" --workload "$W" --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$OUT/pmc_bench.json" 2> "$OUT/pmc.err" || { tail -5 "$OUT/pmc.err"; exit 1; }
     python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 parts = os.environ["PMC_KERNELS"].split()
