@@ -43,8 +43,10 @@ pmc)
     W=${1:?workload}; CTR=${2:?counters}; export PMC_KERNELS="${3:-seed_sliced_kernel}"; shift; shift; shift || true
     # TA_* counters are refused: the one pass that used them on this pool (round 1) never returned; cause undetermined
     case " $CTR " in *" TA_"*) echo "gpu.sh: TA_* counters are refused on this pool" >&2; exit 2;; esac
+    # (FETCH_SIZE and WRITE_SIZE do not fit one pass - rocprofv3 aborts with "exceeds the capabilities of the hardware"
+    # and then does not exit: one of them per call, and a short leash)
     rm -rf "$OUT/pmc"; cd /tmp && export TMPDIR=/tmp
-    timeout -k 10 500 rocprofv3 --pmc $CTR -d "$OUT/pmc" -o run --output-format csv -- python3 "$ROOT/bench.py" --workload "$W" --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$OUT/pmc_bench.json" 2> "$OUT/pmc.err" || { tail -5 "$OUT/pmc.err"; exit 1; }
+    timeout -k 10 240 rocprofv3 --pmc $CTR -d "$OUT/pmc" -o run --output-format csv -- python3 "$ROOT/bench.py" --workload "$W" --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$OUT/pmc_bench.json" 2> "$OUT/pmc.err" || { tail -5 "$OUT/pmc.err"; exit 1; }
     python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 parts = os.environ["PMC_KERNELS"].split()
