@@ -1019,6 +1019,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
     SeedArgs sa{};
     uint64_t part_cap = 0;
     int n_groups = 1;
+    bool seed_shared = false;
     if (algo == VSC_ALGO_SCAN) {
         fill_pam(a, params);
         fill_genome(a, ctx, genome);
@@ -1058,8 +1059,13 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         sa.counters = (unsigned long long *)ctx->counters.p;
         uint32_t groups_per_cu = kSlicedWavesPerSimd;  // resident groups (of four waves) per CU: registers / LDS of the kernel
         if (ctx->dbg.seed_groups_per_cu) groups_per_cu = ctx->dbg.seed_groups_per_cu;
+        // dense searches (c3: 129 reads per bucket) share a chunk between the four waves of a workgroup, sparse ones
+        // (c2: 13) keep a chunk per wave - see seed_sliced_kernel
+        seed_shared = n_pairs / kBuckets >= 48;
+        if (ctx->dbg.seed_shared >= 0) seed_shared = ctx->dbg.seed_shared == 1;
+        const uint32_t n_grabs = (sa.n_chunks + kSlicedGrab - 1) / kSlicedGrab;
         const uint32_t n_waves_max = (uint32_t)ctx->n_cus * groups_per_cu * kWavesPerGroup;
-        const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, (sa.n_chunks + kSlicedGrab - 1) / kSlicedGrab));
+        const uint32_t n_waves = std::max<uint32_t>(1, std::min<uint32_t>(n_waves_max, seed_shared ? n_grabs * kWavesPerGroup : n_grabs));
         n_groups = (int)((n_waves + kWavesPerGroup - 1) / kWavesPerGroup);
         // block of records a wave reserves per atomic and region (a power of two, 64 .. 1024): large when many hits
         // are expected, small otherwise (the unused tail of every wave's last block is written as sentinels
@@ -1096,7 +1102,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         } else {
             sa.hit_recs = (uint64_t *)ctx->keys_a.p;
             sa.part_cap = part_cap;
-            VSC_HIP_H(launch_seed_sliced(sa, n_groups, ctx->stream));
+            VSC_HIP_H(launch_seed_sliced(sa, n_groups, seed_shared, ctx->stream));
         }
         VSC_HIP_H(hipEventRecord(ctx->ev[2], ctx->stream));
         VSC_HIP_H(hipMemcpyAsync(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));

@@ -287,7 +287,7 @@ hipError_t launch_seed_compact(const uint4 *sites16, uint64_t n_per_table, uint6
 hipError_t launch_seed_chunk_flags(uint4 *chunk_tab, uint32_t n_chunks, const uint32_t *edge_bits, hipStream_t stream);
 hipError_t launch_seed_transpose(const uint4 *sites, const uint4 *chunk_tab, uint32_t n_chunks, uint32_t *vert,
                                  hipStream_t stream);
-hipError_t launch_seed_sliced(const SeedArgs &args, int n_groups, hipStream_t stream);
+hipError_t launch_seed_sliced(const SeedArgs &args, int n_groups, bool shared, hipStream_t stream);
 hipError_t launch_merge(const vsc_hit *in, const uint64_t *shard_off_dev, uint32_t n_shards, uint32_t K, uint64_t *bound,
                         uint64_t *key_off, vsc_hit *out, hipStream_t stream);
 

@@ -640,9 +640,17 @@ __device__ __forceinline__ void sliced_load_sites(const SeedArgs &a, const v4u &
 
 // (amdgpu_waves_per_eu: 5 waves per SIMD = at most 102 VGPRs; LDS: 5.7 KB per wave, 20 waves per CU)
 static_assert(kMaxPassReads <= (1 << kTokSlotShift) && kSlicedGrab <= 8 && kTokSlotShift + 3 <= kTokLaneShift, "token fields");
+// kShared: the four waves of a workgroup take the SAME chunks and a quarter of each chunk's read list each.  The
+// resident site records (16 KB per chunk, gathered 8 bytes per hit) then are a working set of one chunk per
+// workgroup instead of one per wave - 3 MB per XCD instead of 12 - which is what its 4 MB L2 can hold: with a chunk
+// per wave every gather of a hit fetched its line from the fabric again (FETCH_SIZE 65 GB per c3 search; 17 GB with
+// one workgroup per CU resident, tools/exp_groups.sh).  For sparse searches (c2: 13 reads per bucket) a chunk visit
+// is mostly the load of its bit-sliced block, which every sharing wave repeats: those keep a chunk per wave.
+template <bool kShared>
 __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(kSlicedWavesPerSimd, kSlicedWavesPerSimd))) void seed_sliced_kernel(
     const SeedArgs a)
 {
+    __shared__ uint32_t s_grab[2];
     __shared__ uint2 s_tok[kWavesPerGroup][kSlicedTokCap];
     __shared__ uint2 s_list[kWavesPerGroup][kWave];  // the current tile of 64 read-list entries (first halves)
     __shared__ uint32_t s_parts[kWavesPerGroup][kParts];
@@ -671,11 +679,23 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     const uint32_t slice_len = (a.n_chunks + kCursors - 1) / kCursors;
     // (uniform(): `wave` derives from threadIdx, and a slice the compiler takes for divergent drags the whole
     // chunk bookkeeping - table entries, list bounds, loop counters - from scalar into vector registers)
-    uint32_t slice = uniform((blockIdx.x * kWavesPerGroup + wave) % kCursors), exhausted = 0;
-    for (;;) {
+    uint32_t slice = uniform((kShared ? blockIdx.x : blockIdx.x * kWavesPerGroup + wave) % kCursors), exhausted = 0;
+    // the rank of this wave among the four that share a chunk rotates from chunk to chunk: the quarters of a list
+    // differ by up to four entries, and consecutive chunks mostly belong to the same bucket
+    const uint32_t wave_u = uniform(wave);
+    for (uint32_t iter = 0;; ++iter) {
         uint32_t off = 0;
-        if (w.lane == 0)
+        if (kShared) {
+            // one grab per workgroup: wave 0 asks, the others read its answer behind the barrier.  Every wave sees the
+            // same sequence of answers, so `slice` and `exhausted` evolve identically and all four leave together.
+            // (Two slots: a wave may be one iteration ahead of the slowest reader, never two - the barrier.)
+            if (threadIdx.x == 0)
+                s_grab[iter & 1u] = (uint32_t)atomicAdd(&a.counters[kCursorBase + slice * kCursorStride], (unsigned long long)kSlicedGrab);
+            block_sync();
+            off = s_grab[iter & 1u];
+        } else if (w.lane == 0) {
             off = (uint32_t)atomicAdd(&a.counters[kCursorBase + slice * kCursorStride], (unsigned long long)kSlicedGrab);
+        }
         off = uniform(off);
         const uint32_t slice_begin = slice * slice_len, slice_end = min(slice_begin + slice_len, a.n_chunks);
         if (slice_begin + off >= slice_end) {
@@ -690,9 +710,23 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
         // The lane's block of bit-sliced sites (8 x 16-byte vector loads) is NOT fetched ahead: holding the next
         // block cost 32 VGPRs, and at 93 instead of 125 a fifth wave per SIMD fits, which covers more than the one
         // exposed round trip per chunk (c3: 26.4 -> 26.0 ms, c2: 2.28 -> 2.07 ms; without the fifth wave 26.6 / 2.27).
+        // this wave's part [q0, q1) of the read list [g0, g1) of a chunk: all of it, or (kShared) the quarter of rank r -
+        // whole groups of kGuideUnroll entries
+        auto my_part = [&](uint32_t g0, uint32_t g1, uint32_t r, uint32_t &q0, uint32_t &q1) {
+            if (!kShared) {
+                q0 = g0;
+                q1 = g1;
+                return;
+            }
+            const uint32_t n4 = (g1 - g0) / (uint32_t)kGuideUnroll;
+            const uint32_t base = n4 / (uint32_t)kWavesPerGroup, rem = n4 % (uint32_t)kWavesPerGroup;
+            q0 = g0 + (r * base + min(r, rem)) * (uint32_t)kGuideUnroll;
+            q1 = q0 + (base + (r < rem ? 1u : 0u)) * (uint32_t)kGuideUnroll;
+        };
         v4u t0 = ctab[first];                             // chunk c
         v4u t1 = ctab[min(first + 1, last - 1)];          // chunk c + 1
-        uint32_t p0a = poff[t0.z & kChunkBucketMask], p0b = poff[(t0.z & kChunkBucketMask) + 1];
+        uint32_t p0a, p0b;
+        my_part(poff[t0.z & kChunkBucketMask], poff[(t0.z & kChunkBucketMask) + 1], wave_u, p0a, p0b);
         uint2 nl = sliced_load_list(a, p0a, p0b, w.lane);
         uint32_t p1a = poff[t1.z & kChunkBucketMask], p1b = poff[(t1.z & kChunkBucketMask) + 1];
         v4u t2 = ctab[min(first + 2, last - 1)];          // chunk c + 2
@@ -703,8 +737,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
             sliced_load_sites(a, cur, g0 != g1, w.lane, v);
             // advance the pipeline before the comparison so that its loads overlap it
             t0 = t1;
-            p0a = p1a;
-            p0b = p1b;
+            my_part(p1a, p1b, (wave_u + (c + 1 - first)) % (uint32_t)kWavesPerGroup, p0a, p0b);
             uint2 tile = nl;
             nl = sliced_load_list(a, p0a, c + 1 < last ? p0b : p0a, w.lane);
             t1 = t2;
@@ -723,7 +756,8 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
             const int32_t left = (int32_t)cur.y - (int32_t)(w.lane * kSlicedSites);
             const uint32_t valid = left >= kSlicedSites ? 0xFFFFFFFFu : (left > 0 ? (1u << left) - 1u : 0u);
             pairs += (unsigned long long)cur.y * (g1 - g0);
-            visited += cur.y;
+            // (the block of a shared chunk comes from HBM once: counted by the wave of rank 0)
+            if (!kShared || (wave_u + (c - first)) % (uint32_t)kWavesPerGroup == 0) visited += cur.y;
             // The read list goes through LDS in tiles of 64 entries: one coalesced vector load per tile,
             // issued a whole tile (or chunk) ahead, then one broadcast LDS read per entry.  Scalar loads of
             // the entries, a group at a time, left ~1 us of scalar-cache miss latency per group exposed
@@ -766,9 +800,12 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     }
 }
 
-hipError_t launch_seed_sliced(const SeedArgs &args, int n_groups, hipStream_t stream)
+hipError_t launch_seed_sliced(const SeedArgs &args, int n_groups, bool shared, hipStream_t stream)
 {
-    hipLaunchKernelGGL(seed_sliced_kernel, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
+    if (shared)
+        hipLaunchKernelGGL(seed_sliced_kernel<true>, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
+    else
+        hipLaunchKernelGGL(seed_sliced_kernel<false>, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
     return hipGetLastError();
 }
 
