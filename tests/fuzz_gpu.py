@@ -62,7 +62,8 @@ def one(ctx, seed):
         world = int(rng.integers(1, 4))
         # sort knobs: smaller LDS capacity / fewer bits per level force partition levels and the oversize path
         hooks = {}
-        for k, choices in (("sort_cap", [0, 0, 64, 1000]), ("sort_max_bits", [0, 0, 2, 5]), ("seed_reserve", [0, 64, 1024])):
+        for k, choices in (("sort_cap", [0, 0, 64, 1000]), ("sort_max_bits", [0, 0, 2, 5]), ("seed_reserve", [0, 64, 1024]),
+                           ("seed_shared", [-1, 0, 1, 1])):
             hooks[k] = choices[int(rng.integers(0, len(choices)))]
         ctx.set_debug(**hooks)
         if world > 1 and rng.integers(0, 2):  # the shards behind the C ABI: contexts on this device, gather, merge

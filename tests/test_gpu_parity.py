@@ -18,6 +18,13 @@ def ctx():
     c.close()
 
 
+@pytest.fixture
+def hooks(ctx):
+    """ctx.set_debug(...) for one test (include/varscot_hip_debug.h); the defaults come back afterwards."""
+    yield ctx.set_debug
+    ctx.set_debug()
+
+
 ALGOS = ["scan", "seed"]
 
 
@@ -51,6 +58,23 @@ def test_search_matches_oracle(ctx, oracle, seed, max_mm, extra_pam, algo):
     got = gpu_search(ctx, contigs, guides, max_mm, extra_pam, algo=algo)
     assert len(want) > 20
     assert hits_as_tuples(got) == hits_as_tuples(want)  # same records in the same (sorted) order
+
+
+@pytest.mark.parametrize("shared", [0, 1])
+@pytest.mark.parametrize("seed,max_mm,n_reads", [(201, 8, 300), (202, 6, 40), (203, 2, 7), (204, 7, 1500)])
+def test_seed_search_with_a_chunk_per_wave_and_per_workgroup(ctx, oracle, hooks, shared, seed, max_mm, n_reads):
+    """seed_sliced_kernel<false> (every wave its own chunks) and <true> (the four waves of a workgroup share a chunk
+    and take a quarter of its read list each: what dense searches like c3 run) return the oracle's records - forced
+    either way by the hook, on read sets from 7 (most quarters empty) to 1 500 reads (lists of several tiles), with
+    planted sites, N runs, tiny contigs and contig-end windows."""
+    hooks(seed_shared=shared)
+    rng = np.random.default_rng(seed)
+    guides = random_guides(rng, n_reads)
+    contigs = make_genome(seed, [70000, 23, 9000, 30000, 64], guides[:60], max_mm, n_plant=400, n_runs=5)
+    want = oracle.search_fast(contigs, guides, max_mm)
+    got = gpu_search(ctx, contigs, guides, max_mm, algo="seed")
+    assert len(want) > 100
+    assert got.tobytes() == want.tobytes()
 
 
 def test_search_matches_reference_flow_order(ctx, oracle):
@@ -566,13 +590,6 @@ def test_exchange_records_pack_and_merge(ctx, oracle, world):
     assert merged.to_numpy().tobytes() == sel.tobytes()
     merged.close()
     any_shard.close()
-
-
-@pytest.fixture
-def hooks(ctx):
-    """ctx.set_debug(...) for one test (include/varscot_hip_debug.h); the defaults come back afterwards."""
-    yield ctx.set_debug
-    ctx.set_debug()
 
 
 @pytest.mark.parametrize("cap,max_bits", [(None, None), (4096, 11), (256, 3), (16, 1)])
