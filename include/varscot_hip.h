@@ -112,7 +112,8 @@ typedef struct {
     uint32_t sort_levels;    /* partition levels the bin sort ran (0: the regions fitted its last stage as they were) */
     uint32_t sort_bin_bits;  /* key bits of the first partition level */
     uint32_t read_passes;    /* passes over the read set (a pass takes at most 16 384 reads) */
-    uint32_t reserved;
+    uint32_t sort_fallbacks; /* sort levels that started without a histogram pass (fixed bin slots) and had to run again with
+                                one because a bin outgrew its slot (repeat-rich genomes; the genome remembers) */
 } vsc_timing;
 
 /* ---- context ------------------------------------------------------------------------------- */

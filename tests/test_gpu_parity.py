@@ -627,6 +627,52 @@ def test_baseline_config_c1(ctx, oracle, algo):
     assert hits_as_tuples(got) == hits_as_tuples(want)
 
 
+def test_sort_without_the_histogram_pass_and_its_fallback(ctx, oracle, hooks):
+    """The seed search's first sort level in SLOT MODE (no histogram pass: fixed bin slots, room reserved by the bin
+    cursors alone), on a result with thousands of hits per read: (a) slots large enough - one level, no fallback;
+    (b) slots smaller than the fullest bins - the partition raises its overflow flag, nothing is finalized, the
+    level runs again with the histogram (sort_fallbacks = 1), and the genome remembers: the next search goes the
+    exact way at once; (c) slot mode switched off.  Same records every way."""
+    rng = np.random.default_rng(4711)
+    guides = random_guides(rng, 70)
+    pieces = []
+    for _ in range(9000):
+        g = guides[int(rng.integers(0, len(guides)))]
+        pieces.append(mutate(rng, g, int(rng.integers(0, 7)), 0, 20) + random_seq(rng, int(rng.integers(0, 3))))
+    contigs = make_genome(4711, [60000, 20000], guides, 8, n_plant=200) + ["".join(pieces)]
+    want = oracle.search_fast(contigs, guides, 8)
+    assert len(want) > 8000
+    packed = va.PackedGenome.from_sequences(contigs)
+
+    def run(gen):
+        h = gen.search(guides, 8, algorithm="seed")
+        got = h.to_numpy().copy()
+        h.close()
+        t = ctx.timing()
+        assert got.tobytes() == want.tobytes()
+        return t["sort_levels"], t["sort_fallbacks"]
+
+    hooks(sort_cap=512, sort_optimistic=1, sort_slot_cap=4096)           # (a)
+    gen = ctx.load_genome(packed)
+    assert run(gen) == (1, 0)
+    gen.close()
+    hooks(sort_cap=512, sort_slot_cap=40)                                # (b): default policy, slots too small
+    gen = ctx.load_genome(packed)
+    levels, fallbacks = run(gen)
+    assert fallbacks == 1 and levels >= 1
+    assert run(gen)[1] == 0                                              # remembered: exact at once
+    gen.close()
+    hooks(sort_cap=512, sort_optimistic=0)                               # (c)
+    gen = ctx.load_genome(packed)
+    assert run(gen)[1] == 0
+    gen.close()
+    hooks(sort_cap=64, sort_optimistic=1, sort_slot_cap=600)             # bins between cap and slot: on to level 2 from their slots
+    gen = ctx.load_genome(packed)
+    levels, fallbacks = run(gen)
+    assert levels >= 2 and fallbacks == 0
+    gen.close()
+
+
 @pytest.mark.parametrize("cap", [None, 512])
 def test_hit_buffer_growth_and_sort_partition(ctx, oracle, cap, hooks):
     """Thousands of hits per read on a small genome: the hit buffer sized from the uniform-genome model has to

@@ -805,6 +805,7 @@ struct SortInfo {
     unsigned levels = 0;     // partition levels run (0: every region fitted the finalize kernel as it was)
     unsigned bin_bits = 0;   // key bits of the first partition level
     uint64_t bytes = 0;      // bytes the sort kernels moved: 8 per record read or written, 16 per result record
+    unsigned slot_fallbacks = 0;  // slot-mode levels that overflowed and ran again with the histogram
 };
 
 // Orders the packed records of `segs` (each segment independently, ascending) and writes the vsc_hit
@@ -813,8 +814,13 @@ struct SortInfo {
 // buffer of the same size; `key_bits` = significant bits of record >> kRecPosShift inside a segment.
 // pair_keys != null: level 0 of the streaming scan - one segment of (key, value) pairs, partitioned by region
 // into `other` and packed on the way; the regions then are the segments.
+// slots != null (the seed search's level 1): the first partition level runs in SLOT MODE when *slots allows it -
+// no histogram pass: every bin owns a fixed slot of `other` (grown to n_bins x slot capacity through `other_buf`), the
+// partition reserves room with the bin cursors alone; a bin that outgrows its slot (repeats) makes the level run again
+// with the histogram and clears *slots, so that later searches of this genome and budget go the exact way at once.
 hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg> segs, uint64_t *src, uint64_t *other,
-                    unsigned key_bits, unsigned pos_pad, vsc_hit *out, hipEvent_t ev_sorted, SortInfo *info)
+                    unsigned key_bits, unsigned pos_pad, vsc_hit *out, hipEvent_t ev_sorted, SortInfo *info,
+                    DeviceBuf *other_buf = nullptr, bool *slots = nullptr)
 {
     // (key_bits counts the meaningful bits: the pos_pad zero bits at the bottom of every position field are not among them)
     hipStream_t st = ctx->stream;
@@ -827,6 +833,10 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
     unsigned max_bits = kSortMaxBinBits;
     if (dbg.sort_cap) sort_cap = std::min<uint64_t>(kSortCap, std::max<uint32_t>(16, dbg.sort_cap));
     if (dbg.sort_max_bits) max_bits = std::min<unsigned>(kSortMaxBinBits, std::max<uint32_t>(1, dbg.sort_max_bits));
+    // a slot holds a quarter more than the finalize kernel orders in LDS: bins between the two go to another level
+    // from their slot, bins beyond make the level fall back
+    uint64_t slot_cap = dbg.sort_slot_cap ? dbg.sort_slot_cap : (sort_cap + sort_cap / 4 + 15) / 16 * 16;
+    slot_cap = std::max<uint64_t>(slot_cap, 16);
     for (unsigned level = 1; !segs.empty(); ++level) {
         if (level > 48) return hipErrorUnknown;  // cannot happen: every level consumes key bits, keys are unique
         uint64_t n_max = 0, n_all = 0;
@@ -842,9 +852,9 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             while (bits > 1 && ((uint64_t)segs.size() << bits) > (1ull << 22)) --bits;  // bounded bin tables
         }
         const size_t n_segs = segs.size();
-        if (dbg.sort_debug)
-            std::fprintf(stderr, "[vsc sort] level %u: %zu segments, %llu records, largest %llu, %u bits (of %u left), cap %llu\n", level,
-                         n_segs, (unsigned long long)n_all, (unsigned long long)n_max, bits, rem, (unsigned long long)sort_cap);
+        const size_t n_bins = n_segs << bits;
+        bool use_slots = level == 1 && bits && slots && other_buf && (dbg.sort_optimistic == 1 || (dbg.sort_optimistic != 0 && *slots)) &&
+                         (uint64_t)n_bins * slot_cap < (1ull << 34);
         std::vector<uint32_t> &tile0 = ctx->host_tile0;
         tile0.assign(n_segs + 1, 0);
         uint64_t tiles = 0;
@@ -861,90 +871,120 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
         ctx->host_segs = segs;  // (the copy the asynchronous upload reads from)
         VSC_TRY(hipMemcpyAsync(d_segs, ctx->host_segs.data(), n_segs * sizeof(SortSeg), hipMemcpyHostToDevice, st));
         VSC_TRY(hipMemcpyAsync(d_tile0, tile0.data(), tile0.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        const size_t n_bins = n_segs << bits;
         VSC_TRY(ctx->sort_over.ensure(256 + n_bins * sizeof(SortSeg)));
-        uint32_t *d_n_over = (uint32_t *)ctx->sort_over.p;
-        VSC_TRY(hipMemsetAsync(d_n_over, 0, 2 * sizeof(uint32_t), st));  // [0] listed bins, [1] the finalize kernel's bin cursor
-        FinArgs f{};
-        f.segs = d_segs;
-        f.n_segs = (uint32_t)n_segs;
-        f.src = src;
-        if (bits) {
-            VSC_TRY(ctx->sort_tabs.ensure(3 * n_bins * sizeof(uint32_t)));
-            SortArgs a{};
-            a.segs = d_segs;
-            a.seg_tile0 = d_tile0;
-            a.n_segs = (uint32_t)n_segs;
-            a.n_tiles = (uint32_t)tiles;
-            a.in = src;
-            a.out = other;
-            a.hist = (uint32_t *)ctx->sort_tabs.p;
-            a.cursor = a.hist + n_bins;
-            a.bin_start = a.cursor + n_bins;
-            a.bin_bits = bits;
-            a.bin_shift = kRecPosShift + pos_pad + rem - bits;
-            if (dbg.sort_xcd != 0 && tiles >= 64) a.xcd_tiles = (uint32_t)((tiles + 7) / 8);
-            VSC_TRY(hipMemsetAsync(a.hist, 0, n_bins * sizeof(uint32_t), st));
-            VSC_TRY(launch_bin_hist(a, st));
-            VSC_TRY(launch_bin_scan(a, st));
-            if (dbg.sort_debug >= 2) {
-                // recount every bin on the host and compare with the device histogram
-                std::vector<uint32_t> h(n_bins);
-                VSC_TRY(hipMemcpyAsync(h.data(), a.hist, n_bins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-                VSC_TRY(hipStreamSynchronize(st));
-                for (size_t i = 0; i < n_segs; ++i) {
-                    std::vector<uint64_t> recs(segs[i].n_in);
-                    VSC_TRY(hipMemcpy(recs.data(), src + segs[i].in_off, recs.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-                    std::vector<uint32_t> want((size_t)1 << bits, 0);
-                    unsigned odd = 0;
-                    for (uint64_t r : recs) {
-                        if (r >> 63) continue;
-                        want[(r >> a.bin_shift) & (((uint64_t)1 << bits) - 1)]++;
-                        if (((r >> kRecPosShift & 0xFFFFFFFFu) >> pos_pad) > 100000u) odd++;
-                    }
-                    for (size_t b = 0; b < want.size(); ++b)
-                        if (want[b] != h[(i << bits) + b] || odd)
-                            std::fprintf(stderr, "[vsc sort]   seg %zu (in_off %llu n %u) bin %zu: device %u host %u, odd records %u\n", i,
-                                         (unsigned long long)segs[i].in_off, segs[i].n_in, b, h[(i << bits) + b], want[b], odd);
+        uint32_t *d_n_over = (uint32_t *)ctx->sort_over.p;  // [0] listed bins, [1] the finalize kernel's bin cursor, [2] slot overflow
+        if (bits) VSC_TRY(ctx->sort_tabs.ensure(3 * n_bins * sizeof(uint32_t)));
+        uint32_t flags[3] = {0, 0, 0};
+        for (;;) {  // once; twice when the slot partition overflowed
+            if (dbg.sort_debug)
+                std::fprintf(stderr, "[vsc sort] level %u: %zu segments, %llu records, largest %llu, %u bits (of %u left), cap %llu%s\n", level,
+                             n_segs, (unsigned long long)n_all, (unsigned long long)n_max, bits, rem, (unsigned long long)sort_cap,
+                             use_slots ? ", slot mode" : "");
+            VSC_TRY(hipMemsetAsync(d_n_over, 0, 3 * sizeof(uint32_t), st));
+            FinArgs f{};
+            f.segs = d_segs;
+            f.n_segs = (uint32_t)n_segs;
+            f.src = src;
+            if (bits) {
+                if (use_slots) {
+                    VSC_TRY(other_buf->ensure((size_t)n_bins * slot_cap * sizeof(uint64_t)));
+                    other = (uint64_t *)other_buf->p;
                 }
+                SortArgs a{};
+                a.segs = d_segs;
+                a.seg_tile0 = d_tile0;
+                a.n_segs = (uint32_t)n_segs;
+                a.n_tiles = (uint32_t)tiles;
+                a.in = src;
+                a.out = other;
+                a.hist = (uint32_t *)ctx->sort_tabs.p;
+                a.cursor = a.hist + n_bins;
+                a.bin_start = a.cursor + n_bins;
+                a.bin_bits = bits;
+                a.bin_shift = kRecPosShift + pos_pad + rem - bits;
+                if (dbg.sort_xcd != 0 && tiles >= 64) a.xcd_tiles = (uint32_t)((tiles + 7) / 8);
+                if (use_slots) {
+                    // partition first (cursors from zero), then the bin starts of the RESULT from the cursors
+                    a.hist = a.cursor;
+                    a.slot_cap = (uint32_t)slot_cap;
+                    a.overflow = d_n_over + 2;
+                    VSC_TRY(hipMemsetAsync(a.cursor, 0, n_bins * sizeof(uint32_t), st));
+                    VSC_TRY(launch_bin_partition(a, st));
+                    VSC_TRY(launch_bin_scan(a, st));
+                } else {
+                    VSC_TRY(hipMemsetAsync(a.hist, 0, n_bins * sizeof(uint32_t), st));
+                    VSC_TRY(launch_bin_hist(a, st));
+                    VSC_TRY(launch_bin_scan(a, st));
+                    if (dbg.sort_debug >= 2) {
+                        // recount every bin on the host and compare with the device histogram
+                        std::vector<uint32_t> h(n_bins);
+                        VSC_TRY(hipMemcpyAsync(h.data(), a.hist, n_bins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                        VSC_TRY(hipStreamSynchronize(st));
+                        for (size_t i = 0; i < n_segs; ++i) {
+                            std::vector<uint64_t> recs(segs[i].n_in);
+                            VSC_TRY(hipMemcpy(recs.data(), src + segs[i].in_off, recs.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                            std::vector<uint32_t> want((size_t)1 << bits, 0);
+                            for (uint64_t r : recs) {
+                                if (r >> 63) continue;
+                                want[(r >> a.bin_shift) & (((uint64_t)1 << bits) - 1)]++;
+                            }
+                            for (size_t b = 0; b < want.size(); ++b)
+                                if (want[b] != h[(i << bits) + b])
+                                    std::fprintf(stderr, "[vsc sort]   seg %zu (in_off %llu n %u) bin %zu: device %u host %u\n", i,
+                                                 (unsigned long long)segs[i].in_off, segs[i].n_in, b, h[(i << bits) + b], want[b]);
+                        }
+                    }
+                    VSC_TRY(launch_bin_partition(a, st));
+                }
+                f.src = other;
+                f.hist = a.hist;
+                f.bin_start = a.bin_start;
+                f.bin_bits = bits;
+                f.slot_cap = a.slot_cap;
+                f.overflow = a.overflow;
             }
-            VSC_TRY(launch_bin_partition(a, st));
-            rem -= bits;
-            f.src = other;
-            f.hist = a.hist;
-            f.bin_start = a.bin_start;
-            f.bin_bits = bits;
-            if (info) {
+            if (!sorted_marked && ev_sorted) {
+                VSC_TRY(hipEventRecord(ev_sorted, st));
+                sorted_marked = true;
+            }
+            const unsigned rem_after = rem - bits;
+            f.sub_bits = std::min<unsigned>(kSortSubBits, rem_after);
+            f.sub_shift = kRecPosShift + pos_pad + rem_after - f.sub_bits;
+            f.pos_pad = pos_pad;
+            f.low_bits = rem_after - f.sub_bits;
+            f.over = (SortSeg *)((char *)ctx->sort_over.p + 256);
+            f.over_cap = (uint32_t)std::min<size_t>(n_bins, 0xFFFFFFFFu);
+            f.n_over = d_n_over;
+            f.cursor = d_n_over + 1;
+            f.cap = (uint32_t)sort_cap;
+            f.contig_off = genome->d_contig_off;
+            f.n_contigs = genome->n_contigs;
+            f.out = out;
+            VSC_TRY(launch_bin_finalize(f, 2 * ctx->n_cus, st));  // two workgroups fit a CU (LDS)
+            if (info && bits) {
                 if (info->levels == 0) info->bin_bits = bits;
                 info->levels++;
-                info->bytes += 24 * n_all;  // histogram read, partition read + write
+                info->bytes += (use_slots ? 16 : 24) * n_all;  // (histogram read,) partition read + write
             }
+            if (info) info->bytes += 24 * n_all;  // finalize: 8-byte read, 16-byte write
+            if (!bits) break;  // every segment fitted: nothing can come back
+            VSC_TRY(hipMemcpyAsync(flags, d_n_over, sizeof flags, hipMemcpyDeviceToHost, st));
+            VSC_TRY(hipStreamSynchronize(st));
+            if (use_slots && flags[2]) {
+                // a bin outgrew its slot: the source is untouched, nothing was finalized - the same level again, exactly
+                use_slots = false;
+                *slots = false;
+                if (info) info->slot_fallbacks++;
+                continue;
+            }
+            break;
         }
-        if (!sorted_marked && ev_sorted) {
-            VSC_TRY(hipEventRecord(ev_sorted, st));
-            sorted_marked = true;
-        }
-        f.sub_bits = std::min<unsigned>(kSortSubBits, rem);
-        f.sub_shift = kRecPosShift + pos_pad + rem - f.sub_bits;
-        f.pos_pad = pos_pad;
-        f.low_bits = rem - f.sub_bits;
-        f.over = (SortSeg *)((char *)ctx->sort_over.p + 256);
-        f.over_cap = (uint32_t)std::min<size_t>(n_bins, 0xFFFFFFFFu);
-        f.n_over = d_n_over;
-        f.cursor = d_n_over + 1;
-        f.cap = (uint32_t)sort_cap;
-        f.contig_off = genome->d_contig_off;
-        f.n_contigs = genome->n_contigs;
-        f.out = out;
-        VSC_TRY(launch_bin_finalize(f, 2 * ctx->n_cus, st));  // two workgroups fit a CU (LDS)
-        if (info) info->bytes += 24 * n_all;  // finalize: 8-byte read, 16-byte write
-        if (!bits) break;  // every segment fitted: nothing can come back
-        uint32_t n_over = 0;
-        VSC_TRY(hipMemcpyAsync(&n_over, d_n_over, sizeof n_over, hipMemcpyDeviceToHost, st));
-        VSC_TRY(hipStreamSynchronize(st));
+        if (!bits) break;
+        rem -= bits;
+        const uint32_t n_over = flags[0];
         if (n_over == 0) break;
         segs.resize(n_over);
-        VSC_TRY(hipMemcpyAsync(segs.data(), f.over, (size_t)n_over * sizeof(SortSeg), hipMemcpyDeviceToHost, st));
+        VSC_TRY(hipMemcpyAsync(segs.data(), (char *)ctx->sort_over.p + 256, (size_t)n_over * sizeof(SortSeg), hipMemcpyDeviceToHost, st));
         VSC_TRY(hipStreamSynchronize(st));
         std::swap(src, other);  // the listed bins are spans of the buffer this level wrote
     }
@@ -1203,7 +1243,11 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         VSC_HIP_H(result_room(ctx, hits, used, n, projected));
         ht.lap("record storage");
         const unsigned key_bits = pos_bits + 1 + ceil_log2(std::min<uint32_t>(n_guides, kRegionReads));
-        VSC_HIP_H(bin_sort(ctx, genome, std::move(segs), src, other, key_bits, pos_pad, hits->d_records, ctx->ev[3], &info));
+        // the seed search's regions go through the slot partition (no histogram pass) unless this genome has shown
+        // bins that outgrow their slots at this budget
+        bool *slots = algo == VSC_ALGO_SEED ? &const_cast<vsc_genome *>(genome)->sort_slots_ok[params->max_mismatches] : nullptr;
+        VSC_HIP_H(bin_sort(ctx, genome, std::move(segs), src, other, key_bits, pos_pad, hits->d_records, ctx->ev[3], &info,
+                           algo == VSC_ALGO_SEED ? &ctx->keys_b : nullptr, slots));
     } else {
         VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
     }
@@ -1219,6 +1263,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
     t.sort_levels = std::max(t.sort_levels, info.levels);
     t.sort_bin_bits = std::max(t.sort_bin_bits, info.bin_bits);
     t.sort_bytes += info.bytes;
+    t.sort_fallbacks += info.slot_fallbacks;
     t.read_passes++;
     res->n = n;
     return VSC_OK;

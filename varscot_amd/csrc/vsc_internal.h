@@ -147,6 +147,11 @@ struct SortArgs {
     uint32_t bin_bits, bin_shift;  // bin = (record >> bin_shift) & ((1 << bin_bits) - 1)
     uint32_t pos_pad;              // level 0: left shift of the position field
     uint32_t xcd_tiles;            // partition: tiles per XCD (0: workgroup b takes tile b)
+    // slot mode (no histogram pass): bin i of the level owns records [i * slot_cap, (i + 1) * slot_cap) of `out`; the
+    // partition reserves room with `cursor` (zeroed) alone and raises *overflow when a bin does not fit its slot -
+    // the caller then repeats the level with the histogram.  0: exact mode (bin_start from the histogram)
+    uint32_t slot_cap;
+    uint32_t *overflow;
 };
 
 struct FinArgs {
@@ -167,6 +172,8 @@ struct FinArgs {
     const uint32_t *contig_off;    // ascending global start positions of all contigs
     uint32_t n_contigs;
     vsc_hit *out;
+    uint32_t slot_cap;             // slot mode: bin i's records are src[i * slot_cap ...) (hist = the partition's cursors)
+    const uint32_t *overflow;      // slot mode: non-zero = the partition gave up, nothing to do
 };
 
 struct ScoreArgs {

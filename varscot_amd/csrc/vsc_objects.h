@@ -95,6 +95,9 @@ struct vsc_genome {
     // hits per read the last search with mismatch budget m produced (scan: all reads; seed: the fullest output
     // region) - real genomes are not the uniform model the first buffer size comes from
     double seen_rate[VSC_MAX_MISMATCHES + 1] = {};
+    // the sort's first level may skip its histogram pass (slot partition) until a search with this budget has
+    // produced a bin that outgrew its slot (repeats)
+    bool sort_slots_ok[VSC_MAX_MISMATCHES + 1] = {true, true, true, true, true, true, true, true, true};
     // seed index (vsc_seed.hip): the PAM-valid sites filed once per segment, sorted by bucket
     bool has_index = false;
     uint8_t index_has_extra_pam = 0;

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512) void bin_scan_kernel(const SortArgs a)
     block_exclusive_scan<512>(s_cnt, nbins, s_wave);
     for (uint32_t b = threadIdx.x; b < nbins; b += 512) {
         a.bin_start[base + b] = s_cnt[b];
-        a.cursor[base + b] = s_cnt[b];
+        if (!a.slot_cap) a.cursor[base + b] = s_cnt[b];  // (slot mode: hist IS the cursor array - the counts stay)
     }
 }
 
@@ -254,7 +254,12 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
     // room in the bins: consecutive lanes take consecutive bins (one coalesced returning atomic per 64 bins)
     for (uint32_t b = t; b < nbins; b += kSortThreads) {
         const uint32_t c = s_cnt[b];
-        s_gbase[b] = c ? atomicAdd(&a.cursor[((size_t)seg << a.bin_bits) + b], c) : 0u;
+        uint32_t at = c ? atomicAdd(&a.cursor[((size_t)seg << a.bin_bits) + b], c) : 0u;
+        if (a.slot_cap && c && at + c > a.slot_cap) {  // the bin outgrew its slot: this level is repeated with a histogram
+            atomicOr(a.overflow, 1u);
+            at = 0xFFFFFFFFu;
+        }
+        s_gbase[b] = at;
     }
     const uint32_t total = block_exclusive_scan<kSortThreads>(s_cnt, nbins, s_wave);  // barriers inside
 #pragma unroll
@@ -276,7 +281,11 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
         } else {
             b = (uint32_t)(x >> a.bin_shift) & (nbins - 1u);
         }
-        a.out[sg.out_off + s_gbase[b] + (i - s_cnt[b])] = x;
+        if (a.slot_cap) {
+            if (s_gbase[b] != 0xFFFFFFFFu) a.out[(((uint64_t)seg << a.bin_bits) + b) * a.slot_cap + s_gbase[b] + (i - s_cnt[b])] = x;
+        } else {
+            a.out[sg.out_off + s_gbase[b] + (i - s_cnt[b])] = x;
+        }
     }
 }
 
@@ -323,13 +332,15 @@ __device__ __forceinline__ void finalize_bin(const FinArgs &a, const uint32_t wh
     const uint32_t seg = which >> a.bin_bits, bin = which & ((1u << a.bin_bits) - 1u);
     const SortSeg sg = a.segs[seg];
     uint64_t src = sg.in_off, dst = sg.final_off;
+    uint64_t compact = sg.in_off;  // slot mode: where the bin would lie in the compact layout of the level's source buffer
     uint32_t n_src = sg.n_in;
     if (a.hist) {
         const size_t idx = ((size_t)seg << a.bin_bits) + bin;
         n_src = a.hist[idx];
         const uint32_t st = a.bin_start[idx];
-        src = sg.out_off + st;
+        src = a.slot_cap ? (uint64_t)idx * a.slot_cap : sg.out_off + st;
         dst = sg.final_off + st;
+        compact = sg.in_off + st;
     }
     if (n_src == 0) return;
     if (n_src > a.cap) {
@@ -339,7 +350,7 @@ __device__ __forceinline__ void finalize_bin(const FinArgs &a, const uint32_t wh
             if (slot < a.over_cap) {
                 SortSeg o;
                 o.in_off = src;
-                o.out_off = src;
+                o.out_off = a.slot_cap ? compact : src;  // (the next level writes into the buffer this level read)
                 o.final_off = dst;
                 o.n_in = n_src;
                 o.guide_base = sg.guide_base;
@@ -571,6 +582,7 @@ __device__ __forceinline__ void finalize_bin(const FinArgs &a, const uint32_t wh
 __global__ __launch_bounds__(kFinThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bin_finalize_kernel(const FinArgs a)
 {
     __shared__ uint32_t s_next[2];
+    if (a.overflow && *a.overflow) return;  // slot mode: the partition gave up - the level runs again, exactly
     const uint32_t total = a.n_segs << a.bin_bits;
     uint32_t which = blockIdx.x, parity = 0;
     while (which < total) {
