@@ -666,10 +666,10 @@ def test_sort_without_the_histogram_pass_and_its_fallback(ctx, oracle, hooks):
     gen = ctx.load_genome(packed)
     assert run(gen)[1] == 0
     gen.close()
-    hooks(sort_cap=64, sort_optimistic=1, sort_slot_cap=8000)            # bins between cap and slot: on to level 2 from their slots
+    hooks(sort_cap=64, sort_max_bits=2, sort_optimistic=1, sort_slot_cap=60000)  # four big bins per region: on to level 2 from their slots
     gen = ctx.load_genome(packed)
     levels, fallbacks = run(gen)
-    assert levels >= 2 and fallbacks == 0
+    assert levels >= 2 and fallbacks == 0, (levels, fallbacks)
     gen.close()
 
 
