@@ -1819,13 +1819,35 @@ uint64_t fnv(const void *p, size_t n, uint64_t h)
     return h;
 }
 
+// Where column `col` (0..441; 442 = the activity rank) sits in the row the kernel extracts tests from
+// (rf_row_words in vsc_kernels.hip; the packed layout is feature_row_packed's)
+void row_field(uint32_t col, uint8_t *word, uint8_t *shift, uint8_t *width)
+{
+    auto set = [&](uint32_t w, uint32_t s, uint32_t n) {
+        *word = (uint8_t)w;
+        *shift = (uint8_t)s;
+        *width = (uint8_t)n;
+    };
+    if (col == VSC_N_FEATURES) return set(19, 0, 8);          // activity rank
+    if (col == 0) return set(0, 21, 5);                        // totalMismatches
+    if (col <= 21) return set(0, col - 1, 1);                  // mismatchPos1..21
+    if (col <= 33) return set(1, col - 22, 1);                 // AtoC..TtoG
+    if (col == 34) return set(1, 12, 5);                       // transitions
+    if (col == 35) return set(1, 17, 5);                       // transversions
+    if (col < 120) return set(2 + ((col - 36) >> 5), (col - 36) & 31u, 1);    // A1..T20, PAMA..PAMT
+    if (col < 424) return set(5 + ((col - 120) >> 5), (col - 120) & 31u, 1);  // AA1..TT19
+    if (col < 440) return set(16 + (col - 424) / 6, 5 * ((col - 424) % 6), 5);  // AA..TT (dinucleotide counts)
+    if (col == 440) return set(0, 26, 5);                      // adjacentMismatches
+    return set(1, 22, 4);                                      // seedMismatches
+}
+
 int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
 {
     if (!model || !model->node_status || !model->feature || !model->left || !model->right || !model->split ||
         !model->node_class || model->n_trees == 0 || model->n_nodes == 0)
         return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": null or empty forest").c_str());
     const size_t nn = (size_t)model->n_trees * model->n_nodes;
-    if (model->n_nodes > (uint32_t)kRfMaxNodes || model->n_nodes > 65535u)
+    if (model->n_nodes > (uint32_t)kRfMaxNodes || (size_t)model->n_nodes * sizeof(uint32_t) > (size_t)kRfTileBytes)
         return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": a tree has more nodes than the kernel stages at once").c_str());
     if (model->n_trees > 65535u) return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": more than 65 535 trees").c_str());
     uint64_t h = 0xcbf29ce484222325ull ^ ((uint64_t)model->n_trees << 32 | model->n_nodes);
@@ -1845,56 +1867,89 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
     std::sort(thr.begin(), thr.end());
     thr.erase(std::unique(thr.begin(), thr.end()), thr.end());
     if (thr.size() > 255) return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": the forest splits the on-target activity at more than 255 values").c_str());
-    std::vector<RfNode> nodes(nn);
-    std::vector<int> slot(VSC_N_FEATURES, -1);
-    std::vector<uint16_t> columns;
+    // the distinct tests (column, integer threshold); a split below zero is never met, one at or above 255 always
+    struct Split { uint16_t col; uint8_t thr; bool never; };
+    auto split_of = [&](size_t i) {
+        Split sp{model->feature[i], 0, false};
+        const double v = model->split[i];
+        if (sp.col == VSC_N_FEATURES) sp.thr = (uint8_t)(std::lower_bound(thr.begin(), thr.end(), v) - thr.begin());
+        else if (v < 0) sp.never = true;
+        else sp.thr = (uint8_t)std::min(255.0, std::floor(v));
+        return sp;
+    };
+    std::vector<uint32_t> keys;  // col << 8 | thr of every split node that can go either way
     for (size_t i = 0; i < nn; ++i) {
-        RfNode &d = nodes[i];
-        d.left = model->left[i];
-        d.right = model->right[i];
-        d.status = model->node_status[i] == 1 ? 1 : -1;  // unused slots behind a tree's last node are never reached
-        d.node_class = model->node_class[i];
-        d.column = 0;
-        d.thr = 0;
-        if (d.status != 1) continue;
+        if (model->node_status[i] != 1) continue;
         const uint16_t ft = model->feature[i];
         // randomForest numbers the daughters of a node behind it: a daughter at or before its parent is a cycle
         const uint32_t own = (uint32_t)(i % model->n_nodes) + 1;  // 1-based index of this node in its tree
-        if (ft > VSC_N_FEATURES || d.left <= own || d.right <= own || d.left > model->n_nodes || d.right > model->n_nodes)
+        if (ft > VSC_N_FEATURES || model->left[i] <= own || model->right[i] <= own || model->left[i] > model->n_nodes ||
+            model->right[i] > model->n_nodes)
             return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": malformed forest (feature or daughter index out of range, or a daughter that does not lie behind its parent)").c_str());
-        const double sp = model->split[i];
-        if (!(sp == sp)) return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": malformed forest (NaN split)").c_str());
-        if (ft == VSC_N_FEATURES) {
-            d.column = 0xFF;  // patched to the activity slot below
-            d.thr = (uint8_t)(std::lower_bound(thr.begin(), thr.end(), sp) - thr.begin());
-        } else {
-            if (slot[ft] < 0) {
-                if (columns.size() == (size_t)kRfMaxColumns)
-                    return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": the forest tests more than 128 distinct feature columns").c_str());
-                slot[ft] = (int)columns.size();
-                columns.push_back(ft);
+        if (!(model->split[i] == model->split[i])) return fail(ctx, VSC_ERR_INVALID, (std::string(who) + ": malformed forest (NaN split)").c_str());
+        const Split sp = split_of(i);
+        if (!sp.never) keys.push_back((uint32_t)sp.col << 8 | sp.thr);
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    if (keys.empty()) keys.push_back(0);  // (a forest of stumps without a usable split still needs a test table)
+    if (keys.size() > (size_t)kRfMaxTests)
+        return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": the forest uses more than 1 024 distinct (predictor, threshold) tests").c_str());
+    // tests sorted by the row word they read (the kernel walks the words in a compile-time loop)
+    std::vector<RfTest> tests(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i) {
+        RfTest &ts = tests[i];
+        ts.dense_col = (uint16_t)(keys[i] >> 8);
+        ts.thr = (uint8_t)keys[i];
+        ts.pad = 0;
+        row_field(ts.dense_col, &ts.word, &ts.shift, &ts.width);
+    }
+    std::stable_sort(tests.begin(), tests.end(), [](const RfTest &x, const RfTest &y) { return x.word < y.word; });
+    std::vector<uint32_t> test_begin(kRfRowWords + 1, 0);
+    for (const RfTest &ts : tests) test_begin[ts.word + 1]++;
+    for (int k = 0; k < kRfRowWords; ++k) test_begin[k + 1] += test_begin[k];
+    auto test_index = [&](uint16_t col, uint8_t t) {
+        for (size_t i = 0; i < tests.size(); ++i)
+            if (tests[i].dense_col == col && tests[i].thr == t) return (uint32_t)i;
+        return 0u;
+    };
+    std::vector<uint32_t> index_of(keys.size());  // by position in `keys`
+    for (size_t i = 0; i < keys.size(); ++i) index_of[i] = test_index((uint16_t)(keys[i] >> 8), (uint8_t)keys[i]);
+    // nodes: test | left << 10 | right << 20 (0-based) | terminal << 30 | votes class "1" << 31
+    std::vector<uint32_t> nodes(nn);
+    std::vector<uint8_t> depth(model->n_trees, 0);
+    std::vector<uint16_t> level(model->n_nodes);
+    for (uint32_t tr = 0; tr < model->n_trees; ++tr) {
+        std::fill(level.begin(), level.end(), 0);
+        for (uint32_t k = 0; k < model->n_nodes; ++k) {
+            const size_t i = (size_t)tr * model->n_nodes + k;
+            if (model->node_status[i] != 1) {  // terminal (or an unused slot behind the tree's last node: never reached)
+                nodes[i] = k << 10 | k << 20 | 1u << 30 | (model->node_class[i] == 2 ? 1u << 31 : 0u);
+                continue;
             }
-            d.column = (uint8_t)slot[ft];
-            // the predictors are integers 0..255: x <= split  <=>  x <= floor(split); a negative split is never met
-            if (sp < 0) {
-                std::swap(d.left, d.right);
-                d.thr = 255;
-            } else {
-                d.thr = (uint8_t)std::min(255.0, std::floor(sp));
-            }
+            const Split sp = split_of(i);
+            uint32_t l = model->left[i] - 1u, r = model->right[i] - 1u, test = 0;
+            if (sp.never) l = r;  // x <= (negative) never holds: both ways lead right
+            else test = index_of[std::lower_bound(keys.begin(), keys.end(), (uint32_t)sp.col << 8 | sp.thr) - keys.begin()];
+            nodes[i] = test | l << 10 | r << 20;
+            level[l] = level[r] = (uint16_t)(level[k] + 1);  // (daughters lie behind their parent: level[k] is final here)
+            depth[tr] = (uint8_t)std::min<uint32_t>(255, std::max<uint32_t>(depth[tr], level[k] + 1u));
         }
     }
-    for (RfNode &d : nodes)
-        if (d.status == 1 && d.column == 0xFF) d.column = (uint8_t)columns.size();
     VSC_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t node_bytes = (nn * sizeof(RfNode) + 255) / 256 * 256;
-    VSC_HIP(ctx, f.nodes.ensure(node_bytes + std::max<size_t>(columns.size(), 1) * sizeof(uint16_t)));
-    VSC_HIP(ctx, hipMemcpyAsync(f.nodes.p, nodes.data(), nn * sizeof(RfNode), hipMemcpyHostToDevice, ctx->stream));
-    if (!columns.empty())
-        VSC_HIP(ctx, hipMemcpyAsync((char *)f.nodes.p + node_bytes, columns.data(), columns.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    auto pad = [](size_t n) { return (n + 255) / 256 * 256; };
+    const size_t nodes_b = pad(nn * sizeof(uint32_t)), depth_b = pad(depth.size()), tests_b = pad(tests.size() * sizeof(RfTest));
+    VSC_HIP(ctx, f.nodes.ensure(nodes_b + depth_b + tests_b + pad(test_begin.size() * sizeof(uint32_t))));
+    char *base = (char *)f.nodes.p;
+    VSC_HIP(ctx, hipMemcpyAsync(base, nodes.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    VSC_HIP(ctx, hipMemcpyAsync(base + nodes_b, depth.data(), depth.size(), hipMemcpyHostToDevice, ctx->stream));
+    VSC_HIP(ctx, hipMemcpyAsync(base + nodes_b + depth_b, tests.data(), tests.size() * sizeof(RfTest), hipMemcpyHostToDevice, ctx->stream));
+    VSC_HIP(ctx, hipMemcpyAsync(base + nodes_b + depth_b + tests_b, test_begin.data(), test_begin.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the host vectors go out of scope)
-    f.columns_at = node_bytes;
-    f.n_columns = (uint32_t)columns.size();
+    f.depth_at = nodes_b;
+    f.tests_at = nodes_b + depth_b;
+    f.begin_at = nodes_b + depth_b + tests_b;
+    f.n_tests = (uint32_t)tests.size();
     f.n_trees = model->n_trees;
     f.n_nodes = model->n_nodes;
     f.thresholds = thr;
@@ -1905,11 +1960,14 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
 void fill_forest(RfArgs &a, const vsc_ctx *ctx)
 {
     const vsc_ctx::Forest &f = ctx->forest;
-    a.nodes = (const RfNode *)f.nodes.p;
+    const char *base = (const char *)f.nodes.p;
+    a.nodes = (const uint32_t *)base;
+    a.depth = (const uint8_t *)(base + f.depth_at);
+    a.tests = (const RfTest *)(base + f.tests_at);
+    a.test_begin = (const uint32_t *)(base + f.begin_at);
+    a.n_tests = f.n_tests;
     a.n_trees = f.n_trees;
     a.n_nodes = f.n_nodes;
-    a.columns = (const uint16_t *)((const char *)f.nodes.p + f.columns_at);
-    a.n_columns = f.n_columns;
 }
 
 uint8_t activity_rank(const std::vector<double> &thr, double activity)

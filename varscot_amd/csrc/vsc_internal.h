@@ -216,28 +216,35 @@ struct SeedArgs {
     unsigned long long *counters;  // kCntPart + 4 p + {0,1,2}, kCntSites (= pairs compared), kCntVisited, kCntOverflow, cursors
 };
 
-// One node of a random-forest tree, 8 bytes, integer compare: every predictor of the feature matrix is a small
-// non-negative integer, so `x <= split` is `x <= floor(split)`; the on-target activity (a double, constant per read)
-// enters as its rank among the forest's distinct activity thresholds (rank = thresholds strictly below it), which
-// turns `activity <= T_j` into `rank <= j` exactly.  A node visit is one 8-byte LDS read + one byte.
-struct RfNode {
-    uint16_t left, right;  // 1-based daughters (x <= thr goes left)
-    uint8_t column;        // slot of the predictor in the workgroup's column table; slot n_columns = the activity rank
-    uint8_t thr;
-    int8_t status;         // 1 split, -1 terminal
-    uint8_t node_class;    // terminal: 1 = class "0", 2 = class "1"
+// ---- random-forest inference ---------------------------------------------------------------------------------
+// Every split of the forest is a TEST `x <= thr` on a small non-negative integer: the predictors of the feature
+// matrix are flags and counts (`x <= split` is `x <= floor(split)`), and the on-target activity (a double, constant
+// per read) enters as its rank among the forest's distinct activity thresholds (rank = thresholds strictly below it),
+// which turns `activity <= T_j` into `rank <= j` exactly.  The forest has few DISTINCT tests (rfClassifier: 217 for
+// 105 235 split nodes), so a row is reduced to one bit per test first (7 words), and a node is 4 bytes:
+//   bits 0..9 test | 10..19 left daughter | 20..29 right daughter (0-based; a terminal node points at itself) |
+//   30 terminal | 31 votes class "1"
+// A node visit is one 4-byte LDS read of the node + one of the row's test word.
+constexpr int kRfRows = 256;             // feature rows per workgroup (one thread each)
+constexpr int kRfMaxTests = 1024;        // distinct (predictor, threshold) pairs a forest may use
+constexpr int kRfMaxNodes = 1024;        // nodes of one tree (rfClassifier: 275)
+constexpr int kRfTileBytes = 12800;      // whole trees staged in LDS per step (with 7 KB of test bits: 8 workgroups per CU)
+constexpr int kRfRowWords = 20;          // a row as the test extraction sees it: 16 packed words, 3 words of dinucleotide
+                                         // counts (5 bits each, 6 / 6 / 4), 1 word activity rank
+// a test: field `width` bits at `shift` of row word `word` <= thr; dense rows read column `dense_col` instead
+struct RfTest {
+    uint8_t word, shift, width, thr;
+    uint16_t dense_col;  // 0..441, or 442 = the activity rank
+    uint16_t pad;
 };
-static_assert(sizeof(RfNode) == 8, "RfNode layout");
-constexpr int kRfRows = 512;          // feature rows per workgroup (one thread each)
-constexpr int kRfMaxColumns = 128;    // distinct feature columns a forest may test (rfClassifier: 79 + the activity)
-constexpr int kRfTileBytes = 32 * 1024;  // whole trees staged in LDS per step
-constexpr int kRfMaxNodes = kRfTileBytes / (int)sizeof(RfNode);  // nodes of one tree (rfClassifier: 275)
 
 struct RfArgs {
-    const RfNode *nodes;        // [n_trees * n_nodes], tree-major
+    const uint32_t *nodes;      // [n_trees * n_nodes], tree-major
+    const uint8_t *depth;       // [n_trees] steps from the root to the deepest terminal node
     uint32_t n_trees, n_nodes;
-    const uint16_t *columns;    // [n_columns] dense feature columns (0..441) the forest tests
-    uint32_t n_columns;
+    const RfTest *tests;        // [n_tests], sorted by the row word they read
+    const uint32_t *test_begin; // [kRfRowWords + 1] first test of every row word
+    uint32_t n_tests;
     // the rows: dense (n x 442 bytes), packed (n x 64 bytes), or - both null - computed in the kernel from `score`'s
     // hits (the fused score -> classify path: the feature rows never exist in memory)
     const uint8_t *dense;

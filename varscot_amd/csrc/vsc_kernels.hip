@@ -863,50 +863,53 @@ hipError_t launch_score(const ScoreArgs &args, hipStream_t stream)
 // staged with coalesced loads, every thread walks them from LDS (a node visit = one 16-byte LDS read + one byte).
 // Few rows: gridDim.y splits the trees over several workgroups per row tile, votes meet in an atomic add.
 // ------------------------------------------------------------------------------------------------
-// column `col` (0..441) of the dense feature row that a packed row stands for (layout: feature_row_packed)
-__device__ __forceinline__ uint32_t packed_column(const uint32_t (&w)[16], uint32_t col)
+// The row the test extraction reads (kRfRowWords words): the 16 packed words + the 16 dinucleotide counts (column
+// sums of the dinucleotide flags, 5 bits each: words 16, 17 hold six counts, word 18 four) + the activity rank.
+__device__ __forceinline__ void rf_row_words(const uint32_t (&w)[16], uint32_t rank, uint32_t (&r)[kRfRowWords])
 {
-    if (col == 0) return (w[0] >> 21) & 31u;                 // totalMismatches
-    if (col <= 21) return (w[0] >> (col - 1)) & 1u;          // mismatchPos1..21
-    if (col <= 33) return (w[1] >> (col - 22)) & 1u;         // AtoC..TtoG
-    if (col == 34) return (w[1] >> 12) & 31u;                // transitions
-    if (col == 35) return (w[1] >> 17) & 31u;                // transversions
-    if (col < 120) {                                         // A1..T20, PAMA..PAMT
-        const uint32_t bit = col - 36;
-        return (w[2 + (bit >> 5)] >> (bit & 31u)) & 1u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = w[k];
+    uint32_t cnt[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) cnt[p] = 0;
+#pragma unroll
+    for (int i = 0; i < 19; ++i) {  // the 16 flags of position i are bits 16 i .. 16 i + 15 of words 5..14
+        const uint32_t half = (w[5 + (i >> 1)] >> ((i & 1) * 16)) & 0xFFFFu;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) cnt[p] += (half >> p) & 1u;
     }
-    if (col < 424) {                                         // AA1..TT19
-        const uint32_t bit = col - 120;
-        return (w[5 + (bit >> 5)] >> (bit & 31u)) & 1u;
-    }
-    if (col < 440) {                                         // AA..TT: column sums of the dinucleotide flags
-        const uint32_t pair = col - 424;
-        uint32_t sum = 0;
-        for (uint32_t i = 0; i < 19; ++i) {
-            const uint32_t bit = 16u * i + pair;
-            sum += (w[5 + (bit >> 5)] >> (bit & 31u)) & 1u;
-        }
-        return sum;
-    }
-    return col == 440 ? (w[0] >> 26) & 31u : (w[1] >> 22) & 15u;  // adjacentMismatches, seedMismatches
+    r[16] = r[17] = r[18] = 0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) r[16 + p / 6] |= cnt[p] << (5 * (p % 6));
+    r[19] = rank;
 }
 
 // kMode 0: dense rows, 1: packed rows, 2: rows computed here from the hits of a.score (score -> classify fused)
 template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kernel(const RfArgs a)
 {
-    extern __shared__ uint4 s_dyn[];
-    // s_x[slot][thread], column-major: the threads of a wave read neighbouring bytes; slot n_columns = activity rank
-    uint8_t *const s_x = (uint8_t *)s_dyn;
-    RfNode *const s_nodes = (RfNode *)((uint8_t *)s_dyn + (((size_t)(a.n_columns + 1) * kRfRows + 15) & ~(size_t)15));
+    extern __shared__ uint32_t s_dyn[];
+    // s_bits[word][thread]: the row's test results, one bit per test; then the tree tile
+    const uint32_t n_words = (a.n_tests + 31u) / 32u;
+    uint32_t *const s_bits = s_dyn;
+    uint32_t *const s_tile = s_dyn + (size_t)n_words * kRfRows;
     const uint32_t t = threadIdx.x;
     const uint64_t row = (uint64_t)blockIdx.x * kRfRows + t;
     const bool live = row < a.n;
-    uint32_t rank = 0;
     if (kMode == 0) {
-        for (uint32_t c = 0; c < a.n_columns; ++c) s_x[c * kRfRows + t] = live ? a.dense[row * VSC_N_FEATURES + a.columns[c]] : 0;
-        if (live) rank = a.act_rank[row];
+        // dense rows (the command-line tool's path): one byte load per test
+        const uint32_t rank = live ? a.act_rank[row] : 0u;
+        for (uint32_t wd = 0; wd < n_words; ++wd) {
+            uint32_t bits = 0;
+            for (uint32_t i = wd * 32u; i < min(a.n_tests, wd * 32u + 32u); ++i) {
+                const RfTest ts = a.tests[i];
+                const uint32_t x = !live ? 0u : (ts.dense_col == VSC_N_FEATURES ? rank : a.dense[row * VSC_N_FEATURES + ts.dense_col]);
+                bits |= (x <= ts.thr ? 1u : 0u) << (i & 31u);
+            }
+            s_bits[wd * kRfRows + t] = bits;
+        }
     } else {
         uint32_t w[16] = {};
+        uint32_t rank = 0;
         if (live) {
             if (kMode == 1) {
 #pragma unroll
@@ -930,36 +933,55 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
                 }
             }
         }
-        for (uint32_t c = 0; c < a.n_columns; ++c) s_x[c * kRfRows + t] = (uint8_t)packed_column(w, a.columns[c]);
+        uint32_t r[kRfRowWords];
+        rf_row_words(w, rank, r);
+        // the tests are sorted by the row word they read: a compile-time loop over the words (registers), a wave-uniform
+        // loop over each word's tests (scalar loads), the bits collected in test order
+        uint32_t bits = 0, i = 0;
+#pragma unroll
+        for (int k = 0; k < kRfRowWords; ++k) {
+            const uint32_t rk = r[k];
+            const uint32_t end = a.test_begin[k + 1];
+            for (; i < end; ++i) {
+                const RfTest ts = a.tests[i];
+                const uint32_t x = (rk >> ts.shift) & ((1u << ts.width) - 1u);
+                bits |= (x <= ts.thr ? 1u : 0u) << (i & 31u);
+                if ((i & 31u) == 31u) {
+                    s_bits[(i >> 5) * kRfRows + t] = bits;
+                    bits = 0;
+                }
+            }
+        }
+        if (a.n_tests & 31u) s_bits[(a.n_tests >> 5) * kRfRows + t] = bits;
     }
-    s_x[a.n_columns * kRfRows + t] = (uint8_t)rank;
     // this workgroup's share of the trees
     const uint32_t per_split = (a.n_trees + a.tree_splits - 1) / a.tree_splits;
     const uint32_t tree_begin = blockIdx.y * per_split, tree_end = min(tree_begin + per_split, a.n_trees);
-    const uint32_t tile_trees = max(1u, (uint32_t)kRfMaxNodes / a.n_nodes);
-    const uint8_t *const xt = s_x + t;
+    const uint32_t tile_trees = max(1u, (uint32_t)(kRfTileBytes / sizeof(uint32_t)) / a.n_nodes);
+    const uint32_t *const bt = s_bits + t;
     uint32_t ones = 0;
     for (uint32_t t0 = tree_begin; t0 < tree_end; t0 += tile_trees) {
         const uint32_t nt = min(tile_trees, tree_end - t0);
-        block_sync();  // the previous tile is done with (first round: the feature columns are in place)
-        const uint2 *src = (const uint2 *)(a.nodes + (size_t)t0 * a.n_nodes);
-        for (uint32_t i = t; i < nt * a.n_nodes; i += kRfRows) ((uint2 *)s_nodes)[i] = src[i];
+        block_sync();  // the previous tile (first round: the rows' words) is done with
+        const uint32_t *src = a.nodes + (size_t)t0 * a.n_nodes;
+        for (uint32_t i = t; i < nt * a.n_nodes; i += kRfRows) s_tile[i] = src[i];
         block_sync();
-        // two trees in flight per thread: a walk is a chain of dependent LDS reads, two chains overlap their latencies
+        // Two trees in flight per thread: a walk is a chain of dependent LDS reads, two chains overlap their latencies.
+        // Terminal nodes point at themselves, so every lane simply takes as many steps as the deeper of the two trees
+        // is deep (wave-uniform trip count: no per-lane exit test).
         for (uint32_t k = 0; k < nt; k += 2) {
-            const RfNode *const tree0 = s_nodes + (size_t)k * a.n_nodes;
-            const RfNode *const tree1 = s_nodes + (size_t)min(k + 1, nt - 1) * a.n_nodes;
-            RfNode n0 = tree0[0], n1 = tree1[0];
-            // (daughters lie behind their parent - the host checks - so a walk ends within n_nodes steps; the
-            // bound only keeps a forest that slipped past the check from hanging the device)
-            for (uint32_t step = 0; step < a.n_nodes; ++step) {
-                const bool go0 = n0.status == 1, go1 = n1.status == 1;
-                if (!(go0 | go1)) break;
-                if (go0) n0 = tree0[(xt[(uint32_t)n0.column * kRfRows] <= n0.thr ? n0.left : n0.right) - 1u];
-                if (go1) n1 = tree1[(xt[(uint32_t)n1.column * kRfRows] <= n1.thr ? n1.left : n1.right) - 1u];
+            const uint32_t k1 = min(k + 1, nt - 1);
+            const uint32_t *const tree0 = s_tile + (size_t)k * a.n_nodes, *const tree1 = s_tile + (size_t)k1 * a.n_nodes;
+            const uint32_t steps = max((uint32_t)a.depth[t0 + k], (uint32_t)a.depth[t0 + k1]);
+            uint32_t n0 = tree0[0], n1 = tree1[0];
+            for (uint32_t step = 0; step < steps; ++step) {
+                const uint32_t b0 = (bt[((n0 & 1023u) >> 5) * kRfRows] >> (n0 & 31u)) & 1u;
+                const uint32_t b1 = (bt[((n1 & 1023u) >> 5) * kRfRows] >> (n1 & 31u)) & 1u;
+                n0 = tree0[(n0 >> (b0 ? 10u : 20u)) & 1023u];
+                n1 = tree1[(n1 >> (b1 ? 10u : 20u)) & 1023u];
             }
-            ones += n0.node_class == 2;
-            if (k + 1 < nt) ones += n1.node_class == 2;
+            ones += n0 >> 31;
+            if (k + 1 < nt) ones += n1 >> 31;
         }
     }
     if (!live) return;
@@ -974,10 +996,13 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
 hipError_t launch_rf_predict(const RfArgs &args, hipStream_t stream)
 {
     if (args.n == 0) return hipSuccess;
-    if (args.n_columns > (uint32_t)kRfMaxColumns || args.n_nodes > (uint32_t)kRfMaxNodes || args.n_nodes == 0) return hipErrorInvalidValue;
+    if (args.n_tests > (uint32_t)kRfMaxTests || args.n_tests == 0 || args.n_nodes > (uint32_t)kRfMaxNodes || args.n_nodes == 0 ||
+        (size_t)args.n_nodes * sizeof(uint32_t) > (size_t)kRfTileBytes)
+        return hipErrorInvalidValue;
     const uint64_t tiles = (args.n + kRfRows - 1) / kRfRows;
     if (tiles >= (1ull << 31)) return hipErrorInvalidValue;
-    const size_t lds = ((((size_t)(args.n_columns + 1) * kRfRows + 15) & ~(size_t)15)) + (size_t)kRfTileBytes;
+    const size_t n_words = (args.n_tests + 31) / 32;
+    const size_t lds = n_words * kRfRows * sizeof(uint32_t) + (size_t)kRfTileBytes;  // test bits + the tree tile
     const int mode = args.dense ? 0 : (args.packed ? 1 : 2);
     if (mode == 2 && args.tree_splits != 1) return hipErrorInvalidValue;
     auto go = [&](auto kernel) {

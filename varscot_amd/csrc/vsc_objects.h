@@ -72,9 +72,9 @@ struct vsc_ctx {
     vsc::DeviceBuf seed_off, seed_poff, seed_lrest;  // per-search read lists: bucket counts, padded list starts, entries
     // the forest of the last classification call, as the kernels read it (prepare_forest in vsc_api.cpp)
     struct Forest {
-        vsc::DeviceBuf nodes, ranks;   // nodes + column table; activity ranks of the reads of a fused call
-        size_t columns_at = 0;
-        uint32_t n_columns = 0, n_trees = 0, n_nodes = 0;
+        vsc::DeviceBuf nodes, ranks;   // nodes + tree depths + test table; activity ranks of the reads of a fused call
+        size_t depth_at = 0, tests_at = 0, begin_at = 0;
+        uint32_t n_tests = 0, n_trees = 0, n_nodes = 0;
         std::vector<double> thresholds;  // distinct activity splits, ascending
         uint64_t fingerprint = 0;
     } forest;
