@@ -398,15 +398,31 @@ __global__ __launch_bounds__(256) void merge_packed_kernel(const uint64_t *in, c
     const uint32_t key = first_key + seg / n_shards;
     const uint64_t src = seg_src[seg], dst = seg_dst[seg];
     uint4 *o = (uint4 *)out;
+    // A segment's records ascend in position, and so do the records a thread takes (every blockDim-th): the contig of
+    // a record is found by one binary search for the thread's first record and a forward walk from there on (a few
+    // contigs per segment: the walk almost never moves).
+    uint32_t c = 0, c_start = 0, c_next = 0;
+    bool placed = false;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         const uint64_t x = in[src + i];
         const uint32_t gpos = (uint32_t)(x >> kRecPosShift), mask = (uint32_t)x & kMask23;
-        uint32_t lo = 0, hi = n_contigs;  // last contig that starts at or before gpos
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (contig_off[mid] <= gpos) lo = mid; else hi = mid;
+        if (!placed) {
+            uint32_t lo = 0, hi = n_contigs;  // last contig that starts at or before gpos
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (contig_off[mid] <= gpos) lo = mid; else hi = mid;
+            }
+            c = lo;
+            placed = true;
+            c_start = contig_off[c];
+            c_next = c + 1 < n_contigs ? contig_off[c + 1] : 0xFFFFFFFFu;
         }
-        o[dst + i] = make_uint4(key >> 1, lo, gpos - contig_off[lo], ((key & 1u) << 31) | ((uint32_t)__popc(mask) << 23) | mask);
+        while (gpos >= c_next) {  // (c_next = 2^32 - 1 behind the last contig: positions stay below it)
+            ++c;
+            c_start = c_next;
+            c_next = c + 1 < n_contigs ? contig_off[c + 1] : 0xFFFFFFFFu;
+        }
+        o[dst + i] = make_uint4(key >> 1, c, gpos - c_start, ((key & 1u) << 31) | ((uint32_t)__popc(mask) << 23) | mask);
     }
 }
 
