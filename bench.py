@@ -469,8 +469,8 @@ def main():
             k_seg = max_mm // 3
             list_entries = n_guides * 3 * (1, 22, 211)[k_seg]
             # what THIS kernel has to move: bit-sliced sites of the visited buckets (4 B each, read once) + the
-            # per-bucket read lists (16 B per entry) + per hit one 16 B site record read and 8 B written
-            structure_bytes = float(stream_bytes) + 16.0 * list_entries + 24.0 * hits_local
+            # per-bucket read lists (16 B per entry) + per hit one 8 B site record read and 8 B written
+            structure_bytes = float(stream_bytes) + 16.0 * list_entries + 16.0 * hits_local
         achieved = survey_bytes / (scan_avg_ms * 1e-3) / 1e9
         compares = float(pairs_local)
         lane_ops = compares * ops_per_compare / (scan_avg_ms * 1e-3)

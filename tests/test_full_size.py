@@ -154,7 +154,7 @@ def test_c5_all_100000_reads_streamed(big):
     """BASELINE.json configs[4] at its stated size on one GPU: all 100 000 reads streamed in 10 batches of 10 000 at
     <= 8 mismatches (1.6e10 records in total), every batch scored from the callback (packed feature rows, dropped).
     Per batch: strictly ascending records, NM <= 8, reads inside the batch's range, NM = popcount(mask) on a
-    sample; the batch counts add up to the library's hit total; batch 0 (= the c3 read set) has the c3 digest; ONE
+    sample; the batch counts add up to the library's hit total; ONE
     batch (reads 30 000 .. 39 999) is compared record for record with the streaming scan of the same reads - the
     other search algorithm over the other data structure; and on a slice of that batch the fused
     score -> classify path equals packed scoring followed by the forest."""
