@@ -24,7 +24,11 @@ Outputs (data only - inputs and expected outputs, no reference source text):
                                   :378-394 samples the records): (guide, site, NM) triples the
                                   reference's mapper emitted at <= 8 mismatches - the one reference-held
                                   output of the search.  Class-1 rows are GUIDE-seq sites (NM from the
-                                  GUIDE-seq tables), not mapper output.
+                                  GUIDE-seq tables), not mapper output - but see mapper_row.
+      mapper_row[6960] int64     Class-1 rows: the row of VARSCOT's SAM output that holds this GUIDE-seq site
+                                  (workflow/data-objects/indexGuideSeq.RData, built by processDataForModel.R:262-279:
+                                  match on Targetsite, Chr, Start; -1 = not reported).  All 348 are >= 1: the
+                                  reference's mapper reported every one of these sites.  Class-0 rows: 0.
   siteseq_pairs.tsv
       4443 (on, off, NM, strand) pairs incl. non-GG PAMs, NM up to 14
       (workflow/data-objects/offtargetBiochemicalData.RData) - inputs only.
@@ -53,9 +57,10 @@ REF = "/root/reference/workflow"
 
 def main():
     ds = load_rdata(f"{REF}/data-objects/datasetsSampling.RData")["datasetsSampling"]
+    found = [int(v) for v in load_rdata(f"{REF}/data-objects/indexGuideSeq.RData")["indexGuideSeq"]["val"]]
     fm = load_rdata(f"{REF}/data-objects/featureMatrix.RData")["featureMatrix"]
     on, off, feat, act = [], [], [], []
-    nm, cls, chrom, start, target = [], [], [], [], []
+    nm, cls, chrom, start, target, mapper_row = [], [], [], [], [], []
     names = None
     for d, f in zip(ds["val"], fm["val"]):
         d = data_frame(d)
@@ -73,6 +78,9 @@ def main():
         chrom += d["Chr"]
         start += [int(v) for v in d["Start"]]
         target += d["Targetsite"]
+        n1 = sum(1 for v in d["Class"] if int(v) == 1)
+        assert n1 == len(found) and all(int(v) == 1 for v in d["Class"][:n1])  # the GUIDE-seq rows come first, in `data` order
+        mapper_row += found + [0] * (n - n1)
         m = np.zeros((n, 442), dtype=np.uint8)
         for j, c in enumerate(names):
             m[:, j] = np.asarray([int(float(v)) for v in f[c]], dtype=np.uint8)
@@ -83,7 +91,7 @@ def main():
     np.savez_compressed(f"{HERE}/features_golden.npz", on=np.array(on), off=np.array(off), feat=feat,
                         names=np.array(names), activity=np.array(act), nm=np.array(nm, dtype=np.uint8),
                         cls=np.array(cls, dtype=np.uint8), chrom=np.array(chrom), start=np.array(start, dtype=np.int64),
-                        target=np.array(target))
+                        target=np.array(target), mapper_row=np.array(mapper_row, dtype=np.int64))
     print("features_golden.npz", feat.shape)
 
     bd = data_frame(load_rdata(f"{REF}/data-objects/offtargetBiochemicalData.RData")["offtargetBiochemicalData"])

@@ -134,13 +134,17 @@ def repeat_rich_genome(seed, n_bases, guides, n_contigs=3):
 
 
 def reference_sam_triples(golden_dir):
-    """The (guide, site, NM) triples of VARSCOT's own SAM output that the reference still holds: the Class-0 rows
-    of workflow/data-objects/datasetsSampling.RData (workflow/processDataForModel.R:257-258 reads
-    guideseq-data/bidir_guideseq.sam, :284 extracts the `NM:i` tag, :378-394 samples the records; the SAM itself
-    is an absent LFS blob).  Returns (guides, rows) with rows = unique (guide index, site in guide orientation, NM)."""
+    """The (guide, site, NM) triples of VARSCOT's own SAM output that the reference still holds:
+    * the Class-0 rows of workflow/data-objects/datasetsSampling.RData (workflow/processDataForModel.R:257-258 reads
+      guideseq-data/bidir_guideseq.sam, :284 extracts the `NM:i` tag, :378-394 samples the records; the SAM itself is
+      an absent LFS blob): NM is the reference mapper's own tag;
+    * the 348 GUIDE-seq sites (Class 1), every one of which the reference found in that SAM output
+      (data-objects/indexGuideSeq.RData, processDataForModel.R:262-279: all row numbers >= 1) - reported sites whose NM
+      is the script's stringDiff over all 23 positions (:238-240).
+    Returns (guides, rows) with rows = unique (guide index, site in guide orientation, NM)."""
     import os
     g = np.load(os.path.join(golden_dir, "features_golden.npz"))
-    sel = g["cls"] == 0
+    sel = (g["cls"] == 0) | (g["mapper_row"] >= 1)
     guides = sorted(set(str(s) for s in g["on"][sel]))
     gidx = {s: i for i, s in enumerate(guides)}
     rows = sorted(set((gidx[str(a)], str(o), int(n)) for a, o, n in zip(g["on"][sel], g["off"][sel], g["nm"][sel])))

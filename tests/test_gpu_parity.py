@@ -264,7 +264,7 @@ def test_search_reports_the_reference_mappers_hits_with_its_nm(ctx, golden_dir, 
     `NM:i` value (= popcount of the record's mask), exactly from the budget m = NM on, by both search kernels."""
     from helpers import plant_reference_sites, reference_sam_triples
     guides, rows = reference_sam_triples(golden_dir)
-    assert len(rows) == 2434
+    assert len(rows) == 2779
     contigs, strands = plant_reference_sites(rows)
     gen = ctx.load_genome(va.PackedGenome.from_sequences(contigs))
     for m in (8, 6, 5, 3, 2):

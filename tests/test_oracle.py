@@ -243,14 +243,15 @@ def test_sam_text(oracle):
 # ---------------------------------------------------------------- the reference mapper's own NM tags (rows R2/R3)
 @pytest.mark.parametrize("mode", ["predicate", "reference_flow", "fastport", "pigeon"])
 def test_search_reports_the_reference_mappers_hits_with_its_nm(oracle, golden_dir, mode):
-    """Pins rows R2/R3 with the one search output the reference still holds: 2 434 distinct (guide, site sequence, NM)
-    triples out of VARSCOT's own SAM file (datasetsSampling.RData, Class 0 - helpers.reference_sam_triples).
+    """Pins rows R2/R3 with the one search output the reference still holds: 2 779 distinct (guide, site sequence, NM)
+    triples out of VARSCOT's own SAM file (datasetsSampling.RData Class 0: the mapper's NM tags; the 348 GUIDE-seq
+    sites the reference found in that file, indexGuideSeq.RData - helpers.reference_sam_triples).
     Every site the reference's mapper reported at <= 8 mismatches must be reported by every formulation of the
     oracle, on the strand it is planted on, with the reference's NM (mismatches over all 23 positions,
     bidir_mapping.cpp:79-86,121), and must appear exactly when the budget reaches that NM (acceptance `<= m`)."""
     from helpers import plant_reference_sites, reference_sam_triples
     guides, rows = reference_sam_triples(golden_dir)
-    assert len(rows) == 2434 and len(guides) == 9
+    assert len(rows) == 2779 and len(guides) == 9
     contigs, strands = plant_reference_sites(rows)
     pig = oracle.PigeonIndex(contigs) if mode == "pigeon" else None
     for m in (8, 7, 6, 5, 4, 3, 2, 1):
