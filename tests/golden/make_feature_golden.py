@@ -38,6 +38,11 @@ Outputs (data only - inputs and expected outputs, no reference source text):
       formula coincides with variant_processing/mit_score.h:12-68 (fewer than two
       mismatches in the 20-mer, or sum of consecutive distances divisible by their count;
       CRISPOR floors the mean, VARSCOT does not - SURVEY.md section 4).
+  guideseq_sam_rows.tsv
+      the 348 GUIDE-seq sites of datasetsSampling (Class 1) with the strand the GUIDE-seq table gives them
+      (workflow/guideseq-data/datasetGUIDESeq.xlsx, column Strand; joined on Targetsite, chromosome, Start) and the
+      row of VARSCOT's SAM output the reference found them in (mapper_row above): target, chrom, start (0-based),
+      strand, nm, sam_row.  Row numbers of known records = what is left of the ORDER of the reference's output.
   guides_ontargets.tsv
       the 9 GUIDE-seq + 7 SITE-seq on-target 23-mers with their activity values
       (workflow/guideseq-data/guideseqOntargets.fasta, guideseqOntargetActivity.txt,
@@ -93,6 +98,32 @@ def main():
                         cls=np.array(cls, dtype=np.uint8), chrom=np.array(chrom), start=np.array(start, dtype=np.int64),
                         target=np.array(target), mapper_row=np.array(mapper_row, dtype=np.int64))
     print("features_golden.npz", feat.shape)
+
+    # strands of the GUIDE-seq sites: the xlsx is a zip of XML sheets (shared strings + one sheet)
+    import re
+    import zipfile
+    import xml.etree.ElementTree as ET
+    ns = {"m": "http://schemas.openxmlformats.org/spreadsheetml/2006/main"}
+    with zipfile.ZipFile(f"{REF}/guideseq-data/datasetGUIDESeq.xlsx") as z:
+        shared = ["".join(t.itertext()) for t in ET.fromstring(z.read("xl/sharedStrings.xml")).findall("m:si", ns)]
+        sheet = ET.fromstring(z.read("xl/worksheets/sheet1.xml"))
+    table = []
+    for r in sheet.find("m:sheetData", ns).findall("m:row", ns):
+        cells = {}
+        for c in r.findall("m:c", ns):
+            v = c.find("m:v", ns)
+            if v is not None:
+                cells[re.match(r"[A-Z]+", c.get("r")).group(0)] = shared[int(v.text)] if c.get("t") == "s" else v.text
+        table.append(cells)
+    assert table[0]["A"] == "#Chromosome" and table[0]["F"] == "Strand" and table[0]["H"] == "Targetsite"
+    strand_of = {(c["H"], c["A"], int(c["B"])): c["F"] for c in table[1:]}
+    n1 = len(found)
+    with open(f"{HERE}/guideseq_sam_rows.tsv", "w") as out:
+        out.write("#target\tchrom\tstart\tstrand\tnm\tsam_row\n")
+        for i in range(n1):  # the Class-1 rows are the same in all ten datasets: the first one's
+            key = (str(target[i]), str(chrom[i]), int(start[i]) - 1)  # (the R script works with 1-based starts)
+            out.write("%s\t%s\t%d\t%s\t%d\t%d\n" % (key[0], key[1], key[2], strand_of[key], nm[i], mapper_row[i]))
+    print("guideseq_sam_rows.tsv", n1)
 
     bd = data_frame(load_rdata(f"{REF}/data-objects/offtargetBiochemicalData.RData")["offtargetBiochemicalData"])
     with open(f"{HERE}/siteseq_pairs.tsv", "w") as out:

@@ -195,3 +195,76 @@ def xmerge(records, key_counts, first_key, contig_offsets):
             out["info"][at:at + n] = ((key & 1) << 31) | (nm << 23) | mask
             at += n
     return out
+
+
+# ---- what is left of the ORDER of the reference's SAM output (row R4) -------------------------------------------------
+# tests/golden/guideseq_sam_rows.tsv: the 348 GUIDE-seq sites with their strand and the row of VARSCOT's own SAM file the
+# reference found them in.  bidir_mapping.cpp:167-187 writes, per read, a '+' block then a '-' block, each in ascending
+# (contig, position) order of its std::map - except that the record with the fewest mismatches so far is held back and
+# written when a better one displaces it, or at the end of its block.  Contig ids are FASTA order; the reference mapped
+# against UCSC's hg19.fa, whose order is by size:
+UCSC_HG19_ORDER = ["chr" + c for c in "1 2 3 4 5 6 7 X 8 9 10 11 12 13 14 15 16 17 18 20 Y 19 22 21".split()]
+
+
+def guideseq_sam_rows(golden_dir):
+    """[(target, chrom, start, strand, nm, sam_row)] in fixture order (= the Class-1 rows of features_golden.npz)."""
+    import os
+    out = []
+    for line in open(os.path.join(golden_dir, "guideseq_sam_rows.tsv")):
+        if not line.startswith("#"):
+            t, c, s, st, nm, r = line.rstrip("\n").split("\t")
+            out.append((t, c, int(s), st, int(nm), int(r)))
+    return out
+
+
+def late_records(block):
+    """block: [(sort key, nm, id)] in OUTPUT order of one (read, strand) block.  Returns the ids of the records that come
+    later than their place in ascending key order (smaller key than a record written before them): under
+    bidir_mapping.cpp:170-187 exactly the records that were held back as the best so far."""
+    late, run_max = [], None
+    for key, nm, ident in block:
+        if run_max is not None and key < run_max:
+            late.append(ident)
+        else:
+            run_max = key
+    return late
+
+
+def check_block_order(block):
+    """The signature of bidir_mapping.cpp:167-187 on one block in output order: ascending keys except for late records,
+    and every late record has strictly fewer mismatches than every record that sorts before it (it was the best so far
+    when the map iteration reached it)."""
+    late = set(late_records(block))
+    for key, nm, ident in block:
+        if ident in late:
+            assert all(n2 > nm for k2, n2, _ in block if k2 < key), (key, nm)
+    rest = [key for key, _, ident in block if ident not in late]
+    assert rest == sorted(rest)
+    return late
+
+
+def guideseq_mini_genome(golden_dir):
+    """A small genome with the reference's contig names in UCSC hg19 order that carries the 348 GUIDE-seq sites on their
+    chromosome, in their real relative order along it, on their real strand.  Returns (guide names, guides, contig names,
+    contigs, planted) with planted[i] = (guide index, contig index, position, strand 0/1, nm, sam_row) in fixture order."""
+    import os
+    rows = guideseq_sam_rows(golden_dir)
+    g = np.load(os.path.join(golden_dir, "features_golden.npz"))
+    names, guides, _ = real_guides(golden_dir)
+    names, guides = names[:9], guides[:9]  # the GUIDE-seq targets, in the order of guideseqOntargets.fasta
+    sites = [str(s) for s in g["off"][:len(rows)]]
+    assert [str(t) for t in g["target"][:len(rows)]] == [r[0] for r in rows]
+    per_contig = {c: [] for c in UCSC_HG19_ORDER}
+    for i, (t, c, start, strand, nm, row) in enumerate(rows):
+        per_contig[c].append((start, i))
+    contigs, planted = [], [None] * len(rows)
+    for ci, c in enumerate(UCSC_HG19_ORDER):
+        seq = ["TTTTTTTT"]
+        for start, i in sorted(per_contig[c]):
+            t, _, _, strand, nm, row = rows[i]
+            pos = sum(len(x) for x in seq)
+            site = sites[i] if strand == "+" else revcomp(sites[i])
+            seq.append(site + ("TTTTTTTTTT" if strand == "+" else "AAAAAAAAAA"))
+            planted[i] = (names.index(t), ci, pos, 0 if strand == "+" else 1, nm, row)
+        contigs.append("".join(seq))
+    return names, guides, list(UCSC_HG19_ORDER), contigs, planted

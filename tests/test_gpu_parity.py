@@ -289,6 +289,38 @@ def test_search_reports_the_reference_mappers_hits_with_its_nm(ctx, golden_dir, 
     gen.close()
 
 
+def test_sam_write_order_equals_the_reference_rows_on_the_guideseq_sites(ctx, oracle, golden_dir):
+    """Row R4 against what is left of the ORDER of the reference's own SAM output (tests/golden/guideseq_sam_rows.tsv:
+    the rows in which the reference found its 348 GUIDE-seq sites): the GPU result of a genome that carries those
+    sites on the reference's contigs (UCSC hg19 order), in their real order along each chromosome and on their
+    real strand, put into write order by vsc_sam_order - apart from the records either side holds back as
+    best-so-far, the sites come out in exactly the order of the reference's SAM rows; and the whole write order
+    (with secondary flags) equals the oracle's REFERENCE_FLOW."""
+    from helpers import guideseq_mini_genome, late_records
+    names, guides, cnames, contigs, planted = guideseq_mini_genome(golden_dir)
+    gen = ctx.load_genome(va.PackedGenome.from_sequences(contigs))
+    hits = gen.search(guides, 8)
+    rec = hits.to_numpy()
+    hits.close()
+    gen.close()
+    order, sec = va.sam_order(rec)
+    written = rec[order.astype(np.int64)]
+    flow = oracle.search(contigs, guides, 8, mode=oracle.MODE_REFERENCE_FLOW)
+    for f in ("guide", "contig", "pos"):
+        assert np.array_equal(written[f], flow[f])
+    assert np.array_equal(written["info"] | (sec.astype(np.uint32) << 30), flow["info"])
+    where = {(g, c, p, s): i for i, (g, s, c, p, nm, _) in enumerate(hits_as_tuples(written))}
+    ours = [i for _, i in sorted((where[(g, c, p, s)], i) for i, (g, c, p, s, nm, row) in enumerate(planted))]
+    theirs = [i for _, i in sorted((planted[i][5], i) for i in range(len(planted)))]
+    held = set()
+    for seq in (ours, theirs):
+        for g in range(len(guides)):
+            for s in (0, 1):
+                held |= set(late_records([((planted[i][1], planted[i][2]), planted[i][4], i) for i in seq
+                                          if planted[i][0] == g and planted[i][3] == s]))
+    assert [i for i in ours if i not in held] == [i for i in theirs if i not in held] and len(ours) - len(held) > 300
+
+
 # ------------------------------------------------------------------------------------ multi-rank
 def _rank_worker(rank, world, port, q, exchange="root"):
     import traceback

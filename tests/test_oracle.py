@@ -282,3 +282,64 @@ def test_reference_sam_triples_are_what_the_generator_says(golden_dir):
     sel = g["cls"] == 0
     assert sel.sum() == 3480 and all(str(o)[21:] == "GG" for o in g["off"][sel])
     assert g["nm"][sel].min() == 2 and g["nm"][sel].max() == 8
+
+
+# ---- what is left of the ORDER of the reference's SAM output (row R4) ---------------------------------------------------
+def test_reference_sam_rows_have_the_write_order_of_bidir_mapping(golden_dir):
+    """The fixture alone: the rows of VARSCOT's own SAM file in which the reference found its 348 GUIDE-seq sites
+    (indexGuideSeq.RData) are what bidir_mapping.cpp:167-187,285-295 writes - reads in input order; per read every
+    '+' record before every '-' record; inside a block ascending (contig in FASTA order, position), except for a
+    handful of LATE records, each of which has strictly fewer mismatches than every record that sorts before it:
+    the best-so-far record that is held back and written when displaced or at the end of its block."""
+    from helpers import UCSC_HG19_ORDER, check_block_order, guideseq_sam_rows, real_guides
+    rows = guideseq_sam_rows(golden_dir)
+    names = real_guides(golden_dir)[0][:9]
+    rank = {c: i for i, c in enumerate(UCSC_HG19_ORDER)}
+    last, n_late = 0, 0
+    for t in names:  # reads in input order: disjoint, ascending row ranges
+        mine = [r for r in rows if r[0] == t]
+        assert mine and min(r[5] for r in mine) > last
+        last = max(r[5] for r in mine)
+        plus = sorted((r[5], (rank[r[1]], r[2]), r[4]) for r in mine if r[3] == "+")
+        minus = sorted((r[5], (rank[r[1]], r[2]), r[4]) for r in mine if r[3] == "-")
+        if plus and minus:
+            assert plus[-1][0] < minus[0][0]  # the '+' block is written before the '-' block
+        for blk in (plus, minus):
+            n_late += len(check_block_order([(key, nm, row) for row, key, nm in blk]))
+    assert 1 <= n_late <= 12  # (9 in the fixture)
+    # a FASTA in natural or lexicographic chromosome order would NOT give ascending blocks: the order is hg19.fa's
+    natural = {"chr%s" % c: i for i, c in enumerate(list(range(1, 23)) + ["X", "Y"])}
+    broken = 0
+    for t in names:
+        for strand in "+-":
+            blk = sorted((r[5], (natural[r[1]], r[2])) for r in rows if r[0] == t and r[3] == strand)
+            broken += sum(1 for a, b in zip(blk, blk[1:]) if b[1] < a[1])
+    assert broken >= 20  # (against 9 under hg19.fa order, all of them held-back records)
+
+
+@pytest.mark.parametrize("mode", ["reference_flow"])
+def test_write_order_equals_the_reference_rows_on_the_guideseq_sites(oracle, golden_dir, mode):
+    """The oracle's REFERENCE_FLOW order (what the product's vsc_sam_order is tested against) on a genome that carries the
+    348 GUIDE-seq sites on the reference's contigs (UCSC hg19 order), in their real order along each chromosome and on
+    their real strand: apart from the records either side holds back as best-so-far (which depends on the other
+    1.7 M records of the real genome), the sites come out in EXACTLY the order of the reference's SAM rows."""
+    from helpers import guideseq_mini_genome, late_records
+    names, guides, cnames, contigs, planted = guideseq_mini_genome(golden_dir)
+    h = oracle.search(contigs, guides, 8, mode=oracle.MODE_REFERENCE_FLOW)
+    where = {(g, c, p, s): i for i, (g, s, c, p, nm, _) in enumerate(hits_as_tuples(h))}
+    ours = []
+    for i, (g, c, p, s, nm, row) in enumerate(planted):
+        assert (g, c, p, s) in where, planted[i]
+        assert hits_as_tuples(h[where[(g, c, p, s)]:where[(g, c, p, s)] + 1])[0][4] == nm
+        ours.append((where[(g, c, p, s)], i))
+    ours = [i for _, i in sorted(ours)]                                   # fixture rows in OUR output order
+    theirs = [i for _, i in sorted((planted[i][5], i) for i in range(len(planted)))]   # ... in the reference's
+    held = set()
+    for seq in (ours, theirs):
+        for g in range(len(guides)):
+            for s in (0, 1):
+                blk = [((planted[i][1], planted[i][2]), planted[i][4], i) for i in seq if planted[i][0] == g and planted[i][3] == s]
+                held |= set(late_records(blk))
+    assert len(held) <= 40  # (29: 9 in the reference rows, the prefix minima of NM of every block here)
+    assert [i for i in ours if i not in held] == [i for i in theirs if i not in held]
+    assert len(ours) - len(held) > 300
