@@ -881,6 +881,29 @@ def test_multi_device_search_behind_the_abi(oracle, devices, algo):
     assert got2.tobytes() == oracle.search_fast(contigs, guides[:10], 3).tobytes()
 
 
+def test_multi_device_search_on_a_genome_smaller_than_the_device_list(oracle):
+    """Five contexts, a genome of one tile: four shards own nothing - the first among them, so the merge on the
+    first device works from the contig table alone (no shard of the genome lives there) - and a second genome of
+    three tiles on the same contexts.  Reads without any hit, a genome without any hit."""
+    rng = np.random.default_rng(55)
+    guides = random_guides(rng, 9)
+    m = va.MultiContext([0] * 5)
+    try:
+        for lens, plants in (([1500, 300], 25), ([2000, 2100, 1900], 40), ([1200], 0)):
+            contigs = make_genome(55 + len(lens), lens, guides[:5] if plants else [], 5, n_plant=plants, n_runs=1)
+            packed = va.PackedGenome.from_sequences(contigs)
+            assert packed.shard_words(0, 5)[1] == 0 or len(lens) == 3  # shard 0 owns nothing of the small genomes
+            g = m.load_genome(packed)
+            for algo in ALGOS:
+                want = oracle.search(contigs, guides, 5, mode=oracle.MODE_PREDICATE)
+                h = g.search(guides, 5, algorithm=algo)
+                assert h.to_numpy().tobytes() == want.tobytes() and (len(want) > 10 or plants == 0)
+                h.close()
+            g.close()
+    finally:
+        m.close()
+
+
 def test_multi_device_exchange_over_rccl_with_one_rank(oracle):
     """The RCCL leg of vsc_multi_search on the one GPU of this box: the hook rccl=1 sets up a one-rank
     communicator (ncclCommInitAll), the hit counts go through ncclAllGather and the records through a grouped
