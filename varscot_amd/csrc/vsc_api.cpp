@@ -887,7 +887,17 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             f.src = src;
             if (bits) {
                 if (use_slots) {
-                    VSC_TRY(other_buf->ensure((size_t)n_bins * slot_cap * sizeof(uint64_t)));
+                    hipError_t ge = other_buf->ensure((size_t)n_bins * slot_cap * sizeof(uint64_t));
+                    if (ge == hipErrorOutOfMemory) {
+                        // no room for the slot layout beside everything else: the exact way needs the compact layout only
+                        (void)hipGetLastError();
+                        uint64_t span = 1;
+                        for (const SortSeg &sg : segs) span = std::max<uint64_t>(span, sg.out_off + sg.n_in);
+                        VSC_TRY(other_buf->ensure(span * sizeof(uint64_t)));
+                        use_slots = false;
+                    } else if (ge != hipSuccess) {
+                        return ge;
+                    }
                     other = (uint64_t *)other_buf->p;
                 }
                 SortArgs a{};
