@@ -140,6 +140,28 @@ void guide_planes(uint64_t g, uint32_t *h, uint32_t *l)
 
 }  // namespace
 
+// No C++ exception crosses the C boundary (include/varscot_hip.h): every entry point that allocates on the host runs
+// inside this guard.
+template <class F> int guarded(vsc_ctx *ctx, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        try {
+            if (ctx) ctx->err = "out of host memory";
+        } catch (...) {
+        }
+        return VSC_ERR_NOMEM;
+    } catch (...) {
+        try {
+            if (ctx) ctx->err = "unexpected C++ exception";
+        } catch (...) {
+        }
+        return VSC_ERR_DEVICE;
+    }
+}
+
+
 extern "C" {
 
 int vsc_abi_version(void) { return VSC_ABI_VERSION; }
@@ -249,6 +271,7 @@ int vsc_genome_load(vsc_ctx *ctx, const uint32_t *hi, const uint32_t *lo, const 
                     uint64_t n_words, uint64_t own_words, const vsc_contig *contigs, uint32_t n_contigs,
                     vsc_genome **out)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx || !out) return VSC_ERR_INVALID;
     *out = nullptr;
     ctx->err.clear();
@@ -306,6 +329,7 @@ int vsc_genome_load(vsc_ctx *ctx, const uint32_t *hi, const uint32_t *lo, const 
     g->device_bytes = 3 * pb + 2 * cb;
     *out = g;
     return VSC_OK;
+    });
 }
 
 }  // extern "C"
@@ -658,6 +682,7 @@ hipError_t index_io(std::FILE *f, void *dev, uint64_t bytes, bool to_file, std::
 
 int vsc_genome_build_index(vsc_ctx *ctx, vsc_genome *genome, const vsc_search_params *params)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx || !genome || genome->ctx != ctx) return VSC_ERR_INVALID;
     ctx->err.clear();
     if (index_matches(genome, params)) return VSC_OK;
@@ -670,10 +695,12 @@ int vsc_genome_build_index(vsc_ctx *ctx, vsc_genome *genome, const vsc_search_pa
     }
     ctx->timing.index_ms = genome->index_ms;
     return VSC_OK;
+    });
 }
 
 int vsc_genome_index_save(vsc_ctx *ctx, const vsc_genome *genome, const char *path)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx || !genome || genome->ctx != ctx || !path) return VSC_ERR_INVALID;
     ctx->err.clear();
     if (!genome->has_index) return fail(ctx, VSC_ERR_INVALID, "vsc_genome_index_save: the genome has no seed index (vsc_genome_build_index)");
@@ -706,10 +733,12 @@ int vsc_genome_index_save(vsc_ctx *ctx, const vsc_genome *genome, const char *pa
     if (ok) ok = std::fflush(fc.f) == 0;
     if (!ok) return fail(ctx, VSC_ERR_DEVICE, (std::string("vsc_genome_index_save: write to ") + path + " failed").c_str());
     return VSC_OK;
+    });
 }
 
 int vsc_genome_index_load(vsc_ctx *ctx, vsc_genome *genome, const char *path)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx || !genome || genome->ctx != ctx || !path) return VSC_ERR_INVALID;
     ctx->err.clear();
     VSC_HIP(ctx, hipSetDevice(ctx->device));
@@ -784,6 +813,7 @@ int vsc_genome_index_load(vsc_ctx *ctx, vsc_genome *genome, const char *path)
     genome->index_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->timing.index_ms = genome->index_ms;
     return VSC_OK;
+    });
 }
 
 }  // extern "C"
@@ -1326,6 +1356,7 @@ extern "C" {
 int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
                const vsc_search_params *params, vsc_hits **out)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx || !out) return VSC_ERR_INVALID;
     *out = nullptr;
     vsc_timing t{};
@@ -1354,11 +1385,13 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
     ctx->timing = t;
     *out = hits;
     return VSC_OK;
+    });
 }
 
 int vsc_search_stream(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
                       const vsc_search_params *params, uint32_t batch_reads, vsc_batch_fn on_batch, void *user)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return VSC_ERR_INVALID;
     vsc_timing t{};
     int algo = 0;
@@ -1387,6 +1420,7 @@ int vsc_search_stream(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *gu
     }
     ctx->timing = t;
     return VSC_OK;
+    });
 }
 
 uint64_t vsc_hits_count(const vsc_hits *hits) { return hits ? hits->n : 0; }
@@ -1395,6 +1429,7 @@ const void *vsc_hits_data_dev(const vsc_hits *hits) { return hits ? hits->d_reco
 
 int vsc_hits_data(vsc_hits *hits, const vsc_hit **out)
 {
+    return guarded(nullptr, [&]() -> int {
     if (!hits || !out) return VSC_ERR_INVALID;
     *out = nullptr;
     if (!hits->host_valid) {
@@ -1414,10 +1449,12 @@ int vsc_hits_data(vsc_hits *hits, const vsc_hit **out)
     }
     *out = hits->host.data();
     return VSC_OK;
+    });
 }
 
 int vsc_hits_copy(vsc_hits *hits, void *dst, int dst_is_device)
 {
+    return guarded(nullptr, [&]() -> int {
     if (!hits || (!dst && hits->n)) return VSC_ERR_INVALID;
     if (hits->n == 0) return VSC_OK;
     vsc_ctx *ctx = hits->ctx;
@@ -1426,11 +1463,13 @@ int vsc_hits_copy(vsc_hits *hits, void *dst, int dst_is_device)
                                 dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VSC_OK;
+    });
 }
 
 int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, const uint64_t *shard_counts,
                    uint32_t n_shards, uint32_t n_guides, vsc_hits **out)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx || !out) return VSC_ERR_INVALID;
     *out = nullptr;
     ctx->err.clear();
@@ -1482,11 +1521,13 @@ int vsc_hits_merge(vsc_ctx *ctx, const void *records, int records_on_device, con
     }
     *out = hits;
     return VSC_OK;
+    });
 }
 
 int vsc_hits_pack_exchange(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, uint32_t n_guides, void *records,
                            int records_on_device, uint32_t *key_counts)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return VSC_ERR_INVALID;
     ctx->err.clear();
     if (!genome || !hits || genome->ctx != ctx || hits->ctx != ctx || (n_guides && !key_counts) || (hits->n && !records))
@@ -1521,11 +1562,13 @@ int vsc_hits_pack_exchange(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hit
         key_counts[k] = (uint32_t)c;
     }
     return VSC_OK;
+    });
 }
 
 int vsc_hits_merge_packed(vsc_ctx *ctx, const vsc_genome *genome, const void *records, int records_on_device, const uint32_t *key_counts,
                           uint32_t n_shards, uint32_t first_key, uint32_t n_keys, vsc_hits **out)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx || !out) return VSC_ERR_INVALID;
     *out = nullptr;
     ctx->err.clear();
@@ -1592,6 +1635,7 @@ int vsc_hits_merge_packed(vsc_ctx *ctx, const vsc_genome *genome, const void *re
     }
     *out = hits;
     return VSC_OK;
+    });
 }
 
 int vsc_hits_free(vsc_hits *hits)
@@ -1666,6 +1710,7 @@ int vsc_score_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits,
                    uint32_t n_guides, uint64_t first, uint64_t count, double *mit, uint8_t *mit_flags,
                    uint8_t *features)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return VSC_ERR_INVALID;
     ctx->err.clear();
     if (!genome || !hits || (n_guides && !guides)) return fail(ctx, VSC_ERR_INVALID, "vsc_score_hits: null argument");
@@ -1701,11 +1746,13 @@ int vsc_score_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits,
     }
     ctx->timing.score_ms = total_ms;
     return VSC_OK;
+    });
 }
 
 int vsc_score_pairs(vsc_ctx *ctx, const uint64_t *on_targets, const uint64_t *off_targets, const uint32_t *masks,
                     uint64_t n, double *mit, uint8_t *mit_flags, uint8_t *features)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return VSC_ERR_INVALID;
     ctx->err.clear();
     if (n && (!on_targets || !off_targets || !masks)) return fail(ctx, VSC_ERR_INVALID, "vsc_score_pairs: null argument");
@@ -1748,12 +1795,14 @@ int vsc_score_pairs(vsc_ctx *ctx, const uint64_t *on_targets, const uint64_t *of
     VSC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->timing.score_ms = ms;
     return VSC_OK;
+    });
 }
 
 int vsc_score_hits_packed(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, const uint64_t *guides,
                           uint32_t n_guides, uint64_t first, uint64_t count, void *packed_dev, uint32_t *packed_host,
                           double *mit_host)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return VSC_ERR_INVALID;
     ctx->err.clear();
     if (!genome || !hits || (n_guides && !guides)) return fail(ctx, VSC_ERR_INVALID, "vsc_score_hits_packed: null argument");
@@ -1813,6 +1862,7 @@ int vsc_score_hits_packed(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits
     }
     ctx->timing.score_ms = total_ms;
     return VSC_OK;
+    });
 }
 
 }  // extern "C"
@@ -2044,21 +2094,26 @@ extern "C" {
 int vsc_rf_predict(vsc_ctx *ctx, const vsc_rf_model *model, const uint8_t *features, const double *activity, uint64_t n,
                    double *prob, uint8_t *cls, uint8_t *tie)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return VSC_ERR_INVALID;
     return rf_predict(ctx, model, features, nullptr, 0, activity, n, prob, cls, tie, "vsc_rf_predict");
+    });
 }
 
 int vsc_rf_predict_packed(vsc_ctx *ctx, const vsc_rf_model *model, const void *packed_rows, int rows_on_device,
                           const double *activity, uint64_t n, double *prob, uint8_t *cls, uint8_t *tie)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return VSC_ERR_INVALID;
     return rf_predict(ctx, model, nullptr, packed_rows, rows_on_device, activity, n, prob, cls, tie, "vsc_rf_predict_packed");
+    });
 }
 
 int vsc_score_classify_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, const uint64_t *guides, uint32_t n_guides,
                             const double *guide_activity, const vsc_rf_model *model, uint64_t first, uint64_t count, void *votes_dev,
                             uint16_t *votes_host, double *mit_host)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return VSC_ERR_INVALID;
     ctx->err.clear();
     if (!genome || !hits || (n_guides && (!guides || !guide_activity)))
@@ -2103,6 +2158,7 @@ int vsc_score_classify_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hi
     }
     ctx->timing.score_ms = total_ms;
     return VSC_OK;
+    });
 }
 
 }  // extern "C"

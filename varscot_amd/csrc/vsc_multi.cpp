@@ -121,12 +121,33 @@ template <class F> void on_all(size_t n, F &&body)
 
 }  // namespace
 
+// no C++ exception crosses the C boundary
+template <class F> int mguarded(vsc_multi *m, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        try {
+            if (m) m->err = "out of host memory";
+        } catch (...) {
+        }
+        return VSC_ERR_NOMEM;
+    } catch (...) {
+        try {
+            if (m) m->err = "unexpected C++ exception";
+        } catch (...) {
+        }
+        return VSC_ERR_DEVICE;
+    }
+}
+
 extern "C" {
 
 int vsc_multi_create(const int *device_ids, int n, vsc_multi **out) { return vsc_multi_create_debug(device_ids, n, nullptr, out); }
 
 int vsc_multi_create_debug(const int *device_ids, int n, const vsc_multi_debug_params *params, vsc_multi **out)
 {
+    return mguarded(nullptr, [&]() -> int {
     if (!out) return VSC_ERR_INVALID;
     *out = nullptr;
     if (!device_ids || n <= 0 || n > 64) return VSC_ERR_INVALID;
@@ -182,6 +203,7 @@ int vsc_multi_create_debug(const int *device_ids, int n, const vsc_multi_debug_p
     }
     *out = m;
     return VSC_OK;
+    });
 }
 
 int vsc_multi_destroy(vsc_multi *m)
@@ -220,6 +242,7 @@ int vsc_multi_get_timing(const vsc_multi *m, vsc_multi_timing *out)
 int vsc_multi_genome_load(vsc_multi *m, const uint32_t *hi, const uint32_t *lo, const uint32_t *nmask, uint64_t n_words,
                           const vsc_contig *contigs, uint32_t n_contigs, vsc_multi_genome **out)
 {
+    return mguarded(m, [&]() -> int {
     if (!m || !out) return VSC_ERR_INVALID;
     *out = nullptr;
     m->err.clear();
@@ -254,6 +277,7 @@ int vsc_multi_genome_load(vsc_multi *m, const uint32_t *hi, const uint32_t *lo, 
     }
     *out = g;
     return VSC_OK;
+    });
 }
 
 int vsc_multi_genome_free(vsc_multi_genome *g)
@@ -268,6 +292,7 @@ int vsc_multi_genome_free(vsc_multi_genome *g)
 
 int vsc_multi_genome_build_index(vsc_multi *m, vsc_multi_genome *g, const vsc_search_params *params)
 {
+    return mguarded(m, [&]() -> int {
     if (!m || !g || g->multi != m) return VSC_ERR_INVALID;
     m->err.clear();
     const size_t n = m->ctx.size();
@@ -278,11 +303,13 @@ int vsc_multi_genome_build_index(vsc_multi *m, vsc_multi_genome *g, const vsc_se
     for (size_t r = 0; r < n; ++r)
         if (rc[r] != VSC_OK) return mfail(m, rc[r], "shard " + std::to_string(r) + ": " + vsc_last_error(m->ctx[r]));
     return VSC_OK;
+    });
 }
 
 int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides, uint32_t n_guides,
                      const vsc_search_params *params, vsc_hits **out)
 {
+    return mguarded(m, [&]() -> int {
     if (!m || !out) return VSC_ERR_INVALID;
     *out = nullptr;
     m->err.clear();
@@ -418,6 +445,7 @@ int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *gu
     return VSC_OK;
 #undef VSC_M
 #undef VSC_N
+    });
 }
 
 }  // extern "C"
