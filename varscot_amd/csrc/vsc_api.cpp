@@ -1140,8 +1140,9 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         uint32_t groups_per_cu = kSlicedWavesPerSimd;  // resident groups (of four waves) per CU: registers / LDS of the kernel
         if (ctx->dbg.seed_groups_per_cu) groups_per_cu = ctx->dbg.seed_groups_per_cu;
         // dense searches (c3: 129 reads per bucket) share a chunk between the four waves of a workgroup, sparse ones
-        // (c2: 13) keep a chunk per wave - see seed_sliced_kernel
-        seed_shared = n_pairs / kBuckets >= 48;
+        // (c2: 13) keep a chunk per wave - see seed_sliced_kernel.  Measured at <= 8 mismatches (tools/
+        // exp_shared_threshold.sh): 51 reads per bucket 12.1 vs 11.4 ms, 77: 15.9 vs 16.0, 103: 19.9 vs 20.7
+        seed_shared = n_pairs / kBuckets >= 72;
         if (ctx->dbg.seed_shared >= 0) seed_shared = ctx->dbg.seed_shared == 1;
         const uint32_t n_grabs = (sa.n_chunks + kSlicedGrab - 1) / kSlicedGrab;
         const uint32_t n_waves_max = (uint32_t)ctx->n_cus * groups_per_cu * kWavesPerGroup;
