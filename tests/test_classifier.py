@@ -118,6 +118,95 @@ def test_fused_score_classify_equals_score_then_predict(golden_dir):
     ctx.close()
 
 
+def _synthetic_forest(path, rng, n_trees, n_nodes, names, depth_first=False):
+    """A random forest file (the exporter's format): random binary trees grown breadth-first (randomForest's node
+    numbering: the daughters of a node are the next two free numbers) over predictors of the feature matrix, with
+    splits at x.5, integer splits, a few below zero and above any value, some trees a single terminal node."""
+    import struct
+    cols = {n: i for i, n in enumerate(feature_names())}
+    status = np.zeros((n_trees, n_nodes), dtype=np.int8)
+    best = np.zeros((n_trees, n_nodes), dtype=np.uint8)
+    left = np.zeros((n_trees, n_nodes), dtype="<u2")
+    right = np.zeros((n_trees, n_nodes), dtype="<u2")
+    split = np.zeros((n_trees, n_nodes), dtype="<f8")
+    cls = np.zeros((n_trees, n_nodes), dtype=np.uint8)
+    for t in range(n_trees):
+        size = 1 if t % 17 == 0 else int(rng.integers(3, n_nodes + 1)) | 1  # odd: every split adds two nodes
+        nxt = 1
+        for k in range(size):
+            if nxt + 2 <= size and (rng.random() < 0.9 or k == 0):
+                status[t, k] = 1
+                v = int(rng.integers(0, len(names)))
+                best[t, k] = v + 1
+                left[t, k], right[t, k] = nxt + 1, nxt + 2
+                nxt += 2
+                if names[v] == "ontargetActivity":
+                    split[t, k] = float(rng.choice([0.31, 0.5, 0.77, 1.02, 1.4]))
+                else:
+                    split[t, k] = float(rng.choice([0.5, 0.5, 0.5, 1.5, 2.5, 1.0, 3.0, -0.5, 300.0]))
+            else:
+                status[t, k] = -1
+                cls[t, k] = int(rng.integers(1, 3))
+        assert nxt == size
+    with open(path, "wb") as f:
+        f.write(b"VSCRF001" + struct.pack("<III", n_trees, n_nodes, len(names)))
+        for n in names:
+            f.write(struct.pack("<H", len(n)) + n.encode())
+        for a in (status, best, left, right, split, cls):
+            f.write(a.tobytes())
+    return cols
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_nodes", [31, 511, 700])
+def test_rf_predict_on_synthetic_forests(tmp_path, golden_dir, n_nodes):
+    """Both node forms of the forest kernel - compact nodes walked through per-lane tree queues (<= 512 nodes per tree)
+    and the self-looping form with wave-uniform step counts (more) - against the Python restatement of
+    randomForest's predict, on random forests: unbalanced trees, trees that are one terminal node, count predictors
+    split at integers and at x.5, splits below zero and above every value, the activity split at a handful of
+    thresholds with rows exactly on them; dense rows, packed rows and few / many rows."""
+    from oracle.rf_oracle import Forest as OracleForest
+    rng = np.random.default_rng(n_nodes)
+    names = ["totalMismatches", "seedMismatches", "adjacentMismatches", "transitionNumber", "transversionNumber", "mismatchPos3",
+             "mismatchPos17", "AtoC", "TtoG", "A1", "T20", "PAMG", "GG", "CA", "TT", "AA7", "CG19", "ontargetActivity"]
+    path = str(tmp_path / "forest.vscrf")
+    _synthetic_forest(path, rng, 64, n_nodes, names)
+    g = np.load(os.path.join(golden_dir, "features_golden.npz"))
+    feats = g["feat"][::9].astype(np.uint8)
+    act = rng.choice([0.2, 0.31, 0.5, 0.77, 0.9, 1.02, 1.4, 1.7], size=len(feats))
+    ctx = va.Context(0)
+    forest = Forest(path)
+    prob, cls, tie = forest.predict(ctx, feats, act)
+    of = OracleForest(path)
+    all_names = feature_names()
+    for i in range(0, len(feats), 3):
+        row = dict(zip(all_names, list(feats[i]) + [act[i]]))
+        p, c, ti = of.predict(row)
+        assert (prob[i], cls[i], bool(tie[i])) == (p, c, ti), i
+    assert 0 < cls.mean() < 1
+    prob3, _, _ = forest.predict(ctx, np.tile(feats, (40, 1)), np.tile(act, 40))  # many rows: whole forest per workgroup
+    assert np.array_equal(prob3, np.tile(prob, 40))
+    # the other two row sources - packed rows, and rows computed in the kernel from hits - vote like the dense rows
+    from helpers import make_genome, random_guides
+    guides = random_guides(rng, 12)
+    contigs = make_genome(n_nodes, [50000, 9000], guides, 6, n_plant=300, n_runs=1)
+    gen = ctx.load_genome(va.PackedGenome.from_sequences(contigs))
+    h = gen.search(guides, 6)
+    rec = h.to_numpy()
+    assert len(rec) > 200
+    _, _, dense = h.scores(mit=False, features=True)
+    rows, _ = h.packed_features()
+    gact = rng.choice([0.2, 0.31, 0.5, 0.77, 1.02, 1.4, 1.7], size=len(guides))
+    want = forest.predict(ctx, dense, gact[rec["guide"]])
+    got = forest.predict_packed(ctx, rows, gact[rec["guide"]])
+    assert all(np.array_equal(x, y) for x, y in zip(want, got))
+    votes, _ = forest.classify_hits(h, gact)
+    assert np.array_equal(votes / float(forest.n_trees), want[0])
+    h.close()
+    gen.close()
+    ctx.close()
+
+
 @pytest.mark.gpu
 def test_classification_pipeline_tool(tmp_path, golden_dir):
     """TSV + feature file in, TSV with the Score column replaced out (classificationPipeline.R:36-48)."""

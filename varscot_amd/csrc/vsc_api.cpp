@@ -1976,7 +1976,9 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
     };
     std::vector<uint32_t> index_of(keys.size());  // by position in `keys`
     for (size_t i = 0; i < keys.size(); ++i) index_of[i] = test_index((uint16_t)(keys[i] >> 8), (uint8_t)keys[i]);
-    // nodes: test | left << 10 | right << 20 (0-based) | terminal << 30 | votes class "1" << 31
+    // nodes: test | left << 10 | right << 20 (0-based) | terminal << 30 | votes class "1" << 31; or the compact form
+    // (trees of <= 512 nodes): test | (daughter | terminal << 9 | vote << 10) << 10 (left) / << 21 (right)
+    const bool compact = model->n_nodes <= 512;
     std::vector<uint32_t> nodes(nn);
     std::vector<uint8_t> depth(model->n_trees, 0);
     std::vector<uint16_t> level(model->n_nodes);
@@ -1993,8 +1995,20 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
             if (sp.never) l = r;  // x <= (negative) never holds: both ways lead right
             else test = index_of[std::lower_bound(keys.begin(), keys.end(), (uint32_t)sp.col << 8 | sp.thr) - keys.begin()];
             nodes[i] = test | l << 10 | r << 20;
+            if (compact) {
+                auto daughter = [&](uint32_t d) {
+                    const size_t j = (size_t)tr * model->n_nodes + d;
+                    return model->node_status[j] == 1 ? d : (1u << 9 | (model->node_class[j] == 2 ? 1u << 10 : 0u));
+                };
+                nodes[i] = test | daughter(l) << 10 | daughter(r) << 21;
+            }
             level[l] = level[r] = (uint16_t)(level[k] + 1);  // (daughters lie behind their parent: level[k] is final here)
             depth[tr] = (uint8_t)std::min<uint32_t>(255, std::max<uint32_t>(depth[tr], level[k] + 1u));
+        }
+        if (compact && model->node_status[(size_t)tr * model->n_nodes] != 1) {
+            // a tree that is one terminal node: a root whose daughters both are "terminal, the root's vote"
+            const uint32_t leaf = 1u << 9 | (model->node_class[(size_t)tr * model->n_nodes] == 2 ? 1u << 10 : 0u);
+            nodes[(size_t)tr * model->n_nodes] = leaf << 10 | leaf << 21;
         }
     }
     VSC_HIP(ctx, hipSetDevice(ctx->device));
@@ -2011,6 +2025,7 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
     f.tests_at = nodes_b + depth_b;
     f.begin_at = nodes_b + depth_b + tests_b;
     f.n_tests = (uint32_t)tests.size();
+    f.compact = compact;
     f.n_trees = model->n_trees;
     f.n_nodes = model->n_nodes;
     f.thresholds = thr;
@@ -2027,6 +2042,7 @@ void fill_forest(RfArgs &a, const vsc_ctx *ctx)
     a.tests = (const RfTest *)(base + f.tests_at);
     a.test_begin = (const uint32_t *)(base + f.begin_at);
     a.n_tests = f.n_tests;
+    a.compact = f.compact ? 1u : 0u;
     a.n_trees = f.n_trees;
     a.n_nodes = f.n_nodes;
 }

@@ -225,6 +225,10 @@ struct SeedArgs {
 //   bits 0..9 test | 10..19 left daughter | 20..29 right daughter (0-based; a terminal node points at itself) |
 //   30 terminal | 31 votes class "1"
 // A node visit is one 4-byte LDS read of the node + one of the row's test word.
+// Trees of at most 512 nodes (rfClassifier: 275) use the COMPACT form, in which a node says of each daughter either where
+// it is or that it is terminal and how it votes - terminal nodes are never visited, and a lane moves on to its next tree
+// the moment it reaches one:
+//   bits 0..9 test | 10..18 left daughter, 19 left is terminal, 20 its vote | 21..29 right daughter, 30 terminal, 31 vote
 constexpr int kRfRows = 256;             // feature rows per workgroup (one thread each)
 constexpr int kRfMaxTests = 1024;        // distinct (predictor, threshold) pairs a forest may use
 constexpr int kRfMaxNodes = 1024;        // nodes of one tree (rfClassifier: 275)
@@ -242,6 +246,7 @@ struct RfArgs {
     const uint32_t *nodes;      // [n_trees * n_nodes], tree-major
     const uint8_t *depth;       // [n_trees] steps from the root to the deepest terminal node
     uint32_t n_trees, n_nodes;
+    uint32_t compact;           // 1: compact nodes (<= 512 per tree), walked through per-lane tree queues; 0: the form above
     const RfTest *tests;        // [n_tests], sorted by the row word they read
     const uint32_t *test_begin; // [kRfRowWords + 1] first test of every row word
     uint32_t n_tests;

@@ -982,9 +982,38 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
         const uint32_t *src = a.nodes + (size_t)t0 * a.n_nodes;
         for (uint32_t i = t; i < nt * a.n_nodes; i += kRfRows) s_tile[i] = src[i];
         block_sync();
-        // Two trees in flight per thread: a walk is a chain of dependent LDS reads, two chains overlap their latencies.
-        // Terminal nodes point at themselves, so every lane simply takes as many steps as the deeper of the two trees
-        // is deep (wave-uniform trip count: no per-lane exit test).
+        if (a.compact) {
+            // Per-lane tree queues: a lane that reaches a terminal node goes straight on to its next tree instead of
+            // idling until the deepest tree of the wave is through (the trees are 11 - 21 levels deep, a row's path 9
+            // on average).  A node names, per daughter, either the daughter's index or "terminal, class c", so terminal
+            // nodes are never read.  Two chains per lane (the two halves of the tile) overlap their LDS latencies; the
+            // wave leaves when every lane has finished both.
+            const uint32_t half = (nt + 1) / 2;
+            uint32_t k0 = 0, k1 = half;
+            uint32_t n0 = s_tile[0], n1 = s_tile[(size_t)min(half, nt - 1) * a.n_nodes];
+            for (;;) {
+                const bool go0 = k0 < half, go1 = k1 < nt;
+                if (!__ballot(go0 | go1)) break;
+                const uint32_t b0 = (bt[((n0 & 1023u) >> 5) * kRfRows] >> (n0 & 31u)) & 1u;
+                const uint32_t b1 = (bt[((n1 & 1023u) >> 5) * kRfRows] >> (n1 & 31u)) & 1u;
+                const uint32_t c0 = (n0 >> (b0 ? 10u : 21u)) & 0x7FFu, c1 = (n1 >> (b1 ? 10u : 21u)) & 0x7FFu;
+                const uint32_t l0 = (c0 >> 9) & 1u, l1 = (c1 >> 9) & 1u;
+                if (go0) {
+                    ones += l0 & (c0 >> 10);
+                    k0 += l0;
+                    n0 = s_tile[min(k0, nt - 1) * a.n_nodes + (l0 ? 0u : (c0 & 511u))];  // (a finished chain keeps reading a valid node)
+                }
+                if (go1) {
+                    ones += l1 & (c1 >> 10);
+                    k1 += l1;
+                    n1 = s_tile[min(k1, nt - 1) * a.n_nodes + (l1 ? 0u : (c1 & 511u))];
+                }
+            }
+            continue;
+        }
+        // (forests with more than 512 nodes per tree) Two trees in flight per thread: a walk is a chain of dependent LDS
+        // reads, two chains overlap their latencies.  Terminal nodes point at themselves, so every lane simply takes as
+        // many steps as the deeper of the two trees is deep (wave-uniform trip count: no per-lane exit test).
         for (uint32_t k = 0; k < nt; k += 2) {
             const uint32_t k1 = min(k + 1, nt - 1);
             const uint32_t *const tree0 = s_tile + (size_t)k * a.n_nodes, *const tree1 = s_tile + (size_t)k1 * a.n_nodes;

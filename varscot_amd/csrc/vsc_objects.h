@@ -75,6 +75,7 @@ struct vsc_ctx {
         vsc::DeviceBuf nodes, ranks;   // nodes + tree depths + test table; activity ranks of the reads of a fused call
         size_t depth_at = 0, tests_at = 0, begin_at = 0;
         uint32_t n_tests = 0, n_trees = 0, n_nodes = 0;
+        bool compact = false;           // node form (vsc_internal.h)
         std::vector<double> thresholds;  // distinct activity splits, ascending
         uint64_t fingerprint = 0;
     } forest;
