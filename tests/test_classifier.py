@@ -131,10 +131,10 @@ def _synthetic_forest(path, rng, n_trees, n_nodes, names, depth_first=False):
     split = np.zeros((n_trees, n_nodes), dtype="<f8")
     cls = np.zeros((n_trees, n_nodes), dtype=np.uint8)
     for t in range(n_trees):
-        size = 1 if t % 17 == 0 else int(rng.integers(3, n_nodes + 1)) | 1  # odd: every split adds two nodes
-        nxt = 1
-        for k in range(size):
-            if nxt + 2 <= size and (rng.random() < 0.9 or k == 0):
+        size = 1 if t % 17 == 0 else min(n_nodes, int(rng.integers(3, n_nodes + 1)) | 1)  # odd: every split adds two nodes
+        nxt, k = 1, 0
+        while k < nxt:  # nodes in creation order; nodes behind nxt do not exist
+            if nxt + 2 <= size and (rng.random() < 0.9 or k == nxt - 1):
                 status[t, k] = 1
                 v = int(rng.integers(0, len(names)))
                 best[t, k] = v + 1
@@ -147,7 +147,7 @@ def _synthetic_forest(path, rng, n_trees, n_nodes, names, depth_first=False):
             else:
                 status[t, k] = -1
                 cls[t, k] = int(rng.integers(1, 3))
-        assert nxt == size
+            k += 1
     with open(path, "wb") as f:
         f.write(b"VSCRF001" + struct.pack("<III", n_trees, n_nodes, len(names)))
         for n in names:
