@@ -1996,11 +1996,12 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
             else test = index_of[std::lower_bound(keys.begin(), keys.end(), (uint32_t)sp.col << 8 | sp.thr) - keys.begin()];
             nodes[i] = test | l << 10 | r << 20;
             if (compact) {
+                // (x <= thr takes the LEFT daughter: filed in the upper field, which the kernel selects with 10 + 11 * bit)
                 auto daughter = [&](uint32_t d) {
                     const size_t j = (size_t)tr * model->n_nodes + d;
                     return model->node_status[j] == 1 ? d : (1u << 9 | (model->node_class[j] == 2 ? 1u << 10 : 0u));
                 };
-                nodes[i] = test | daughter(l) << 10 | daughter(r) << 21;
+                nodes[i] = test | daughter(r) << 10 | daughter(l) << 21;
             }
             level[l] = level[r] = (uint16_t)(level[k] + 1);  // (daughters lie behind their parent: level[k] is final here)
             depth[tr] = (uint8_t)std::min<uint32_t>(255, std::max<uint32_t>(depth[tr], level[k] + 1u));

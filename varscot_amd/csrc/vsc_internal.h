@@ -228,7 +228,8 @@ struct SeedArgs {
 // Trees of at most 512 nodes (rfClassifier: 275) use the COMPACT form, in which a node says of each daughter either where
 // it is or that it is terminal and how it votes - terminal nodes are never visited, and a lane moves on to its next tree
 // the moment it reaches one:
-//   bits 0..9 test | 10..18 left daughter, 19 left is terminal, 20 its vote | 21..29 right daughter, 30 terminal, 31 vote
+//   bits 0..9 test | 10..18 right daughter, 19 right is terminal, 20 its vote | 21..29 left daughter, 30 terminal, 31 vote
+// (a terminal daughter's index bits are 0; the all-zero word is the SINK behind the last tree of a chain)
 constexpr int kRfRows = 256;             // feature rows per workgroup (one thread each)
 constexpr int kRfMaxTests = 1024;        // distinct (predictor, threshold) pairs a forest may use
 constexpr int kRfMaxNodes = 1024;        // nodes of one tree (rfClassifier: 275)

@@ -980,34 +980,40 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
         const uint32_t nt = min(tile_trees, tree_end - t0);
         block_sync();  // the previous tile (first round: the rows' words) is done with
         const uint32_t *src = a.nodes + (size_t)t0 * a.n_nodes;
-        for (uint32_t i = t; i < nt * a.n_nodes; i += kRfRows) s_tile[i] = src[i];
+        if (a.compact) {  // [trees of chain 0][sink][trees of chain 1][sink] - see below
+            const uint32_t cut = ((nt + 1) / 2) * a.n_nodes, total = nt * a.n_nodes;
+            for (uint32_t i = t; i < total; i += kRfRows) s_tile[i + (i >= cut ? 1u : 0u)] = src[i];
+            if (t == 0) s_tile[cut] = 0u;
+            if (t == 1) s_tile[total + 1u] = 0u;
+        } else {
+            for (uint32_t i = t; i < nt * a.n_nodes; i += kRfRows) s_tile[i] = src[i];
+        }
         block_sync();
         if (a.compact) {
             // Per-lane tree queues: a lane that reaches a terminal node goes straight on to its next tree instead of
             // idling until the deepest tree of the wave is through (the trees are 11 - 21 levels deep, a row's path 9
-            // on average).  A node names, per daughter, either the daughter's index or "terminal, class c", so terminal
-            // nodes are never read.  Two chains per lane (the two halves of the tile) overlap their LDS latencies; the
-            // wave leaves when every lane has finished both.
+            // on average).  A node names, per daughter, either the daughter's index or "terminal, vote v" (index bits
+            // zero), so terminal nodes are never read: reaching one adds the vote and moves the lane's tree base on by
+            // one tree, where index 0 is the next root.  Two chains per lane - the two halves of the tile - overlap their
+            // LDS latencies; behind the last tree of each half lies a SINK word (0 = test 0, both daughters "index 0,
+            // not terminal": it points at itself and votes nothing), so a finished chain spins without side effects
+            // and the wave leaves when every lane's two nodes are sinks.  Straight-line code, no per-lane predicates.
+            //   tile layout: [trees of chain 0][sink][trees of chain 1][sink]
             const uint32_t half = (nt + 1) / 2;
-            uint32_t k0 = 0, k1 = half;
-            uint32_t n0 = s_tile[0], n1 = s_tile[(size_t)min(half, nt - 1) * a.n_nodes];
-            for (;;) {
-                const bool go0 = k0 < half, go1 = k1 < nt;
-                if (!__ballot(go0 | go1)) break;
-                const uint32_t b0 = (bt[((n0 & 1023u) >> 5) * kRfRows] >> (n0 & 31u)) & 1u;
-                const uint32_t b1 = (bt[((n1 & 1023u) >> 5) * kRfRows] >> (n1 & 31u)) & 1u;
-                const uint32_t c0 = (n0 >> (b0 ? 10u : 21u)) & 0x7FFu, c1 = (n1 >> (b1 ? 10u : 21u)) & 0x7FFu;
-                const uint32_t l0 = (c0 >> 9) & 1u, l1 = (c1 >> 9) & 1u;
-                if (go0) {
-                    ones += l0 & (c0 >> 10);
-                    k0 += l0;
-                    n0 = s_tile[min(k0, nt - 1) * a.n_nodes + (l0 ? 0u : (c0 & 511u))];  // (a finished chain keeps reading a valid node)
-                }
-                if (go1) {
-                    ones += l1 & (c1 >> 10);
-                    k1 += l1;
-                    n1 = s_tile[min(k1, nt - 1) * a.n_nodes + (l1 ? 0u : (c1 & 511u))];
-                }
+            uint32_t base0 = 0, base1 = (half * a.n_nodes + 1u) * 4u;  // byte offsets of the lane's current trees
+            const char *const tile_b = (const char *)s_tile;
+            uint32_t n0 = s_tile[0], n1 = s_tile[half * a.n_nodes + 1u];
+            const uint32_t tree_bytes = a.n_nodes * 4u;
+            while (__ballot((n0 | n1) != 0u)) {
+                const uint32_t w0 = bt[((n0 >> 5) & 31u) * kRfRows], w1 = bt[((n1 >> 5) & 31u) * kRfRows];
+                // x <= thr (bit set) takes the left daughter, filed at bits 21..31; else the right one at bits 10..20
+                const uint32_t c0 = __builtin_amdgcn_ubfe(n0, 10u + 11u * __builtin_amdgcn_ubfe(w0, n0, 1u), 11u);
+                const uint32_t c1 = __builtin_amdgcn_ubfe(n1, 10u + 11u * __builtin_amdgcn_ubfe(w1, n1, 1u), 11u);
+                ones += (c0 >> 10) + (c1 >> 10);                  // the vote bit is set for terminal daughters only
+                base0 += ((c0 >> 9) & 1u) * tree_bytes;           // terminal: on to the next tree (its root: index 0)
+                base1 += ((c1 >> 9) & 1u) * tree_bytes;
+                n0 = *(const uint32_t *)(tile_b + base0 + (c0 & 511u) * 4u);
+                n1 = *(const uint32_t *)(tile_b + base1 + (c1 & 511u) * 4u);
             }
             continue;
         }
@@ -1047,7 +1053,7 @@ hipError_t launch_rf_predict(const RfArgs &args, hipStream_t stream)
     const uint64_t tiles = (args.n + kRfRows - 1) / kRfRows;
     if (tiles >= (1ull << 31)) return hipErrorInvalidValue;
     const size_t n_words = (args.n_tests + 31) / 32;
-    const size_t lds = n_words * kRfRows * sizeof(uint32_t) + (size_t)kRfTileBytes;  // test bits + the tree tile
+    const size_t lds = n_words * kRfRows * sizeof(uint32_t) + (size_t)kRfTileBytes + 8;  // test bits + the tree tile (+ two sink words)
     const int mode = args.dense ? 0 : (args.packed ? 1 : 2);
     if (mode == 2 && args.tree_splits != 1) return hipErrorInvalidValue;
     auto go = [&](auto kernel) {
