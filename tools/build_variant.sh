@@ -14,7 +14,7 @@ while [ $# -ge 2 ]; do
     shift; shift
 done
 cd "$TMP"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I"$ROOT/include" -I"$TMP" -x hip vsc_kernels.hip -x hip vsc_seed.hip \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $VARIANT_FLAGS -I"$ROOT/include" -I"$TMP" -x hip vsc_kernels.hip -x hip vsc_seed.hip \
     -x hip vsc_sort.hip -x hip vsc_api.cpp -x hip vsc_pack.cpp -x hip vsc_windows.cpp -x hip vsc_multi.cpp -pthread -ldl -shared \
     -o "$ROOT/varscot_amd/libvsc_$NAME.so"
 rm -rf "$TMP"

@@ -230,10 +230,11 @@ struct SeedArgs {
 // the moment it reaches one:
 //   bits 0..9 test | 10..18 right daughter, 19 right is terminal, 20 its vote | 21..29 left daughter, 30 terminal, 31 vote
 // (a terminal daughter's index bits are 0; the all-zero word is the SINK behind the last tree of a chain)
-constexpr int kRfRows = 256;             // feature rows per workgroup (one thread each)
+constexpr int kRfRows = 512;             // feature rows per workgroup (one thread each)
 constexpr int kRfMaxTests = 1024;        // distinct (predictor, threshold) pairs a forest may use
 constexpr int kRfMaxNodes = 1024;        // nodes of one tree (rfClassifier: 275)
-constexpr int kRfTileBytes = 12800;      // whole trees staged in LDS per step (with 7 KB of test bits: 8 workgroups per CU)
+constexpr int kRfTileBytes = 26624;      // whole trees staged in LDS per step (with 14 KB of test bits: 4 workgroups = 32 waves per CU)
+constexpr int kRfChains = 2;             // trees a thread walks at the same time (compact form)
 constexpr int kRfRowWords = 20;          // a row as the test extraction sees it: 16 packed words, 3 words of dinucleotide
                                          // counts (5 bits each, 6 / 6 / 4), 1 word activity rank
 // a test: field `width` bits at `shift` of row word `word` <= thr; dense rows read column `dense_col` instead

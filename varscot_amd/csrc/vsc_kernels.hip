@@ -981,10 +981,18 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
         block_sync();  // the previous tile (first round: the rows' words) is done with
         const uint32_t *src = a.nodes + (size_t)t0 * a.n_nodes;
         if (a.compact) {  // [trees of chain 0][sink][trees of chain 1][sink] - see below
-            const uint32_t cut = ((nt + 1) / 2) * a.n_nodes, total = nt * a.n_nodes;
-            for (uint32_t i = t; i < total; i += kRfRows) s_tile[i + (i >= cut ? 1u : 0u)] = src[i];
-            if (t == 0) s_tile[cut] = 0u;
-            if (t == 1) s_tile[total + 1u] = 0u;
+            // chain c's trees lie c words further on: a sink word follows every chain
+            const uint32_t per_nodes = ((nt + kRfChains - 1) / kRfChains) * a.n_nodes, total = nt * a.n_nodes;
+            for (uint32_t i = t; i < total; i += kRfRows) {
+                uint32_t c = 0;  // the chain word i belongs to (no division: a handful of compares)
+#pragma unroll
+                for (int k = 1; k < kRfChains; ++k) c += i >= (uint32_t)k * per_nodes ? 1u : 0u;
+                s_tile[i + c] = src[i];
+            }
+            if (t < (uint32_t)kRfChains) {
+                const uint32_t end = min((t + 1u) * per_nodes, total);  // words of the trees of chains 0 .. t
+                s_tile[end + t] = 0u;
+            }
         } else {
             for (uint32_t i = t; i < nt * a.n_nodes; i += kRfRows) s_tile[i] = src[i];
         }
@@ -994,26 +1002,35 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
             // idling until the deepest tree of the wave is through (the trees are 11 - 21 levels deep, a row's path 9
             // on average).  A node names, per daughter, either the daughter's index or "terminal, vote v" (index bits
             // zero), so terminal nodes are never read: reaching one adds the vote and moves the lane's tree base on by
-            // one tree, where index 0 is the next root.  Two chains per lane - the two halves of the tile - overlap their
-            // LDS latencies; behind the last tree of each half lies a SINK word (0 = test 0, both daughters "index 0,
+            // one tree, where index 0 is the next root.  kRfChains chains per lane - consecutive parts of the tile - overlap
+            // their LDS latencies (c5 batch, 256 rows: one chain 8.8 s, two 5.2 s, three 5.9 s; 512 rows and a 26 KB tile: 4.8 s); behind the last tree of each part lies a SINK word (0 = test 0, both daughters "index 0,
             // not terminal": it points at itself and votes nothing), so a finished chain spins without side effects
             // and the wave leaves when every lane's two nodes are sinks.  Straight-line code, no per-lane predicates.
-            //   tile layout: [trees of chain 0][sink][trees of chain 1][sink]
-            const uint32_t half = (nt + 1) / 2;
-            uint32_t base0 = 0, base1 = (half * a.n_nodes + 1u) * 4u;  // byte offsets of the lane's current trees
+            //   tile layout: [trees of chain 0][sink][trees of chain 1][sink] ...
+            const uint32_t per = (nt + kRfChains - 1) / kRfChains;  // trees per chain (the last chains may have fewer, or none)
             const char *const tile_b = (const char *)s_tile;
-            uint32_t n0 = s_tile[0], n1 = s_tile[half * a.n_nodes + 1u];
             const uint32_t tree_bytes = a.n_nodes * 4u;
-            while (__ballot((n0 | n1) != 0u)) {
-                const uint32_t w0 = bt[((n0 >> 5) & 31u) * kRfRows], w1 = bt[((n1 >> 5) & 31u) * kRfRows];
-                // x <= thr (bit set) takes the left daughter, filed at bits 21..31; else the right one at bits 10..20
-                const uint32_t c0 = __builtin_amdgcn_ubfe(n0, 10u + 11u * __builtin_amdgcn_ubfe(w0, n0, 1u), 11u);
-                const uint32_t c1 = __builtin_amdgcn_ubfe(n1, 10u + 11u * __builtin_amdgcn_ubfe(w1, n1, 1u), 11u);
-                ones += (c0 >> 10) + (c1 >> 10);                  // the vote bit is set for terminal daughters only
-                base0 += ((c0 >> 9) & 1u) * tree_bytes;           // terminal: on to the next tree (its root: index 0)
-                base1 += ((c1 >> 9) & 1u) * tree_bytes;
-                n0 = *(const uint32_t *)(tile_b + base0 + (c0 & 511u) * 4u);
-                n1 = *(const uint32_t *)(tile_b + base1 + (c1 & 511u) * 4u);
+            uint32_t base[kRfChains], n[kRfChains];
+            uint32_t any = 0;
+#pragma unroll
+            for (int c = 0; c < kRfChains; ++c) {
+                const uint32_t first = min((uint32_t)c * per, nt);  // chain c walks trees [first, min(first + per, nt))
+                base[c] = (first * a.n_nodes + (uint32_t)c) * 4u;   // (c sink words lie in front of it)
+                n[c] = *(const uint32_t *)(tile_b + base[c]);
+                any |= n[c];
+            }
+            while (__ballot(any != 0u)) {
+                any = 0;
+#pragma unroll
+                for (int c = 0; c < kRfChains; ++c) {
+                    const uint32_t w = bt[((n[c] >> 5) & 31u) * kRfRows];
+                    // x <= thr (bit set) takes the left daughter, filed at bits 21..31; else the right one at bits 10..20
+                    const uint32_t d = __builtin_amdgcn_ubfe(n[c], 10u + 11u * __builtin_amdgcn_ubfe(w, n[c], 1u), 11u);
+                    ones += d >> 10;                               // the vote bit is set for terminal daughters only
+                    base[c] += ((d >> 9) & 1u) * tree_bytes;       // terminal: on to the next tree (its root: index 0)
+                    n[c] = *(const uint32_t *)(tile_b + base[c] + (d & 511u) * 4u);
+                    any |= n[c];
+                }
             }
             continue;
         }
@@ -1053,7 +1070,7 @@ hipError_t launch_rf_predict(const RfArgs &args, hipStream_t stream)
     const uint64_t tiles = (args.n + kRfRows - 1) / kRfRows;
     if (tiles >= (1ull << 31)) return hipErrorInvalidValue;
     const size_t n_words = (args.n_tests + 31) / 32;
-    const size_t lds = n_words * kRfRows * sizeof(uint32_t) + (size_t)kRfTileBytes + 8;  // test bits + the tree tile (+ two sink words)
+    const size_t lds = n_words * kRfRows * sizeof(uint32_t) + (size_t)kRfTileBytes + 4 * kRfChains;  // test bits + the tree tile (+ a sink word per chain)
     const int mode = args.dense ? 0 : (args.packed ? 1 : 2);
     if (mode == 2 && args.tree_splits != 1) return hipErrorInvalidValue;
     auto go = [&](auto kernel) {
