@@ -321,6 +321,29 @@ def test_sam_write_order_equals_the_reference_rows_on_the_guideseq_sites(ctx, or
     assert [i for i in ours if i not in held] == [i for i in theirs if i not in held] and len(ours) - len(held) > 300
 
 
+def test_release_scratch_between_searches(ctx, oracle):
+    """vsc_ctx_release_scratch gives the pooled buffers back (the next search allocates again) without touching the
+    resident genome, its seed index or a live result."""
+    rng = np.random.default_rng(99)
+    guides = random_guides(rng, 30)
+    contigs = make_genome(99, [80000, 30000], guides, 7, n_plant=400, n_runs=2)
+    want = oracle.search_fast(contigs, guides, 7)
+    gen = ctx.load_genome(va.PackedGenome.from_sequences(contigs))
+    live = gen.search(guides, 7, algorithm="seed")
+    before = gen.device_bytes
+    ctx.release_scratch()
+    assert gen.device_bytes == before and live.to_numpy().tobytes() == want.tobytes()
+    again = gen.search(guides, 7, algorithm="seed")
+    assert again.to_numpy().tobytes() == want.tobytes()
+    mit, _, _ = again.scores(mit=True)
+    ctx.release_scratch()
+    mit2, _, _ = live.scores(mit=True)
+    assert np.array_equal(mit, mit2)
+    live.close()
+    again.close()
+    gen.close()
+
+
 # ------------------------------------------------------------------------------------ multi-rank
 def _rank_worker(rank, world, port, q, exchange="root"):
     import traceback
