@@ -60,14 +60,18 @@ def test_search_matches_oracle(ctx, oracle, seed, max_mm, extra_pam, algo):
     assert hits_as_tuples(got) == hits_as_tuples(want)  # same records in the same (sorted) order
 
 
-@pytest.mark.parametrize("shared", [0, 1])
+@pytest.mark.parametrize("shared", [0, 1, 2])
 @pytest.mark.parametrize("seed,max_mm,n_reads", [(201, 8, 300), (202, 6, 40), (203, 2, 7), (204, 7, 1500)])
 def test_seed_search_with_a_chunk_per_wave_and_per_workgroup(ctx, oracle, hooks, shared, seed, max_mm, n_reads):
     """seed_sliced_kernel<false> (every wave its own chunks) and <true> (the four waves of a workgroup share a chunk
     and take a quarter of its read list each: what dense searches like c3 run) return the oracle's records - forced
     either way by the hook, on read sets from 7 (most quarters empty) to 1 500 reads (lists of several tiles), with
-    planted sites, N runs, tiny contigs and contig-end windows."""
-    hooks(seed_shared=shared)
+    planted sites, N runs, tiny contigs and contig-end windows.  shared = 2: the sharing kernel with the workgroup's
+    output blocks shared as well (hook seed_group_out; small blocks so that the cross-wave reservation path runs often)."""
+    if shared == 2:
+        hooks(seed_shared=1, seed_group_out=1, seed_reserve=64)
+    else:
+        hooks(seed_shared=shared)
     rng = np.random.default_rng(seed)
     guides = random_guides(rng, n_reads)
     contigs = make_genome(seed, [70000, 23, 9000, 30000, 64], guides[:60], max_mm, n_plant=400, n_runs=5)

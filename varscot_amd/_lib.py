@@ -61,7 +61,7 @@ class DebugParams(C.Structure):
                 ("sort_max_bits", C.c_uint32), ("sort_xcd", C.c_int32), ("sort_debug", C.c_uint32),
                 ("sort_optimistic", C.c_int32), ("sort_slot_cap", C.c_uint32), ("score_chunk", C.c_uint64),
                 ("score_slices", C.c_int32), ("score_slice_shift", C.c_uint32), ("seed_shared", C.c_int32),
-                ("reserved", C.c_uint32 * 4)]
+                ("seed_group_out", C.c_int32), ("reserved", C.c_uint32 * 3)]
     SIGNED_DEFAULT = ("sort_xcd", "sort_optimistic", "score_slices", "seed_shared")
 
     @classmethod

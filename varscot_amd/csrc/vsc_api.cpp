@@ -1151,8 +1151,12 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         // block of records a wave reserves per atomic and region (a power of two, 64 .. 1024): large when many hits
         // are expected, small otherwise (the unused tail of every wave's last block is written as sentinels
         // and read by the sort)
-        const uint64_t per_wave = cap / ((uint64_t)n_groups * kWavesPerGroup * 8 * n_parts);
-        uint32_t want_reserve = (uint32_t)std::min<uint64_t>(n_parts > 8 ? 128 : 1024, std::max<uint64_t>(kWave, per_wave));
+        // (hook seed_group_out: the four waves of a workgroup share their open blocks - four times the block for the same
+        // padding; chunk-sharing kernel only)
+        sa.group_out = seed_shared && ctx->dbg.seed_group_out == 1 ? 1u : 0u;
+        const uint32_t owners = sa.group_out ? (uint32_t)n_groups : (uint32_t)n_groups * kWavesPerGroup;  // open blocks per region
+        const uint64_t per_wave = cap / ((uint64_t)owners * 8 * n_parts);
+        uint32_t want_reserve = (uint32_t)std::min<uint64_t>(n_parts > 8 ? (sa.group_out ? 512 : 128) : 1024, std::max<uint64_t>(kWave, per_wave));
         if (ctx->dbg.seed_reserve) want_reserve = std::min<uint32_t>(1024, std::max<uint32_t>(kWave, ctx->dbg.seed_reserve));
         sa.reserve_log2 = 6;
         while ((2u << sa.reserve_log2) <= want_reserve) ++sa.reserve_log2;
@@ -1162,14 +1166,14 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         // a region gets its share of the expected hits + 15 % (read ranges differ) + the open blocks
         part_cap = cap / n_parts + cap / n_parts / 7 + 4096;
         part_cap = std::max<uint64_t>(part_cap, (uint64_t)(1.2 * seen_rate * std::min<uint32_t>(n_guides, kRegionReads)) + 4096);
-        part_cap += (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
+        part_cap += (uint64_t)owners * sa.reserve;
         cap = part_cap * n_parts;
     }
 
     ht.lap("prep enqueue");
     for (unsigned tries = 0;; ++tries) {
-        // (the kernel keeps a block number in 21 bits: part_cap / reserve < 2^21)
-        if (algo == VSC_ALGO_SEED && (part_cap >= (1ull << 32) - (1u << 20) || part_cap >= ((uint64_t)sa.reserve << 21)))
+        // (the kernel keeps a block number in 20 bits, all ones meaning "full": part_cap / reserve < 2^20 - 1)
+        if (algo == VSC_ALGO_SEED && (part_cap >= (1ull << 32) - (1u << 20) || part_cap >= ((uint64_t)sa.reserve << 20) - sa.reserve))
             return fail(ctx, VSC_ERR_RANGE, "vsc_search: more than 2^32 hits in a block of 64 reads");
         VSC_HIP_H(ctx->keys_a.ensure(cap * sizeof(uint64_t)));
         VSC_HIP_H(hipMemsetAsync(ctx->counters.p, 0, kCounterWords * sizeof(unsigned long long), ctx->stream));
@@ -1196,7 +1200,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         if (algo == VSC_ALGO_SEED) {
             uint64_t need = 0;
             for (int q = 0; q < n_parts; ++q) need = std::max<uint64_t>(need, cnt[kCntPart + 4 * q] + cnt[kCntPart + 4 * q + 2]);
-            part_cap = need + (need >> 6) + 4096 + (uint64_t)n_groups * kWavesPerGroup * sa.reserve;
+            part_cap = need + (need >> 6) + 4096 + (uint64_t)(sa.group_out ? n_groups : n_groups * kWavesPerGroup) * sa.reserve;
             cap = part_cap * n_parts;
         } else {
             cap = cnt[kCntHits] + (cnt[kCntHits] >> 6) + 4096;

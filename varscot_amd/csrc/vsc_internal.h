@@ -208,6 +208,7 @@ struct SeedArgs {
     const uint32_t *contig_end;
     uint32_t n_contigs;
     uint64_t *hit_recs;            // out: packed records (layout above), region p = [p * part_cap, (p + 1) * part_cap)
+    uint32_t group_out;            // 1: the four waves of a workgroup share their open blocks (chunk-sharing kernel only)
     uint32_t reserve;              // records a wave reserves per atomic on its region's cursor: a power of two, 64 .. 1024
     uint32_t reserve_log2;
     uint32_t pos_pad;              // left shift of the position field of a record

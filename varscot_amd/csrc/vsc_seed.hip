@@ -443,8 +443,13 @@ struct SlicedFetch {
 // LDS atomic on its region's word and stores straight from registers; nothing in the common path depends on
 // how many regions a pass touches.  Only when a block is used up (once per `reserve` hits of a region) do the
 // lanes that found it full take the wave-uniform path that reserves the next block.
+// State word of an open block: records claimed (11 bits) | BUSY (group-shared blocks: a wave is reserving the next
+// block) | block number (20 bits; all ones: the region is full).
 constexpr uint32_t kPartUsedBits = 11;
 constexpr uint32_t kPartUsedMask = (1u << kPartUsedBits) - 1u;
+constexpr uint32_t kPartBusy = 1u << kPartUsedBits;
+constexpr uint32_t kPartBlockShift = kPartUsedBits + 1;
+constexpr uint32_t kPartDeadBlock = 0xFFFFFu;
 
 // Reserves a new block in region p (wave-uniform).  Returns false when the region is full: the host
 // re-runs with room for reserved + lost records in every region.
@@ -466,6 +471,65 @@ __device__ __forceinline__ bool sliced_reserve(const SeedArgs &a, const SeedWave
     return true;
 }
 
+// Group-shared open blocks (SeedArgs.group_out; with chunk sharing only): the four waves of a workgroup fill ONE open
+// block per region - a quarter of the partly written lines in flight and of the sentinels at the end, blocks four times
+// as large for the same padding (fewer reservations).  The slow path serialises per region on the BUSY bit: the wave
+// that finds the block full and not busy sets BUSY (LDS compare-and-swap), reserves the next block (global atomic) and
+// installs it with a plain LDS store that clears BUSY; a wave that finds BUSY waits (s_sleep, bounded) and then claims
+// again.  A wave holds BUSY only across its own reservation, so nobody waits on a waiter.
+__device__ __forceinline__ void sliced_store_group_slow(const SeedArgs &a, SeedWave &w, uint32_t p, bool mine, uint64_t rec)
+{
+    volatile uint32_t *const word = &w.parts[p];
+    for (uint32_t spins = 0;;) {
+        uint32_t s = 0;
+        if (w.lane == 0) s = *word;
+        s = uniform(s);
+        const uint32_t used = s & kPartUsedMask;
+        if ((s >> kPartBlockShift) == kPartDeadBlock) {
+            // the region is full: these hits are lost, the host re-runs with more room (and the claim counter starts again)
+            const uint64_t b = __ballot(mine);
+            if (w.lane == 0) {
+                atomicAdd(&a.counters[kCntPart + 4 * p + 2], (unsigned long long)__popcll(b));
+                *word = (kPartDeadBlock << kPartBlockShift) | a.reserve;
+            }
+            return;
+        }
+        if (!(s & kPartBusy) && used < a.reserve) {
+            // somebody installed a block with room: claim again
+            uint32_t st = kPartUsedMask;
+            if (mine) st = atomicAdd(&w.parts[p], 1u);
+            const bool ok = mine && (st & kPartUsedMask) < a.reserve;
+            if (ok) a.hit_recs[(unsigned long long)p * (uint32_t)a.part_cap + (((st >> kPartBlockShift) << a.reserve_log2) + (st & kPartUsedMask))] = rec;
+            mine = mine && !ok;
+            if (__ballot(mine) == 0) return;
+            continue;
+        }
+        if (s & kPartBusy) {
+            if (++spins > (1u << 20)) {  // (never seen; a safety net instead of a hang: counted as lost, the host re-runs)
+                const uint64_t b = __ballot(mine);
+                if (w.lane == 0) {
+                    atomicAdd(&a.counters[kCntPart + 4 * p + 2], (unsigned long long)__popcll(b));
+                    atomicMax(&a.counters[kCntOverflow], 1ull);
+                }
+                return;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        // full and nobody is reserving: this wave does, if it wins the compare-and-swap
+        uint32_t won = 0;
+        if (w.lane == 0) won = atomicCAS(&w.parts[p], s, s | kPartBusy) == s ? 1u : 0u;
+        if (!uniform(won)) continue;
+        const uint64_t b = __ballot(mine);
+        const uint32_t n = (uint32_t)__popcll(b);
+        uint32_t next = 0;
+        const bool ok = sliced_reserve(a, w, p, n, next);
+        if (mine && ok) a.hit_recs[(unsigned long long)p * a.part_cap + next + lanes_below(b)] = rec;
+        if (w.lane == 0) *word = ok ? ((next >> a.reserve_log2) << kPartBlockShift) | n : (kPartDeadBlock << kPartBlockShift) | a.reserve;
+        return;
+    }
+}
+
 // lanes with `hit` store their record in the region of their read
 __device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, bool hit, uint32_t region, uint64_t rec)
 {
@@ -474,30 +538,36 @@ __device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, boo
     const uint32_t slot = state & kPartUsedMask;
     const bool placed = hit && slot < a.reserve;
     // (part_cap < 2^32 - the host checks - so the slot index is one 32 x 32 -> 64-bit multiply-add)
-    if (placed) a.hit_recs[(unsigned long long)region * (uint32_t)a.part_cap + (((state >> kPartUsedBits) << a.reserve_log2) + slot)] = rec;
+    if (placed) a.hit_recs[(unsigned long long)region * (uint32_t)a.part_cap + (((state >> kPartBlockShift) << a.reserve_log2) + slot)] = rec;
     uint64_t todo = __ballot(hit && !placed);
     while (todo != 0) {
         const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)region, (int)__builtin_ctzll(todo));
         const bool mine = hit && !placed && region == p;
         const uint64_t b = __ballot(mine);
-        const uint32_t n = (uint32_t)__popcll(b);
-        uint32_t next = 0;
-        const bool ok = sliced_reserve(a, w, p, n, next);
-        if (mine && ok) a.hit_recs[(unsigned long long)p * a.part_cap + next + lanes_below(b)] = rec;
-        // (a region that is full keeps a "used up" block: later hits come here again and are counted as lost)
-        if (w.lane == 0) w.parts[p] = ok ? ((next >> a.reserve_log2) << kPartUsedBits) | n : a.reserve;
+        if (a.group_out) {
+            sliced_store_group_slow(a, w, p, mine, rec);
+        } else {
+            const uint32_t n = (uint32_t)__popcll(b);
+            uint32_t next = 0;
+            const bool ok = sliced_reserve(a, w, p, n, next);
+            if (mine && ok) a.hit_recs[(unsigned long long)p * a.part_cap + next + lanes_below(b)] = rec;
+            // (a region that is full keeps a "used up" block: later hits come here again and are counted as lost)
+            if (w.lane == 0) w.parts[p] = ok ? ((next >> a.reserve_log2) << kPartBlockShift) | n : a.reserve;
+        }
         wave_sync();
         todo &= ~b;
     }
 }
 
-// end of the kernel: the open blocks are filled up with sentinels, which the sort drops
-__device__ __forceinline__ void sliced_finish_hits(const SeedArgs &a, SeedWave &w)
+// end of the kernel: the open blocks are filled up with sentinels, which the sort drops (group-shared blocks: behind
+// the workgroup's last barrier, region q by wave q mod 4)
+__device__ __forceinline__ void sliced_finish_hits(const SeedArgs &a, SeedWave &w, uint32_t first, uint32_t step)
 {
     wave_sync();
-    for (uint32_t q = 0; q < a.n_parts; ++q) {
+    for (uint32_t q = first; q < a.n_parts; q += step) {
         const uint32_t state = uniform(w.parts[q]);
-        const uint32_t base = (state >> kPartUsedBits) << a.reserve_log2, used = state & kPartUsedMask;
+        if ((state >> kPartBlockShift) == kPartDeadBlock) continue;
+        const uint32_t base = (state >> kPartBlockShift) << a.reserve_log2, used = state & kPartUsedMask;
         const uint32_t left = used < a.reserve ? a.reserve - used : 0u;
         for (uint32_t i = w.lane; i < left; i += kWave) a.hit_recs[(unsigned long long)q * a.part_cap + base + used + i] = kRecSentinel;
         if (w.lane == 0 && left) atomicAdd(&a.counters[kCntPart + 4 * q + 1], (unsigned long long)left);
@@ -662,7 +732,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     w.tok = s_tok[wave];
     w.ntok = 0;
     w.thead = 0;
-    w.parts = s_parts[wave];
+    w.parts = s_parts[kShared && a.group_out ? 0u : wave];  // (group-shared blocks: first used behind the first grab's barrier)
     w.first = s_first[wave];
     w.info = s_first[wave] + kSlicedGrab;
     for (uint32_t q = w.lane; q < (uint32_t)kParts; q += kWave) w.parts[q] = a.reserve;  // no block yet = a used-up one
@@ -793,7 +863,12 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
         }
         if (w.ntok) sliced_resolve<true>(a, w);  // the tokens name chunks of this grab: all out before the next
     }
-    sliced_finish_hits(a, w);
+    if (kShared && a.group_out) {
+        block_sync();  // (the four waves leave the loop together: every store into the shared blocks is issued)
+        sliced_finish_hits(a, w, wave_u, kWavesPerGroup);
+    } else {
+        sliced_finish_hits(a, w, 0, 1);
+    }
     if (w.lane == 0 && pairs) {
         atomicAdd(&a.counters[kCntSites], pairs);
         atomicAdd(&a.counters[kCntVisited], visited);
