@@ -30,7 +30,7 @@ typedef struct {
     int32_t score_slices;        /* -1 default; 0 / 1: slice-major scoring order off / forced */
     uint32_t score_slice_shift;  /* log2 positions per slice (8 .. 31) */
     int32_t seed_shared;         /* -1 default; 0 / 1: one chunk per wave / one chunk per workgroup in seed_sliced_kernel */
-    int32_t seed_group_out;      /* 1: the four waves of a workgroup share their open output blocks (experiment; default off) */
+    int32_t seed_group_out;      /* -1 default (on with chunk sharing); 0 / 1: per-wave / workgroup-shared open output blocks */
     uint32_t reserved[3];
 } vsc_debug_params;
 

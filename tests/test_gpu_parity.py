@@ -67,7 +67,7 @@ def test_seed_search_with_a_chunk_per_wave_and_per_workgroup(ctx, oracle, hooks,
     and take a quarter of its read list each: what dense searches like c3 run) return the oracle's records - forced
     either way by the hook, on read sets from 7 (most quarters empty) to 1 500 reads (lists of several tiles), with
     planted sites, N runs, tiny contigs and contig-end windows.  shared = 2: the sharing kernel with the workgroup's
-    output blocks shared as well (hook seed_group_out; small blocks so that the cross-wave reservation path runs often)."""
+    output blocks shared as well (small blocks so that the cross-wave reservation path runs often)."""
     if shared == 2:
         hooks(seed_shared=1, seed_group_out=1, seed_reserve=64)
     else:
@@ -732,12 +732,14 @@ def test_sort_without_the_histogram_pass_and_its_fallback(ctx, oracle, hooks):
     gen.close()
 
 
-@pytest.mark.parametrize("cap", [None, 512])
+@pytest.mark.parametrize("cap", [None, 512, "group"])
 def test_hit_buffer_growth_and_sort_partition(ctx, oracle, cap, hooks):
     """Thousands of hits per read on a small genome: the hit buffer sized from the uniform-genome model has to
     grow (second search launch), the second search reuses the grown buffers; with a reduced bin capacity the
     region goes through the partition level.  A read count that is not a multiple of four."""
-    if cap:
+    if cap == "group":  # the chunk-sharing kernel with workgroup-shared output blocks: regions that fill up, re-run
+        hooks(seed_shared=1, seed_group_out=1)
+    elif cap:
         hooks(sort_cap=cap)
     rng = np.random.default_rng(909)
     guides = random_guides(rng, 37)

@@ -1151,12 +1151,13 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         // block of records a wave reserves per atomic and region (a power of two, 64 .. 1024): large when many hits
         // are expected, small otherwise (the unused tail of every wave's last block is written as sentinels
         // and read by the sort)
-        // (hook seed_group_out: the four waves of a workgroup share their open blocks - four times the block for the same
-        // padding; chunk-sharing kernel only)
-        sa.group_out = seed_shared && ctx->dbg.seed_group_out == 1 ? 1u : 0u;
+        // with chunk sharing the four waves of a workgroup also share their open output blocks: a quarter of the open
+        // lines and of the padding, so the blocks can be eight times as large (c3: per-wave blocks of 128 records 40.6 ms
+        // per step, group blocks of 512 39.3, of 1 024 39.0 - tools/exp_group_out.sh; hook seed_group_out = 0 switches it off)
+        sa.group_out = seed_shared && ctx->dbg.seed_group_out != 0 ? 1u : 0u;
         const uint32_t owners = sa.group_out ? (uint32_t)n_groups : (uint32_t)n_groups * kWavesPerGroup;  // open blocks per region
         const uint64_t per_wave = cap / ((uint64_t)owners * 8 * n_parts);
-        uint32_t want_reserve = (uint32_t)std::min<uint64_t>(n_parts > 8 ? (sa.group_out ? 512 : 128) : 1024, std::max<uint64_t>(kWave, per_wave));
+        uint32_t want_reserve = (uint32_t)std::min<uint64_t>(n_parts > 8 ? (sa.group_out ? 1024 : 128) : 1024, std::max<uint64_t>(kWave, per_wave));
         if (ctx->dbg.seed_reserve) want_reserve = std::min<uint32_t>(1024, std::max<uint32_t>(kWave, ctx->dbg.seed_reserve));
         sa.reserve_log2 = 6;
         while ((2u << sa.reserve_log2) <= want_reserve) ++sa.reserve_log2;

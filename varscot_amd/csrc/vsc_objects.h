@@ -46,6 +46,7 @@ inline vsc_debug_params default_debug_params()
     d.sort_optimistic = -1;
     d.score_slices = -1;
     d.seed_shared = -1;
+    d.seed_group_out = -1;
     return d;
 }
 
