@@ -31,7 +31,7 @@ done
 # bench lines of the other workloads (no profiling)
 timeout -k 10 500 python3 $ROOT/bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err" || true
 timeout -k 10 500 python3 $ROOT/bench.py --workload c5 --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err" || true
-timeout -k 10 500 python3 $ROOT/bench.py --workload c5 --steps 1 --warmup 0 --no-cpu-baseline --classify > "$OUT/bench_c5_classify.json" 2> "$OUT/bench_c5_classify.err" || true
+timeout -k 10 500 python3 $ROOT/bench.py --workload c5 --steps 1 --warmup 1 --no-cpu-baseline --classify > "$OUT/bench_c5_classify.json" 2> "$OUT/bench_c5_classify.err" || true
 timeout -k 10 500 python3 $ROOT/bench.py --workload c3 --steps 3 --warmup 1 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || true
 find "$OUT" -name '*kernel_trace.csv' -delete
 du -sh "$OUT"
