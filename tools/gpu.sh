@@ -8,6 +8,7 @@
 #   gpurun -- 'bash tools/gpu.sh stats c3'                                      rocprofv3 --kernel-trace --stats
 #   gpurun -- 'bash tools/gpu.sh pmc c3 "FETCH_SIZE" ["kernel name parts" [bench.py args]]'   one counter group, one pass
 #   gpurun -- 'bash tools/gpu.sh collect r03'                                   tools/collect_profiles.sh
+#   gpurun --timeout 1150 -- 'bash tools/gpu.sh final'                          smoke + GPU suite + default bench line
 #   gpurun -- 'bash tools/gpu.sh bw'                                            fill / read / copy rates of the part
 # TAG (environment) names the directory under gpurun_out/ (default: the subcommand).  Steps are joined so that a
 # step that was killed starts no further GPU step.
@@ -66,6 +67,13 @@ PY
     ;;
 collect)
     bash tools/collect_profiles.sh "${1:-r03}";;
+final)
+    # what the driver runs at the end of a round, in one go: smoke, the GPU suite, the default bench line
+    python3 -c "import __graft_entry__ as g; g.smoke()" || exit 1
+    timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1 || { tail -5 "$OUT/pytest.log"; exit 1; }
+    tail -2 "$OUT/pytest.log"
+    timeout -k 10 300 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || { tail -5 "$OUT/bench_default.err"; exit 1; }
+    line "$OUT/bench_default.json";;
 bw)
     timeout -k 10 300 python3 - <<'PY'
 import torch

@@ -1141,7 +1141,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         if (ctx->dbg.seed_groups_per_cu) groups_per_cu = ctx->dbg.seed_groups_per_cu;
         // dense searches (c3: 129 reads per bucket) share a chunk between the four waves of a workgroup, sparse ones
         // (c2: 13) keep a chunk per wave - see seed_sliced_kernel.  Measured at <= 8 mismatches (tools/
-        // exp_shared_threshold.sh): 51 reads per bucket 12.1 vs 11.4 ms, 77: 15.9 vs 16.0, 103: 19.9 vs 20.7
+        // experiments.sh shared-threshold): 51 reads per bucket 12.1 vs 11.4 ms, 77: 15.9 vs 16.0, 103: 19.9 vs 20.7
         seed_shared = n_pairs / kBuckets >= 72;
         if (ctx->dbg.seed_shared >= 0) seed_shared = ctx->dbg.seed_shared == 1;
         const uint32_t n_grabs = (sa.n_chunks + kSlicedGrab - 1) / kSlicedGrab;
@@ -1153,7 +1153,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         // and read by the sort)
         // with chunk sharing the four waves of a workgroup also share their open output blocks: a quarter of the open
         // lines and of the padding, so the blocks can be eight times as large (c3: per-wave blocks of 128 records 40.6 ms
-        // per step, group blocks of 512 39.3, of 1 024 39.0 - tools/exp_group_out.sh; hook seed_group_out = 0 switches it off)
+        // per step, group blocks of 512 39.3, of 1 024 39.0 - tools/experiments.sh group-out; hook seed_group_out = 0 switches it off)
         sa.group_out = seed_shared && ctx->dbg.seed_group_out != 0 ? 1u : 0u;
         const uint32_t owners = sa.group_out ? (uint32_t)n_groups : (uint32_t)n_groups * kWavesPerGroup;  // open blocks per region
         const uint64_t per_wave = cap / ((uint64_t)owners * 8 * n_parts);

@@ -714,7 +714,7 @@ static_assert(kMaxPassReads <= (1 << kTokSlotShift) && kSlicedGrab <= 8 && kTokS
 // resident site records (16 KB per chunk, gathered 8 bytes per hit) then are a working set of one chunk per
 // workgroup instead of one per wave - 3 MB per XCD instead of 12 - which is what its 4 MB L2 can hold: with a chunk
 // per wave every gather of a hit fetched its line from the fabric again (FETCH_SIZE 65 GB per c3 search; 17 GB with
-// one workgroup per CU resident, tools/exp_groups.sh).  For sparse searches (c2: 13 reads per bucket) a chunk visit
+// one workgroup per CU resident, tools/experiments.sh groups).  For sparse searches (c2: 13 reads per bucket) a chunk visit
 // is mostly the load of its bit-sliced block, which every sharing wave repeats: those keep a chunk per wave.
 template <bool kShared>
 __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(kSlicedWavesPerSimd, kSlicedWavesPerSimd))) void seed_sliced_kernel(
