@@ -31,7 +31,8 @@ typedef struct {
     uint32_t score_slice_shift;  /* log2 positions per slice (8 .. 31) */
     int32_t seed_shared;         /* -1 default; 0 / 1: one chunk per wave / one chunk per workgroup in seed_sliced_kernel */
     int32_t seed_group_out;      /* -1 default (on with chunk sharing); 0 / 1: per-wave / workgroup-shared open output blocks */
-    uint32_t reserved[3];
+    int32_t seed_pam21;          /* -1 default (on when every PAM of the index starts with the same letter); 0: the general comparison */
+    uint32_t reserved[2];
 } vsc_debug_params;
 
 /* Replaces the context's hooks (NULL: back to the defaults). */

@@ -81,6 +81,31 @@ def test_seed_search_with_a_chunk_per_wave_and_per_workgroup(ctx, oracle, hooks,
     assert got.tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("pam21", [-1, 0])
+@pytest.mark.parametrize("shared", [0, 1])
+@pytest.mark.parametrize("seed,max_mm,extra_pam", [(301, 8, None), (302, 5, None), (303, 1, None), (304, 0, None),
+                                                   (305, 6, "GT"), (306, 6, "AG")])
+def test_seed_search_reads_that_mismatch_the_first_pam_letter(ctx, oracle, hooks, pam21, shared, seed, max_mm, extra_pam):
+    """Every site of an index built for GG / GA (or with an extra PAM that also starts with G) has G at read position 21,
+    so the sliced comparison leaves that position out and takes the read's mismatch there from its budget
+    (sliced_within<true>).  Reads with A, C, T and G at position 21 (and any letter at 22), sites planted at every
+    distance up to the limit: the records are the oracle's, with the shortcut (default), without it (hook) and for an
+    index whose extra PAM starts with another letter (the general comparison by itself)."""
+    hooks(seed_shared=shared, seed_pam21=pam21)
+    rng = np.random.default_rng(seed)
+    guides = [random_seq(rng, 21) + p for p in ("AG", "CG", "TG", "GG", "GA", "AA", "TC", "CT", "GT", "AG", "GG", "TA") for _ in range(6)]
+    contigs = make_genome(seed, [60000, 23, 25000, 64], guides[::3], max_mm, n_plant=500, n_runs=4)
+    want = oracle.search(contigs, guides, max_mm, extra_pam, mode=oracle.MODE_PREDICATE)
+    got = gpu_search(ctx, contigs, guides, max_mm, extra_pam, algo="seed")
+    by_pam = {g[21:]: 0 for g in guides}
+    for r in want:
+        by_pam[guides[r["guide"]][21:]] += 1
+    if max_mm >= 5:
+        assert min(by_pam[p] for p in ("AG", "CG", "TG", "GG")) > 0  # reads that mismatch at 21 have hits too
+    assert len(want) > (0 if max_mm == 0 else 20)
+    assert hits_as_tuples(got) == hits_as_tuples(want)
+
+
 def test_search_matches_reference_flow_order(ctx, oracle):
     """SAM emission order + secondary flags (bidir_mapping.cpp:167-187) from the sorted GPU result."""
     rng = np.random.default_rng(7)

@@ -1120,7 +1120,13 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         VSC_HIP_H(ctx->seed_poff.ensure((kBuckets + 1) * sizeof(uint32_t)));
         VSC_HIP_H(ctx->seed_lrest.ensure(list_cap * sizeof(uint4)));
         VSC_HIP_H(hipMemsetAsync(ctx->seed_lrest.p, 0xFF, list_cap * sizeof(uint4), ctx->stream));  // padding: y = ~0, skipped
-        VSC_HIP_H(launch_seed_lists((const uint2 *)ctx->guides.p, n_guides, n_nbr, (uint32_t *)ctx->seed_off.p,
+        // GG and GA start with the same letter, and so does the index unless -P added a PAM that starts differently:
+        // read position 21 then needs no per-site comparison - the read lists take a mismatch there out of the
+        // budget of their entries (seed_enum_kernel, sliced_within)
+        sa.pam21 = 2u;
+        if (genome->index_has_extra_pam && base_code(genome->index_extra_pam[0]) != 2) sa.pam21 = 4u;
+        if (ctx->dbg.seed_pam21 == 0) sa.pam21 = 4u;
+        VSC_HIP_H(launch_seed_lists((const uint2 *)ctx->guides.p, n_guides, n_nbr, params->max_mismatches, sa.pam21, (uint32_t *)ctx->seed_off.p,
                                     (uint32_t *)ctx->seed_poff.p, (uint4 *)ctx->seed_lrest.p, ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
         sa.chunk_tab = genome->d_ix_chunk_tab;

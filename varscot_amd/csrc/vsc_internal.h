@@ -34,7 +34,7 @@ constexpr int kSeedHitCap = 256;                // smallest block of records a w
 constexpr int kSlicedSites = 32;                // sites per lane of the bit-sliced comparison (one bit each)
 constexpr int kSlicedChunk = kWave * kSlicedSites;  // 2048 sites per wave and chunk
 constexpr int kRestBases = VSC_READ_LEN - kSegBases;  // 16 read positions outside the seed segment
-constexpr int kListDistShift = 30;              // list entry y: read index | seed distance << 30
+constexpr int kListBudgetShift = 28;            // list entry y: read index | mismatches left for the rest positions << 28
 constexpr int kTokLaneShift = 26;               // sliced hit token, high word: read of the pass (14 bits) | chunk slot << 14 | lane << 26
 constexpr int kTokSlotShift = 14;
 constexpr uint32_t kTokReadMask = (1u << kTokSlotShift) - 1u;
@@ -198,7 +198,7 @@ struct ScoreArgs {
 struct SeedArgs {
     const uint4 *chunk_tab;        // [n_chunks] {first site, site count, bucket | first '-' rank << 16 | edge << 28, first vertical block}
     const uint32_t *vert;          // bit-sliced copies of the sites: 32 words per block of 32 sites (see seed_transpose_kernel)
-    const uint4 *list_rest;        // per list entry {rest(hi) | rest(lo) << 16, read | distance << 30, hi, lo}
+    const uint4 *list_rest;        // per list entry {rest(hi) | rest(lo) << 16, read | budget << 28, hi, lo}
     const uint2 *sites;            // {rest(hi) | rest(lo) << 16, position} per site
     const uint32_t *edge_bits;     // 1 bit per site: its window is followed by N
     const uint2 *guides;           // (hi plane, lo plane) per read
@@ -209,6 +209,7 @@ struct SeedArgs {
     uint32_t n_contigs;
     uint64_t *hit_recs;            // out: packed records (layout above), region p = [p * part_cap, (p + 1) * part_cap)
     uint32_t group_out;            // 1: the four waves of a workgroup share their open blocks (chunk-sharing kernel only)
+    uint32_t pam21;                // base code every site has at read position 21 (first PAM letter), or >= 4: not all the same
     uint32_t reserve;              // records a wave reserves per atomic on its region's cursor: a power of two, 64 .. 1024
     uint32_t reserve_log2;
     uint32_t pos_pad;              // left shift of the position field of a record
@@ -300,8 +301,8 @@ hipError_t launch_sort32(void *temp, size_t temp_bytes, const uint32_t *keys_in,
 hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint32_t *keys, uint32_t *idx, hipStream_t stream);
 hipError_t launch_lower_bound(const uint32_t *sorted_keys, uint64_t n, uint32_t n_buckets, uint32_t key_offset,
                               uint32_t base, uint32_t *out, hipStream_t stream);
-hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *count, uint32_t *poff,
-                             uint4 *list_rest, hipStream_t stream);
+hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t max_mm, uint32_t pam21, uint32_t *count,
+                             uint32_t *poff, uint4 *list_rest, hipStream_t stream);
 hipError_t launch_seed_pack16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, uint64_t n, uint4 *rec, hipStream_t stream);
 hipError_t launch_seed_gather16(const uint4 *rec, const uint32_t *idx, uint64_t n, uint4 *out, hipStream_t stream);
 hipError_t launch_seed_compact(const uint4 *sites16, uint64_t n_per_table, uint64_t n, uint2 *sites8, uint32_t *edge_bits,

@@ -47,6 +47,7 @@ inline vsc_debug_params default_debug_params()
     d.score_slices = -1;
     d.seed_shared = -1;
     d.seed_group_out = -1;
+    d.seed_pam21 = -1;
     return d;
 }
 

@@ -206,11 +206,15 @@ __device__ __forceinline__ uint32_t rest_of(uint32_t v, uint32_t seg)
 }
 
 // One thread per (read, segment, neighbour).  kScatter = false: count[bucket]++.  kScatter = true: the list entry
-// goes to poff[bucket] + (cursor[bucket]++) - x = rest(hi) | rest(lo) << 16, y = read index | seed distance << 30,
+// goes to poff[bucket] + (cursor[bucket]++) - x = rest(hi) | rest(lo) << 16, y = read index | mismatch budget << 28,
 // z / w = the full hi / lo planes.
+// The entry also carries what the comparison may still spend on the 16 rest positions: max_mm - seed distance, less
+// one if every site of the index has base `pam21` (< 4) at read position 21 and the read has another one there (the
+// comparison then leaves that position out, sliced_within<true>).  A read that has nothing left to spend on a bucket
+// gets no entry in its list.
 template <bool kScatter>
-__global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *count,
-                                                        const uint32_t *poff, uint4 *list_rest)
+__global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t max_mm,
+                                                        uint32_t pam21, uint32_t *count, const uint32_t *poff, uint4 *list_rest)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total = (uint64_t)n_guides * kSegments * n_nbr;
@@ -221,8 +225,11 @@ __global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uin
     const uint2 gp = guides[g];
     uint32_t d;
     const uint32_t b = seed_neighbour(gp, s, n, &d);
+    if (pam21 < 4u && ((((gp.x >> 21) & 1u) << 1) | ((gp.y >> 21) & 1u)) != pam21) ++d;
+    if (d > max_mm) return;
     const uint32_t at = atomicAdd(&count[b], 1u);
-    if (kScatter) list_rest[poff[b] + at] = make_uint4(rest_of(gp.x, s) | (rest_of(gp.y, s) << 16), g | (d << kListDistShift), gp.x, gp.y);
+    if (kScatter)
+        list_rest[poff[b] + at] = make_uint4(rest_of(gp.x, s) | (rest_of(gp.y, s) << 16), g | ((max_mm - d) << kListBudgetShift), gp.x, gp.y);
 }
 
 // poff[b] = sum over b' < b of roundup4(count[b']); the counts are cleared for pass 2; one workgroup, kBuckets + 1 outputs
@@ -253,16 +260,16 @@ __global__ __launch_bounds__(1024) void seed_pad_scan_kernel(uint32_t *count, ui
 
 // count: kBuckets words of scratch; poff: kBuckets + 1 list starts (multiples of kGuideUnroll); list_rest: the lists,
 // pre-filled with the padding pattern (y = ~0) by the caller
-hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t *count, uint32_t *poff,
-                             uint4 *list_rest, hipStream_t stream)
+hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t max_mm, uint32_t pam21, uint32_t *count,
+                             uint32_t *poff, uint4 *list_rest, hipStream_t stream)
 {
     const uint64_t total = (uint64_t)n_guides * kSegments * n_nbr;
     hipError_t e = hipMemsetAsync(count, 0, (size_t)kBuckets * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (total) hipLaunchKernelGGL(seed_enum_kernel<false>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, n_nbr, count, (const uint32_t *)nullptr, (uint4 *)nullptr);
+    if (total) hipLaunchKernelGGL(seed_enum_kernel<false>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, n_nbr, max_mm, pam21, count, (const uint32_t *)nullptr, (uint4 *)nullptr);
     hipLaunchKernelGGL(seed_pad_scan_kernel, dim3(1), dim3(1024), 0, stream, count, poff);
-    if (total) hipLaunchKernelGGL(seed_enum_kernel<true>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, n_nbr, count, (const uint32_t *)poff, list_rest);
+    if (total) hipLaunchKernelGGL(seed_enum_kernel<true>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, n_nbr, max_mm, pam21, count, (const uint32_t *)poff, list_rest);
     return hipGetLastError();
 }
 
@@ -392,31 +399,51 @@ __device__ __forceinline__ uint32_t count_le(uint32_t b0, uint32_t b1, uint32_t 
 // and 2, also group B for segment 2) was reported from that segment's bucket.  Without this 40 % of the
 // candidates at m = 8 (1.67 qualifying segments per hit on average) went through the hit path only to be
 // dropped there.
+template <bool kPam21>
 __device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[2 * kRestBases], uint32_t rx, uint32_t budget,
                                                   uint32_t valid, uint32_t seg, uint32_t k_seg)
 {
     uint32_t mm[kRestBases];
 #pragma unroll
-    for (int q = 0; q < kRestBases; ++q)  // (hi ^ read hi) | (lo ^ read lo)
+    for (int q = 0; q < kRestBases; ++q) {  // (hi ^ read hi) | (lo ^ read lo)
+        if (kPam21 && q == 2 * kSegBases) continue;  // the caller's business, see below
         mm[q] = bitop3<0xF6>(v[q] ^ spread(rx, q), v[kRestBases + q], spread(rx, kRestBases + q));
+    }
     uint32_t a0, a1, a2, b0, b1, b2;
     count7(mm, a0, a1, a2);
     count7(mm + kSegBases, b0, b1, b2);
-    // A + B + mm[14] + mm[15] -> c4 .. c0
-    uint32_t t0, t1, t2, k0, k1, k2, j0, j1, j2, c0, c1, c2, c3, c4;
-    full_add(a0, b0, mm[14], t0, k0);
-    half_add(t0, mm[15], c0, j0);
-    full_add(a1, b1, k0, t1, k1);
-    half_add(t1, j0, c1, j1);
-    full_add(a2, b2, k1, t2, k2);
-    half_add(t2, j1, c2, j2);
-    half_add(k2, j2, c3, c4);
-    // count <= budget, from the least significant bit up: le_i = (~c_i & b_i) | (~(c_i ^ b_i) & le_{i-1})
-    uint32_t le = ~c0 | spread(budget, 0);
-    le = bitop3<0x8E>(c1, spread(budget, 1), le);
-    le = bitop3<0x8E>(c2, spread(budget, 2), le);
-    le = bitop3<0x8E>(c3, spread(budget, 3), le);
-    uint32_t ok = bitop3<0x20>(le, c4, valid);  // le & ~c4 & valid
+    uint32_t ok;
+    if (kPam21) {
+        // Read position 21 holds the same base in EVERY site of the index (the PAM set is GG / GA): whether the read
+        // mismatches there is known before any site is looked at: the read lists have it taken out of `budget` already.
+        // A + B + mm[15] is a 4-bit count: three full adders and a 4-bit comparison instead of three full and four half
+        // adders and a 5-bit one - 57 instead of 68 instructions per (chunk, read) in a kernel that is bound by them.
+        uint32_t t0, t1, t2, k0, k1, k2;
+        full_add(a0, b0, mm[15], t0, k0);
+        full_add(a1, b1, k0, t1, k1);
+        full_add(a2, b2, k1, t2, k2);
+        uint32_t le = ~t0 | spread(budget, 0);
+        le = bitop3<0x8E>(t1, spread(budget, 1), le);
+        le = bitop3<0x8E>(t2, spread(budget, 2), le);
+        le = bitop3<0x8E>(k2, spread(budget, 3), le);
+        ok = le & valid;
+    } else {
+        // A + B + mm[14] + mm[15] -> c4 .. c0
+        uint32_t t0, t1, t2, k0, k1, k2, j0, j1, j2, c0, c1, c2, c3, c4;
+        full_add(a0, b0, mm[14], t0, k0);
+        half_add(t0, mm[15], c0, j0);
+        full_add(a1, b1, k0, t1, k1);
+        half_add(t1, j0, c1, j1);
+        full_add(a2, b2, k1, t2, k2);
+        half_add(t2, j1, c2, j2);
+        half_add(k2, j2, c3, c4);
+        // count <= budget, from the least significant bit up: le_i = (~c_i & b_i) | (~(c_i ^ b_i) & le_{i-1})
+        uint32_t le = ~c0 | spread(budget, 0);
+        le = bitop3<0x8E>(c1, spread(budget, 1), le);
+        le = bitop3<0x8E>(c2, spread(budget, 2), le);
+        le = bitop3<0x8E>(c3, spread(budget, 3), le);
+        ok = bitop3<0x20>(le, c4, valid);  // le & ~c4 & valid
+    }
     if (seg >= 1) ok &= ~count_le(a0, a1, a2, k_seg);
     if (seg >= 2) ok &= ~count_le(b0, b1, b2, k_seg);
     return ok;
@@ -716,7 +743,8 @@ static_assert(kMaxPassReads <= (1 << kTokSlotShift) && kSlicedGrab <= 8 && kTokS
 // per wave every gather of a hit fetched its line from the fabric again (FETCH_SIZE 65 GB per c3 search; 17 GB with
 // one workgroup per CU resident, tools/experiments.sh groups).  For sparse searches (c2: 13 reads per bucket) a chunk visit
 // is mostly the load of its bit-sliced block, which every sharing wave repeats: those keep a chunk per wave.
-template <bool kShared>
+// kPam21: all sites have base a.pam21 at read position 21 (sliced_within)
+template <bool kShared, bool kPam21>
 __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(kSlicedWavesPerSimd, kSlicedWavesPerSimd))) void seed_sliced_kernel(
     const SeedArgs a)
 {
@@ -740,7 +768,6 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     uint2 *const lt = s_list[wave];
     const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
     const const_u32_ptr poff = (const_u32_ptr)(uintptr_t)a.poff;
-    const uint32_t m = a.max_mm;
     const uint32_t lane_tag = w.lane << kTokLaneShift;
     unsigned long long pairs = 0, visited = 0;
 
@@ -847,11 +874,11 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
                         const uint32_t ry = uniform(rd[u].y);
                         if (ry == 0xFFFFFFFFu) continue;  // list padding
                         const uint32_t rx = uniform(rd[u].x);
-                        const uint32_t budget = m - (ry >> kListDistShift);
-                        const uint32_t word = sliced_within(v, rx, budget, valid, seg, a.k_seg);
+                        const uint32_t budget = ry >> kListBudgetShift;  // what is left of max_mm for the rest positions (seed_enum_kernel)
+                        const uint32_t word = sliced_within<kPam21>(v, rx, budget, valid, seg, a.k_seg);
                         const uint64_t b = __ballot(word != 0);
                         if (b == 0) continue;
-                        const uint32_t gid = ry & ((1u << kListDistShift) - 1u);
+                        const uint32_t gid = ry & ((1u << kListBudgetShift) - 1u);
                         if (word != 0)
                             w.tok[ring_slot(lanes_below(b, ring_tail(w)))] = make_uint2(word, gid | slot_tag | lane_tag);
                         w.ntok += (uint32_t)__popcll(b);
@@ -877,10 +904,12 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
 
 hipError_t launch_seed_sliced(const SeedArgs &args, int n_groups, bool shared, hipStream_t stream)
 {
-    if (shared)
-        hipLaunchKernelGGL(seed_sliced_kernel<true>, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
-    else
-        hipLaunchKernelGGL(seed_sliced_kernel<false>, dim3(n_groups), dim3(kWave * kWavesPerGroup), 0, stream, args);
+    const dim3 grid(n_groups), block(kWave * kWavesPerGroup);
+    const bool pam21 = args.pam21 < 4u;
+    if (shared && pam21) hipLaunchKernelGGL((seed_sliced_kernel<true, true>), grid, block, 0, stream, args);
+    else if (shared) hipLaunchKernelGGL((seed_sliced_kernel<true, false>), grid, block, 0, stream, args);
+    else if (pam21) hipLaunchKernelGGL((seed_sliced_kernel<false, true>), grid, block, 0, stream, args);
+    else hipLaunchKernelGGL((seed_sliced_kernel<false, false>), grid, block, 0, stream, args);
     return hipGetLastError();
 }
 
