@@ -381,14 +381,6 @@ __device__ __forceinline__ void count7(const uint32_t *m, uint32_t &b0, uint32_t
     full_add(c1, c2, c3, b1, b2);
 }
 
-// 3-bit-sliced count <= k (k wave-uniform, 0..7)
-__device__ __forceinline__ uint32_t count_le(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t k)
-{
-    uint32_t le = ~b0 | spread(k, 0);
-    le = bitop3<0x8E>(b1, spread(k, 1), le);
-    return bitop3<0x8E>(b2, spread(k, 2), le);
-}
-
 // Bit i of the result: site i of this lane's block is valid, within `budget` mismatches of the read on the
 // 16 rest positions, and NOT already reported by an earlier segment.  rx = rest(hi) | rest(lo) << 16 of the
 // read (wave-uniform), budget <= 15.
@@ -401,7 +393,7 @@ __device__ __forceinline__ uint32_t count_le(uint32_t b0, uint32_t b1, uint32_t 
 // dropped there.
 template <bool kPam21>
 __device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[2 * kRestBases], uint32_t rx, uint32_t budget,
-                                                  uint32_t valid, uint32_t seg, uint32_t k_seg)
+                                                  uint32_t valid, uint32_t seg, const uint32_t (&kv)[2])
 {
     uint32_t mm[kRestBases];
 #pragma unroll
@@ -444,8 +436,11 @@ __device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[2 * kRestB
         le = bitop3<0x8E>(c3, spread(budget, 3), le);
         ok = bitop3<0x20>(le, c4, valid);  // le & ~c4 & valid
     }
-    if (seg >= 1) ok &= ~count_le(a0, a1, a2, k_seg);
-    if (seg >= 2) ok &= ~count_le(b0, b1, b2, k_seg);
+    // Not reported by an earlier segment's bucket: its group count > k_seg.  k_seg <= 2 (VSC_MAX_MISMATCHES / 3), so
+    // bit 2 of the count alone says "greater"; kv = bits 0 and 1 of k_seg, spread, in VECTOR registers: an instruction
+    // with a scalar operand issues at 4.2 cycles per SIMD, with vector operands only at 2.6 (tools/micro/valu_rate.hip).
+    if (seg >= 1) ok = bitop3<0xD0>(ok, a2, bitop3<0x8E>(a1, kv[1], ~a0 | kv[0]));  // ok & (a2 | ~le)
+    if (seg >= 2) ok = bitop3<0xD0>(ok, b2, bitop3<0x8E>(b1, kv[1], ~b0 | kv[0]));
     return ok;
 }
 
@@ -766,6 +761,9 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     for (uint32_t q = w.lane; q < (uint32_t)kParts; q += kWave) w.parts[q] = a.reserve;  // no block yet = a used-up one
 
     uint2 *const lt = s_list[wave];
+    uint32_t kv[2];  // bits 0 and 1 of k_seg, spread (the duplicate test of sliced_within)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(kv[i]) : "s"(spread(a.k_seg, i)));
     const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
     const const_u32_ptr poff = (const_u32_ptr)(uintptr_t)a.poff;
     const uint32_t lane_tag = w.lane << kTokLaneShift;
@@ -875,7 +873,7 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
                         if (ry == 0xFFFFFFFFu) continue;  // list padding
                         const uint32_t rx = uniform(rd[u].x);
                         const uint32_t budget = ry >> kListBudgetShift;  // what is left of max_mm for the rest positions (seed_enum_kernel)
-                        const uint32_t word = sliced_within<kPam21>(v, rx, budget, valid, seg, a.k_seg);
+                        const uint32_t word = sliced_within<kPam21>(v, rx, budget, valid, seg, kv);
                         const uint64_t b = __ballot(word != 0);
                         if (b == 0) continue;
                         const uint32_t gid = ry & ((1u << kListBudgetShift) - 1u);
