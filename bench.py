@@ -38,7 +38,11 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz (32-bit integer lane-ops / s)
 LANE_OPS_PER_COMPARE = {"scan": 3.5,     # v_xor + v_bitop3 + v_bcnt + 1/2 v_min3 per (site, read) pair
-                        "sliced": 2.25}  # 72 instructions per read and 32 sites: 16 x 2 mismatch vectors + adder tree + test
+                        "sliced": 1.875}  # 60 instructions per read and 32 sites: 15 x 2 mismatch vectors (read position 21 is the
+                                          # lists' business with the GG / GA PAM set) + 22 adder tree + 5 test + 3 duplicate test
+# measured issue cost of those 60 (tools/micro/valu_rate.hip, cycles per SIMD at 2.4 GHz, 6 waves resident): the 34 that take a
+# mask of the read as SCALAR operand 4.2 each, the 26 with vector operands only 2.6 each
+SLICED_ISSUE_CYCLES_PER_READ_BLOCK = 34 * 4.2 + 26 * 2.6
 
 
 def parse():
@@ -513,9 +517,15 @@ def main():
                          "whole_step_frac": survey_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "integer/bitwise compare kernel; VALU issue is the binding resource next to HBM "
                                  "(DESIGN.md section 4) - both are reported; valu counts the comparison only, not the hit path",
-                         "valu": {"pair_compares_per_s": compares / (scan_avg_ms * 1e-3),
-                                  "lane_ops_per_compare": ops_per_compare, "achieved_lane_ops_per_s": lane_ops,
-                                  "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK, "frac": lane_ops / VALU_LANE_OPS_PEAK}},
+                         "valu": dict({"pair_compares_per_s": compares / (scan_avg_ms * 1e-3),
+                                       "lane_ops_per_compare": ops_per_compare, "achieved_lane_ops_per_s": lane_ops,
+                                       "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK, "frac": lane_ops / VALU_LANE_OPS_PEAK},
+                                      **({"issue_cycles_per_read_and_block": SLICED_ISSUE_CYCLES_PER_READ_BLOCK,
+                                          "issue_frac": compares / 2048.0 * SLICED_ISSUE_CYCLES_PER_READ_BLOCK
+                                                        / (256 * 4 * 2.4e9 * scan_avg_ms * 1e-3),
+                                          "issue_note": "share of the SIMDs' vector issue cycles the comparison alone takes at its "
+                                                        "measured issue costs (the hit path, ~30 more instructions per read and "
+                                                        "block, comes on top)"} if algorithm != "scan" else {}))},
             # the ordering of the hits (hand-written bin sort) is the second largest share of a step at m = 8
             "roofline_sort": sort_roofline(sums, args.steps),
             "kernels_ms": {"search": scan_avg_ms, "prep": sums["prep_ms"] / args.steps, "sort": sums["sort_ms"] / args.steps,
