@@ -40,7 +40,7 @@ constexpr int kTokSlotShift = 14;
 constexpr uint32_t kTokReadMask = (1u << kTokSlotShift) - 1u;
 constexpr int kSlicedResolve = 3;                // sliced kernel: resolve when this many passes of 64 tokens wait (the
                                                 // gathers of the later passes overlap the earlier ones)
-constexpr int kSlicedTokCap = (kSlicedResolve + 4) * 64;  // per-wave LDS ring of 8-byte hit tokens: a group of four reads adds <= 256
+constexpr int kSlicedTokCap = 512;  // per-wave LDS ring of 8-byte hit tokens (a power of two: the slot is an AND): a group of four reads adds <= 256
 // chunk table word z: bucket (16 bits) | rank in the chunk of its first '-' site (0 .. 2048) << 16 | "holds a window
 // that is followed by N" << 28
 constexpr uint32_t kChunkBucketMask = 0xFFFFu;

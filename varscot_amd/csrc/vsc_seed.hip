@@ -596,10 +596,10 @@ __device__ __forceinline__ void sliced_finish_hits(const SeedArgs &a, SeedWave &
     }
 }
 
-// ring slot of running position p (p < 2 * kSlicedTokCap is all the callers need)
+// ring slot of running position p
 __device__ __forceinline__ uint32_t ring_slot(uint32_t p)
 {
-    return p >= (uint32_t)kSlicedTokCap ? p - kSlicedTokCap : p;
+    return p & (uint32_t)(kSlicedTokCap - 1);
 }
 
 // ring slots head .. head + n - 1 -> one token per lane (lanes >= n stay empty), gather issued
@@ -732,6 +732,7 @@ __device__ __forceinline__ void sliced_load_sites(const SeedArgs &a, const v4u &
 
 // (amdgpu_waves_per_eu: 5 waves per SIMD = at most 102 VGPRs; LDS: 5.7 KB per wave, 20 waves per CU)
 static_assert(kMaxPassReads <= (1 << kTokSlotShift) && kSlicedGrab <= 8 && kTokSlotShift + 3 <= kTokLaneShift, "token fields");
+static_assert((kSlicedTokCap & (kSlicedTokCap - 1)) == 0 && kSlicedTokCap >= (kSlicedResolve + kGuideUnroll) * kWave, "token ring");
 // kShared: the four waves of a workgroup take the SAME chunks and a quarter of each chunk's read list each.  The
 // resident site records (16 KB per chunk, gathered 8 bytes per hit) then are a working set of one chunk per
 // workgroup instead of one per wave - 3 MB per XCD instead of 12 - which is what its 4 MB L2 can hold: with a chunk
