@@ -1988,7 +1988,7 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
     std::vector<uint32_t> index_of(keys.size());  // by position in `keys`
     for (size_t i = 0; i < keys.size(); ++i) index_of[i] = test_index((uint16_t)(keys[i] >> 8), (uint8_t)keys[i]);
     // nodes: test | left << 10 | right << 20 (0-based) | terminal << 30 | votes class "1" << 31; or the compact form
-    // (trees of <= 512 nodes): test | (daughter | terminal << 9 | vote << 10) << 10 (left) / << 21 (right)
+    // (trees of <= 512 nodes): test | (nodes to skip | vote << 10) << 10 (right) / << 21 (left)
     const bool compact = model->n_nodes <= 512;
     std::vector<uint32_t> nodes(nn);
     std::vector<uint8_t> depth(model->n_trees, 0);
@@ -2008,9 +2008,12 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
             nodes[i] = test | l << 10 | r << 20;
             if (compact) {
                 // (x <= thr takes the LEFT daughter: filed in the upper field, which the kernel selects with 10 + 11 * bit)
+                // a daughter field = how many nodes further on the walk continues (10 bits) | vote (bit 10): a split
+                // daughter lies d - k nodes behind its parent; a terminal one sends the walk to the NEXT tree's root,
+                // n_nodes - k nodes on (trees lie back to back at a stride of n_nodes), and brings its vote along
                 auto daughter = [&](uint32_t d) {
                     const size_t j = (size_t)tr * model->n_nodes + d;
-                    return model->node_status[j] == 1 ? d : (1u << 9 | (model->node_class[j] == 2 ? 1u << 10 : 0u));
+                    return model->node_status[j] == 1 ? d - k : ((model->n_nodes - k) | (model->node_class[j] == 2 ? 1u << 10 : 0u));
                 };
                 nodes[i] = test | daughter(r) << 10 | daughter(l) << 21;
             }
@@ -2019,7 +2022,7 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
         }
         if (compact && model->node_status[(size_t)tr * model->n_nodes] != 1) {
             // a tree that is one terminal node: a root whose daughters both are "terminal, the root's vote"
-            const uint32_t leaf = 1u << 9 | (model->node_class[(size_t)tr * model->n_nodes] == 2 ? 1u << 10 : 0u);
+            const uint32_t leaf = model->n_nodes | (model->node_class[(size_t)tr * model->n_nodes] == 2 ? 1u << 10 : 0u);
             nodes[(size_t)tr * model->n_nodes] = leaf << 10 | leaf << 21;
         }
     }

@@ -227,11 +227,12 @@ struct SeedArgs {
 //   bits 0..9 test | 10..19 left daughter | 20..29 right daughter (0-based; a terminal node points at itself) |
 //   30 terminal | 31 votes class "1"
 // A node visit is one 4-byte LDS read of the node + one of the row's test word.
-// Trees of at most 512 nodes (rfClassifier: 275) use the COMPACT form, in which a node says of each daughter either where
-// it is or that it is terminal and how it votes - terminal nodes are never visited, and a lane moves on to its next tree
-// the moment it reaches one:
-//   bits 0..9 test | 10..18 right daughter, 19 right is terminal, 20 its vote | 21..29 left daughter, 30 terminal, 31 vote
-// (a terminal daughter's index bits are 0; the all-zero word is the SINK behind the last tree of a chain)
+// Trees of at most 512 nodes (rfClassifier: 275) use the COMPACT form, in which a node says of each daughter how many
+// nodes further on the walk continues - at the daughter (which lies behind its parent), or, if the daughter is terminal,
+// at the root of the NEXT tree (trees lie back to back) with the terminal node's vote in the field: terminal nodes are never
+// visited, a lane moves on to its next tree the moment it reaches one, and a step is one add:
+//   bits 0..9 test | 10..19 right: nodes to skip, 20 its vote | 21..30 left: nodes to skip, 31 vote
+// (the all-zero word is the SINK behind the last tree of a chain: it skips nothing and votes nothing)
 constexpr int kRfRows = 512;             // feature rows per workgroup (one thread each)
 constexpr int kRfMaxTests = 1024;        // distinct (predictor, threshold) pairs a forest may use
 constexpr int kRfMaxNodes = 1024;        // nodes of one tree (rfClassifier: 275)

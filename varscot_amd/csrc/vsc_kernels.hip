@@ -1000,35 +1000,44 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
         if (a.compact) {
             // Per-lane tree queues: a lane that reaches a terminal node goes straight on to its next tree instead of
             // idling until the deepest tree of the wave is through (the trees are 11 - 21 levels deep, a row's path 9
-            // on average).  A node names, per daughter, either the daughter's index or "terminal, vote v" (index bits
-            // zero), so terminal nodes are never read: reaching one adds the vote and moves the lane's tree base on by
-            // one tree, where index 0 is the next root.  kRfChains chains per lane - consecutive parts of the tile - overlap
-            // their LDS latencies (c5 batch, 256 rows: one chain 8.8 s, two 5.2 s, three 5.9 s; 512 rows and a 26 KB tile: 4.8 s); behind the last tree of each part lies a SINK word (0 = test 0, both daughters "index 0,
-            // not terminal": it points at itself and votes nothing), so a finished chain spins without side effects
+            // on average).  A node names, per daughter, how many nodes further on the walk continues - to the daughter, or
+            // (terminal daughter: never read, its vote travels in the field) to the root of the next tree, which lies right
+            // behind this one: one add per step, no tree base to keep.  kRfChains chains per lane - consecutive parts of the tile - overlap
+            // their LDS latencies (c5 batch, 256 rows: one chain 8.8 s, two 5.2 s, three 5.9 s; 512 rows and a 26 KB tile: 4.8 s); behind the last tree of each part lies a SINK word (0 = test 0, both daughters "0 nodes
+            // on, no vote": it points at itself and votes nothing), so a finished chain spins without side effects
             // and the wave leaves when every lane's two nodes are sinks.  Straight-line code, no per-lane predicates.
             //   tile layout: [trees of chain 0][sink][trees of chain 1][sink] ...
             const uint32_t per = (nt + kRfChains - 1) / kRfChains;  // trees per chain (the last chains may have fewer, or none)
-            const char *const tile_b = (const char *)s_tile;
-            const uint32_t tree_bytes = a.n_nodes * 4u;
-            uint32_t base[kRfChains], n[kRfChains];
+            // (LDS addresses as 32-bit integers: pointer arithmetic on generic pointers costs 64-bit adds and flat loads;
+            // the two opaque one-instruction asm statements keep the compiler from re-folding "field, then shift-and-add"
+            // into shift + mask + add - three instructions instead of two, twice per step)
+            typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
+            const uint32_t tile_at = (uint32_t)(uintptr_t)(lds_u32)s_tile, bits_at = (uint32_t)(uintptr_t)(lds_u32)bt;
+            uint32_t at[kRfChains];  // LDS address of the chain's current node
+            uint32_t n[kRfChains];   // ... and its word
             uint32_t any = 0;
 #pragma unroll
             for (int c = 0; c < kRfChains; ++c) {
                 const uint32_t first = min((uint32_t)c * per, nt);  // chain c walks trees [first, min(first + per, nt))
-                base[c] = (first * a.n_nodes + (uint32_t)c) * 4u;   // (c sink words lie in front of it)
-                n[c] = *(const uint32_t *)(tile_b + base[c]);
+                at[c] = tile_at + (first * a.n_nodes + (uint32_t)c) * 4u;  // (c sink words lie in front of it)
+                n[c] = *(lds_u32)(uintptr_t)at[c];
                 any |= n[c];
             }
             while (__ballot(any != 0u)) {
                 any = 0;
 #pragma unroll
                 for (int c = 0; c < kRfChains; ++c) {
-                    const uint32_t w = bt[((n[c] >> 5) & 31u) * kRfRows];
+                    // the row's word that holds the node's test (word index = test / 32; words lie kRfRows apart)
+                    uint32_t wi;
+                    asm("v_bfe_u32 %0, %1, 5, 5" : "=v"(wi) : "v"(n[c]));
+                    const uint32_t w = *(lds_u32)(uintptr_t)(bits_at + (wi << 11));
                     // x <= thr (bit set) takes the left daughter, filed at bits 21..31; else the right one at bits 10..20
                     const uint32_t d = __builtin_amdgcn_ubfe(n[c], 10u + 11u * __builtin_amdgcn_ubfe(w, n[c], 1u), 11u);
-                    ones += d >> 10;                               // the vote bit is set for terminal daughters only
-                    base[c] += ((d >> 9) & 1u) * tree_bytes;       // terminal: on to the next tree (its root: index 0)
-                    n[c] = *(const uint32_t *)(tile_b + base[c] + (d & 511u) * 4u);
+                    ones += d >> 10;  // the vote bit is set for terminal daughters only
+                    uint32_t skip;    // split daughter: that many nodes on; terminal: the next tree's root
+                    asm("v_and_b32 %0, 0x3ff, %1" : "=v"(skip) : "v"(d));
+                    at[c] += skip << 2;
+                    n[c] = *(lds_u32)(uintptr_t)at[c];
                     any |= n[c];
                 }
             }
