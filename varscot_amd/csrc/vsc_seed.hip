@@ -293,7 +293,8 @@ struct SeedWave {
 // adders, 2 instructions each) + a 5-instruction bit-sliced "count <= budget" = ~67 instructions per 32
 // pairs, no popcount, no per-pair branch.  Only the 16 positions OUTSIDE the bucket's seed segment are
 // compared: all sites of a bucket share the segment, whose distance d to the read is a property of
-// the list entry (0, 1 or 2 substitutions), so the budget for the rest is m - d.
+// the list entry (0, 1 or 2 substitutions), so the budget for the rest is m - d (the entry carries it).  With the
+// GG / GA PAM set read position 21 leaves the comparison as well (kPam21, see sliced_within): 57 instructions.
 //
 // Vertical block of 32 sites (32 words): words 0..15 = hi-plane bit of rest position q = 0..15, words 16..31 =
 // lo-plane bit.  Block b of a chunk holds the chunk's sites [32 b, 32 b + 32); the blocks of a chunk are
@@ -383,7 +384,7 @@ __device__ __forceinline__ void count7(const uint32_t *m, uint32_t &b0, uint32_t
 
 // Bit i of the result: site i of this lane's block is valid, within `budget` mismatches of the read on the
 // 16 rest positions, and NOT already reported by an earlier segment.  rx = rest(hi) | rest(lo) << 16 of the
-// read (wave-uniform), budget <= 15.
+// read (wave-uniform), budget <= 15 (what the list entry leaves of max_mm: seed_enum_kernel).
 // Whatever the bucket's segment, the 16 rest positions are [7 positions of another segment][7 of the third]
 // [read positions 21, 22], so the adder tree first counts the two groups of seven (3 bits each) and then
 // adds them and the last two inputs: the same 30 instructions as a flat tree, and the group counts give
