@@ -158,7 +158,7 @@ def _synthetic_forest(path, rng, n_trees, n_nodes, names, depth_first=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_nodes", [31, 511, 700])
+@pytest.mark.parametrize("n_nodes", [31, 511, 512, 700])
 def test_rf_predict_on_synthetic_forests(tmp_path, golden_dir, n_nodes):
     """Both node forms of the forest kernel - compact nodes walked through per-lane tree queues (<= 512 nodes per tree)
     and the self-looping form with wave-uniform step counts (more) - against the Python restatement of
