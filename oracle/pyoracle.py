@@ -55,6 +55,8 @@ def lib():
         L.orc_mit_score.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
         L.orc_feature_row.argtypes = [C.c_char_p, C.c_char_p, u32p]
         L.orc_max_threads.restype = C.c_int
+        L.orc_planes_to_text.restype = None
+        L.orc_planes_to_text.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         L.orc_pigeon_build.restype = C.c_void_p
         L.orc_pigeon_build.argtypes = [pp, u32p, C.c_uint32]
         L.orc_pigeon_free.argtypes = [C.c_void_p]
@@ -66,8 +68,9 @@ def lib():
 
 
 def _genome_args(contigs):
-    bufs = [c if isinstance(c, bytes) else c.encode() for c in contigs]
-    arr = (C.c_char_p * max(1, len(bufs)))(*bufs)
+    bufs = [c if isinstance(c, (bytes, np.ndarray)) else c.encode() for c in contigs]
+    # numpy uint8 arrays (planes_to_text of a whole chromosome) are passed by address, not copied
+    arr = (C.c_char_p * max(1, len(bufs)))(*[C.cast(b.ctypes.data, C.c_char_p) if isinstance(b, np.ndarray) else b for b in bufs])
     lens = (C.c_uint32 * max(1, len(bufs)))(*[len(b) for b in bufs])
     return bufs, arr, lens
 
@@ -114,6 +117,16 @@ def search_fast(contigs, guides, max_mm, extra_pam=None, threads=0, cap=None):
     if n < 0:
         raise ValueError("orc_search_fast failed")
     return out[:min(n, len(out))]
+
+
+def planes_to_text(hi, lo, nmask, pos, n):
+    """n characters from global position pos of packed planes (uint32 arrays; layout of include/varscot_hip.h,
+    restated in vsc_planes.c independently of the product's vsc_unpack_bases) as a bytes-like numpy uint8 array."""
+    hi, lo, nmask = (np.ascontiguousarray(a, dtype=np.uint32) for a in (hi, lo, nmask))
+    assert pos + n <= 32 * len(hi)
+    out = np.empty(n, dtype=np.uint8)
+    lib().orc_planes_to_text(hi.ctypes.data, lo.ctypes.data, nmask.ctypes.data, pos, n, out.ctypes.data)
+    return out
 
 
 def count_fast(contigs, guides, max_mm, extra_pam=None, threads=0):

@@ -100,6 +100,10 @@ long orc_count_fast(const char *const *contigs, const uint32_t *contig_len, uint
                     int threads, long *sites);
 int orc_max_threads(void);
 
+/* vsc_planes.c: n characters from global position pos of a genome in the packed-plane layout of
+ * include/varscot_hip.h (restated from the header, independent of the product's unpacking). */
+void orc_planes_to_text(const uint32_t *hi, const uint32_t *lo, const uint32_t *nmask, uint64_t pos, uint64_t n, char *out);
+
 /* The same search in the reference's algorithmic shape (vsc_pigeon.c): pigeonhole halves with floor(m/2)
  * substitutions each (read_mapping/bidir_mapping.cpp:129-146,157-162) through a k-mer table of the text,
  * every occurrence verified by the delegate (:39-126), reads under OpenMP (:285-295).  Build once per text. */

@@ -1,13 +1,21 @@
-"""BASELINE.json full sizes (c2, c3) through size-independent properties, on the bench's own synthetic
-3 Gbp genome: the streaming scan and the seed search - two independent algorithms over different data
-structures - must return the same records; results are strictly sorted and unique; planted sites are
-found.  (The oracle cannot run at this size; it checks both algorithms at sizes it finishes in seconds,
-tests/test_gpu_parity.py.)"""
+"""BASELINE.json full sizes (c2 ... c5) on the bench's own synthetic 3 Gbp genome.
+
+Against the ORACLE: the oracle's OpenMP port (oracle/vsc_fastport.c, checked against the character-level
+restatement in tests/test_oracle.py) runs on the WHOLE genome - decoded from the packed planes by the oracle's own
+decoder - for a subset of the reads (region edges 0 / 63 / 64, the last read, reads spread over the set), and every
+record the GPU returns for those reads must equal it byte for byte: seed search and streaming scan at c2 and c3
+size, the same reads inside streamed c5 batches, whole contigs (the last one, and the one that crosses position 2^31)
+of a 4.28 Gbp genome, and the chrX / chrY windows of the c4 SNP genome (contig ids beyond 2^23; the windows
+themselves against oracle/variants_oracle.py).  What the reference does there: read_mapping/bidir_mapping.cpp:39-86,
+167-187.
+Beyond the subset: the streaming scan and the seed search - two independent algorithms over different data
+structures - must return the same records; results are strictly sorted and unique; planted sites are found."""
 import numpy as np
 import pytest
 import torch
 
 import varscot_amd as va
+from oracle import pyoracle
 from varscot_amd import synth
 from varscot_amd.dist import DeviceAlias as _DeviceAlias
 
@@ -29,6 +37,68 @@ def big():
     ctx.close()
 
 
+# Reads the oracle searches on the whole genome.  Output regions hold 64 reads (read >> 6), a search pass 16 384, a
+# streamed batch 10 000: both sides of every such boundary inside the c3 read set, + reads spread over it.
+ORACLE_READS_C3 = sorted({0, 1, 62, 63, 64, 65, 127, 128, 999, 1000, 4095, 4096, 8191, 8192, 9998, 9999} | set(range(311, 9999, 421)))
+ORACLE_READS_C2 = [r for r in ORACLE_READS_C3 if r < 1000] + [500, 937]
+ORACLE_READS_STREAM = [10_000, 10_063, 10_064, 14_321, 19_999]  # second streamed batch of the c5 read set
+
+
+def _genome_text(packed):
+    """Every contig as text, decoded by the ORACLE's reader of the plane layout (oracle/vsc_planes.c)."""
+    return [pyoracle.planes_to_text(packed.hi, packed.lo, packed.nmask, int(r["offset"]), int(r["length"])) for r in packed.contigs]
+
+
+def _oracle_records(text, all_reads, which, max_mm, extra_pam=None):
+    """The oracle's records for the reads `which` (ascending indices into all_reads), guide = the index in all_reads."""
+    which = sorted(which)
+    want = pyoracle.search_fast(text, [all_reads[i] for i in which], max_mm, extra_pam=extra_pam, cap=400_000 * len(which))
+    want = want.copy()
+    want["guide"] = np.asarray(which, dtype=np.uint32)[want["guide"]]
+    return want
+
+
+@pytest.fixture(scope="module")
+def oracle_big(big):
+    """What the oracle finds on the 3 Gbp genome: c3 subset at <= 8 mismatches (+ five reads of the second c5 batch),
+    c2 subset at <= 6.  ~0.1 s per read on the GPU box's host."""
+    ctx, packed, genome, guides, planted = big
+    text = _genome_text(packed)
+    ids, guides100k = synth.synthetic_guides(100_000)
+    out = {
+        "c3": _oracle_records(text, guides100k, ORACLE_READS_C3 + ORACLE_READS_STREAM, 8),
+        "c2": _oracle_records(text, guides100k, sorted(ORACLE_READS_C2), 6),
+    }
+    del text
+    assert len(out["c3"]) > 150_000 * len(ORACLE_READS_C3) and len(out["c2"]) > 3_000 * len(ORACLE_READS_C2)
+    return out
+
+
+def _records_of_reads(rec, reads):
+    """The records of `reads` out of a device result (int32 [n, 4], sorted by guide) as a host HIT_DTYPE array."""
+    g, n = rec[:, 0], rec.shape[0]
+
+    def lower(v):
+        lo, hi = 0, n
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if int(g[mid]) < v:
+                lo = mid + 1
+            else:
+                hi = mid
+        return lo
+
+    parts = [rec[lower(r):lower(r + 1)] for r in sorted(reads)]
+    got = torch.cat(parts).contiguous().cpu().numpy() if parts else np.zeros((0, 4), dtype=np.int32)
+    return got.view(np.uint32).reshape(-1, 4).view(va.HIT_DTYPE).reshape(-1)
+
+
+def _assert_equals_oracle(got, want, reads):
+    want = want[np.isin(want["guide"], np.asarray(sorted(reads), dtype=np.uint32))]
+    assert len(got) == len(want), (len(got), len(want))
+    assert got.tobytes() == want.tobytes()
+
+
 def _device_records(hits):
     n = len(hits)
     t = torch.as_tensor(_DeviceAlias(hits.device_ptr, n * va.HIT_DTYPE.itemsize), device="cuda:0")
@@ -44,7 +114,7 @@ def _keys(rec):
     return (((g << 1 | s) << 6 | c) << 32) | p
 
 
-def test_c2_scan_and_seed_agree_and_find_planted_sites(big):
+def test_c2_scan_and_seed_agree_and_find_planted_sites(big, oracle_big):
     ctx, packed, genome, guides, planted = big
     reads = guides[:1000]
     h_seed = genome.search(reads, 6, algorithm="seed")
@@ -55,6 +125,8 @@ def test_c2_scan_and_seed_agree_and_find_planted_sites(big):
     h_scan.close()
     assert len(a) > 1_000_000
     assert a.tobytes() == b.tobytes()
+    # the oracle on the whole 3 Gbp genome, for a subset of the reads: byte-equal records
+    _assert_equals_oracle(a[np.isin(a["guide"], np.asarray(ORACLE_READS_C2, dtype=np.uint32))], oracle_big["c2"], ORACLE_READS_C2)
     key = ((a["guide"].astype(np.int64) << 1 | (a["info"] >> 31)) << 6 | a["contig"]) << 32 | a["pos"]
     assert np.all(np.diff(key) > 0)  # strictly ascending: sorted and no duplicates
     nm = (a["info"] >> 23) & 31
@@ -86,21 +158,41 @@ def _digest(hits, chunk=1 << 27):
     return n, ascending, max_nm, sums
 
 
-def test_c3_scan_and_seed_agree_on_the_device(big):
-    """1.6e9 records per result: compared where they are (HBM), through torch views of the record buffers."""
+def test_c3_scan_and_seed_agree_on_the_device(big, oracle_big):
+    """1.6e9 records per result: compared where they are (HBM), through torch views of the record buffers - and, for
+    the oracle's read subset, byte for byte with what the oracle finds on the whole genome (both kernels)."""
     ctx, packed, genome, guides, planted = big
     h_seed = genome.search(guides, 8, algorithm="seed")
     n, ascending, max_nm, sums = _digest(h_seed)
     assert n > 1_000_000_000 and ascending and max_nm <= 8
     mid = n // 2
     seed_mid = _device_records(h_seed)[mid:mid + 1_000_000].clone()
+    _assert_equals_oracle(_records_of_reads(_device_records(h_seed), ORACLE_READS_C3), oracle_big["c3"], ORACLE_READS_C3)
     h_seed.close()
     torch.cuda.empty_cache()
     h_scan = genome.search(guides, 8, algorithm="scan")
     assert _digest(h_scan) == (n, True, max_nm, sums)
     # and record by record on a slice from the middle
     assert bool((seed_mid == _device_records(h_scan)[mid:mid + 1_000_000]).all())
+    _assert_equals_oracle(_records_of_reads(_device_records(h_scan), ORACLE_READS_C3), oracle_big["c3"], ORACLE_READS_C3)
     h_scan.close()
+    torch.cuda.empty_cache()
+
+
+def test_c5_streamed_batches_equal_the_oracle_on_the_read_subset(big, oracle_big):
+    """Two streamed batches of 10 000 reads (the first 20 000 of the c5 read set, <= 8 mismatches): the records of
+    the oracle's reads inside each batch - first / last read of a batch, region edges - equal the oracle's."""
+    ctx, packed, genome, guides, planted = big
+    ids, guides100k = synth.synthetic_guides(100_000)
+    seen = []
+
+    def on_batch(h, first, count):
+        reads = [r for r in ORACLE_READS_C3 + ORACLE_READS_STREAM if first <= r < first + count]
+        _assert_equals_oracle(_records_of_reads(_device_records(h), reads), oracle_big["c3"], reads)
+        seen.append((first, count, len(reads)))
+
+    genome.search_streamed(guides100k[:20_000], 8, on_batch, batch=10_000, algorithm="seed")
+    assert seen == [(0, 10_000, len(ORACLE_READS_C3)), (10_000, 10_000, len(ORACLE_READS_STREAM))]
     torch.cuda.empty_cache()
 
 
@@ -271,6 +363,40 @@ def test_c4_variant_windows_at_full_size(big, tmp_path):
     assert (k + 1, off) in set(zip(exact["contig"].tolist(), exact["pos"].tolist()))
     one_off = mine[(mine["contig"] == k) & (mine["pos"] == off)]
     assert len(one_off) == 1 and int(one_off["info"][0]) & 0x7FFFFF == 1 << 10  # REF window: the SNP position mismatches
+    # Against the oracle, on the windows of chr22, chrX and chrY (the last ~ 8 % of the SNP genome: contig ids from below
+    # to far beyond 2^23).  (1) the windows themselves = oracle/variants_oracle.py on those chromosomes' VCF records and
+    # the oracle's decoding of the reference planes; (2) the records of ALL 1 000 reads on them = the oracle's search of
+    # the oracle's window sequences.
+    from oracle import variants_oracle as vo
+    chroms = ("chr22", "chrX", "chrY")
+    with open(vcf) as f:
+        sub = "".join(line for line in f if line[0] == "#" or line.split("\t", 1)[0] in chroms)
+    ref_text = {}
+    for name in chroms:
+        c = packed.names.index(name)
+        ref_text[name] = pyoracle.planes_to_text(packed.hi, packed.lo, packed.nmask, int(packed.contigs[c]["offset"]),
+                                                 int(packed.contigs[c]["length"])).tobytes().decode()
+    want_windows = vo.vcf_loader(sub, ref_text, 0, 23)
+    del ref_text
+    n_win = len(snp.contigs)
+    first = n_win - len(want_windows)
+    assert len(want_windows) > 400_000 and first < (1 << 23) < n_win
+    assert snp.names[first].startswith("chr22_") and not snp.names[first - 1].startswith("chr22_")
+    window_text = pyoracle.planes_to_text(snp.hi, snp.lo, snp.nmask, int(snp.contigs[first]["offset"]),
+                                          int(snp.contigs[n_win - 1]["offset"]) + int(snp.contigs[n_win - 1]["length"]) - int(snp.contigs[first]["offset"]))
+    base = int(snp.contigs[first]["offset"])
+    for i in range(0, len(want_windows), 1):
+        rid, seq = want_windows[i]
+        row = snp.contigs[first + i]
+        o = int(row["offset"]) - base
+        if int(row["length"]) != len(seq) or window_text[o:o + len(seq)].tobytes() != seq.encode() or (i % 97 == 0 and snp.names[first + i] != rid):
+            raise AssertionError("window %d (%s) differs from the oracle's %s" % (first + i, snp.names[first + i], rid))
+    want = pyoracle.search_fast([seq.encode() for _, seq in want_windows], reads, 6, extra_pam=probe[21:], cap=2_000_000).copy()
+    want["contig"] += first
+    got = a[a["contig"] >= first]
+    assert len(want) > 5_000 and len(got) == len(want)
+    # a holds (guide, strand, contig, pos) order; so does the oracle
+    assert got.tobytes() == want.tobytes()
 
 
 def test_skewed_reads_at_scale():
@@ -358,6 +484,17 @@ def test_genome_close_to_the_32_bit_position_limit():
     found = set(zip(a["guide"].tolist(), a["contig"].tolist(), a["pos"].tolist(), (a["info"] >> 31).tolist()))
     assert all(p in found for p in planted)
     assert int((a["contig"] == last).sum()) > 10_000
+    # the oracle on whole contigs of this genome: the last one (positions up to 2^32 - 1.4e7) and the one that holds
+    # global position 2^31 (the sign bit of a 32-bit position) - all 200 reads, byte-equal records
+    offs = packed.contigs["offset"].astype(np.int64)
+    across = int(np.searchsorted(offs, 1 << 31, side="right")) - 1
+    assert offs[across] < (1 << 31) < offs[across] + int(packed.contigs[across]["length"]) and across != last
+    for c in (across, last):
+        text = pyoracle.planes_to_text(packed.hi, packed.lo, packed.nmask, int(offs[c]), int(packed.contigs[c]["length"]))
+        want = pyoracle.search_fast([text], guides, 6, cap=4_000_000).copy()
+        want["contig"] = c
+        got = a[a["contig"] == c]
+        assert len(want) > 10_000 and len(got) == len(want) and got.tobytes() == want.tobytes()
 
 
 def _lib_handle():

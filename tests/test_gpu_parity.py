@@ -673,6 +673,27 @@ def test_exchange_records_pack_and_merge(ctx, oracle, world):
     sel = want[(want["guide"] >= 11) & (want["guide"] < 29)]
     assert merged.to_numpy().tobytes() == sel.tobytes()
     merged.close()
+    # records a receiver must refuse (they come from a peer or from the caller): a position of all ones (the walk over the
+    # contig table ends at the last contig instead of never), one inside the separator between two contigs, one in the
+    # padding behind the genome, and two records of one segment swapped (descending)
+    from varscot_amd._lib import VarscotError
+    first = int(np.flatnonzero(all_counts.sum(axis=0) >= 2)[0])  # a key some shard holds two records of
+    shard = int(np.argmax(all_counts[:, first] >= 2))
+    at = int(sum(len(r) for r in recs[:shard]) + all_counts[shard, :first].sum())
+    sep = int(packed.contigs["offset"][0]) + int(packed.contigs["length"][0])
+    end = int(packed.contigs["offset"][-1]) + int(packed.contigs["length"][-1])
+    for bad in (0xFFFFFFFF, sep - 5, end + 40, "swap"):
+        broken = cat.copy()
+        if bad == "swap":
+            broken[at], broken[at + 1] = cat[at + 1], cat[at]
+        else:
+            broken[at] = np.uint64(bad) << np.uint64(23) | (cat[at] & np.uint64(0x7FFFFF))
+        with pytest.raises(VarscotError) as err:
+            merge_packed_records(ctx, any_shard, broken.ctypes.data, False, all_counts)
+        assert err.value.code == -22 and "exchange records" in str(err.value)
+    merged = merge_packed_records(ctx, any_shard, cat.ctypes.data, False, all_counts)  # the context is fine afterwards
+    assert merged.to_numpy().tobytes() == want.tobytes()
+    merged.close()
     any_shard.close()
 
 

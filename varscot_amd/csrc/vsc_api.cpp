@@ -1622,7 +1622,7 @@ int vsc_hits_merge_packed(vsc_ctx *ctx, const vsc_genome *genome, const void *re
     auto step = [&](hipError_t r) {
         if (e == hipSuccess) e = r;
     };
-    const size_t tab_bytes = n_segs * (2 * sizeof(uint64_t) + sizeof(uint32_t));
+    const size_t tab_bytes = n_segs * (2 * sizeof(uint64_t) + sizeof(uint32_t)) + 2 * sizeof(uint32_t);
     step(ctx->keys_b.ensure(tab_bytes));
     step(take_records(ctx, hits, n));
     const uint64_t *records_dev = (const uint64_t *)records;
@@ -1633,17 +1633,26 @@ int vsc_hits_merge_packed(vsc_ctx *ctx, const vsc_genome *genome, const void *re
     }
     uint64_t *d_src = (uint64_t *)ctx->keys_b.p, *d_dst = d_src + n_segs;
     uint32_t *d_n = (uint32_t *)(d_dst + n_segs);
+    uint32_t *d_bad = d_n + n_segs;  // records whose position lies in no contig or that descend inside a segment
+    uint32_t n_bad = 0;
     if (e == hipSuccess) {
         step(hipMemcpyAsync(d_src, seg_src.data(), n_segs * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
         step(hipMemcpyAsync(d_dst, seg_dst.data(), n_segs * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
         step(hipMemcpyAsync(d_n, seg_n.data(), n_segs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        step(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream));
         step(launch_merge_packed(records_dev, d_src, d_dst, d_n, (uint32_t)n_segs, n_shards, first_key, genome->d_contig_off,
-                                 genome->n_contigs, hits->d_records, ctx->stream));
+                                 genome->d_contig_end, genome->n_contigs, hits->d_records, d_bad, ctx->stream));
+        step(hipMemcpyAsync(&n_bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         step(hipStreamSynchronize(ctx->stream));  // (the host tables go out of scope)
     }
     if (e != hipSuccess) {
         vsc_hits_free(hits);
         return fail(ctx, e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, "vsc_hits_merge_packed", e);
+    }
+    if (n_bad) {  // what a peer or the caller sent is not a sorted shard result of this genome
+        vsc_hits_free(hits);
+        return fail(ctx, VSC_ERR_INVALID, ("vsc_hits_merge_packed: " + std::to_string(n_bad) +
+                    " exchange records lie in no contig of the genome or descend inside their (key, shard) segment").c_str());
     }
     *out = hits;
     return VSC_OK;

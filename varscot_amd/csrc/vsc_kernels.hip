@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256) void xpack_kernel(const vsc_hit *in, uint64_t 
 // vsc_hit records [seg_dst, ...) of `out` with guide / strand of key first_key + k
 __global__ __launch_bounds__(256) void merge_packed_kernel(const uint64_t *in, const uint64_t *seg_src, const uint64_t *seg_dst,
                                                            const uint32_t *seg_n, uint32_t n_shards, uint32_t first_key,
-                                                           const uint32_t *contig_off, uint32_t n_contigs, vsc_hit *out)
+                                                           const uint32_t *contig_off, const uint32_t *contig_end, uint32_t n_contigs,
+                                                           vsc_hit *out, uint32_t *bad)
 {
     const uint32_t seg = blockIdx.x;
     const uint32_t n = seg_n[seg];
@@ -400,13 +401,16 @@ __global__ __launch_bounds__(256) void merge_packed_kernel(const uint64_t *in, c
     uint4 *o = (uint4 *)out;
     // A segment's records ascend in position, and so do the records a thread takes (every blockDim-th): the contig of
     // a record is found by one binary search for the thread's first record and a forward walk from there on (a few
-    // contigs per segment: the walk almost never moves).
-    uint32_t c = 0, c_start = 0, c_next = 0;
+    // contigs per segment: the walk almost never moves).  The records come from a peer or from the caller: one whose
+    // window lies in no contig, or that descends, is counted in *bad (the host refuses the result) and the walk is
+    // bounded by the contig table whatever the position says.
+    uint32_t c = 0, c_start = 0, c_next = 0, prev = 0, n_bad = 0;
     bool placed = false;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         const uint64_t x = in[src + i];
         const uint32_t gpos = (uint32_t)(x >> kRecPosShift), mask = (uint32_t)x & kMask23;
-        if (!placed) {
+        if (!placed || gpos < prev) {
+            n_bad += placed;  // descending inside a segment
             uint32_t lo = 0, hi = n_contigs;  // last contig that starts at or before gpos
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
@@ -417,13 +421,16 @@ __global__ __launch_bounds__(256) void merge_packed_kernel(const uint64_t *in, c
             c_start = contig_off[c];
             c_next = c + 1 < n_contigs ? contig_off[c + 1] : 0xFFFFFFFFu;
         }
-        while (gpos >= c_next) {  // (c_next = 2^32 - 1 behind the last contig: positions stay below it)
+        prev = gpos;
+        while (c + 1 < n_contigs && gpos >= c_next) {
             ++c;
             c_start = c_next;
             c_next = c + 1 < n_contigs ? contig_off[c + 1] : 0xFFFFFFFFu;
         }
+        n_bad += gpos < c_start || (uint64_t)gpos + VSC_READ_LEN > contig_end[c];
         o[dst + i] = make_uint4(key >> 1, c, gpos - c_start, ((key & 1u) << 31) | ((uint32_t)__popc(mask) << 23) | mask);
     }
+    if (n_bad) atomicAdd(bad, n_bad);
 }
 
 hipError_t launch_xpack(const vsc_hit *in, uint64_t n, const uint32_t *contig_off, uint64_t *out, hipStream_t stream)
@@ -440,12 +447,12 @@ hipError_t launch_key_bounds(const vsc_hit *in, const uint64_t *range_dev, uint3
 }
 
 hipError_t launch_merge_packed(const uint64_t *in, const uint64_t *seg_src, const uint64_t *seg_dst, const uint32_t *seg_n,
-                               uint32_t n_segs, uint32_t n_shards, uint32_t first_key, const uint32_t *contig_off, uint32_t n_contigs,
-                               vsc_hit *out, hipStream_t stream)
+                               uint32_t n_segs, uint32_t n_shards, uint32_t first_key, const uint32_t *contig_off,
+                               const uint32_t *contig_end, uint32_t n_contigs, vsc_hit *out, uint32_t *bad, hipStream_t stream)
 {
     if (n_segs == 0) return hipSuccess;
     hipLaunchKernelGGL(merge_packed_kernel, dim3(n_segs), dim3(256), 0, stream, in, seg_src, seg_dst, seg_n, n_shards, first_key,
-                       contig_off, n_contigs, out);
+                       contig_off, contig_end, n_contigs, out, bad);
     return hipGetLastError();
 }
 
