@@ -144,6 +144,81 @@ def test_variant_aware_pipeline(scenario):
     assert any(r.split("\t")[-1].startswith("VAR_") for r in rows) and any(r.split("\t")[-1] == "REF" for r in rows)
 
 
+def test_mergers_take_reference_bases_from_the_packed_genomes(scenario):
+    """The mergers with the packed genomes of `bidir_index` in place of the two FASTA files they are given (reference:
+    VARSCOT_PACKED_GENOME, SNP genome: VARSCOT_PACKED_SNP_GENOME - what the driver exports): the hit sequences, the on-target
+    sequences and the windows of the shadow filter come from <prefix>.vsc; result and feature matrix are the restatement's."""
+    d, records, bed, tus, targets = scenario
+    run("vcf_loader", d / "in.vcf", d / "snp.fa", d / "genome.fa", 0, 23, 4)
+    run("bidir_index", "-G", d / "genome.fa", "-I", d / "ref_idx")
+    run("bidir_index", "-G", d / "snp.fa", "-I", d / "snp_idx")
+    run("bidir_mapping", "-G", d / "genome.fa", "-I", d / "ref_idx", "-R", d / "targets.fa", "-M", 5, "-O", d / "ref.sam")
+    run("bidir_mapping", "-G", d / "snp.fa", "-I", d / "snp_idx", "-R", d / "targets.fa", "-M", 5, "-O", d / "snp.sam")
+    env = dict(os.environ, VARSCOT_TRACE="1", VARSCOT_PACKED_GENOME=str(d / "ref_idx"), VARSCOT_PACKED_SNP_GENOME=str(d / "snp_idx"))
+    ref_sam, snp_sam = (d / "ref.sam").read_text(), (d / "snp.sam").read_text()
+    snp_records = read_fasta(d / "snp.fa")
+    r = subprocess.run([os.path.join(BIN, "bam_merger"), str(d / "pm.txt"), str(d / "pmf.txt"), str(d / "ref.sam"), str(d / "snp.sam"),
+                        str(d / "targets.bed"), str(d / "genome.fa"), str(d / "snp.fa"), str(d / "activity.txt"), "5", "23", "4", "1"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stderr.count("from the packed genome") == 2 and "FASTA text" not in r.stderr
+    want_tsv, want_fm = mo.merge_results(ref_sam, snp_sam, bed, records, snp_records, tus, 23, True)
+    assert (d / "pm.txt").read_text() == want_tsv and (d / "pmf.txt").read_text() == want_fm
+    r = subprocess.run([os.path.join(BIN, "bam_merger_ref_only"), str(d / "pr.txt"), str(d / "prf.txt"), str(d / "ref.sam"),
+                        str(d / "targets.bed"), str(d / "genome.fa"), str(d / "activity.txt"), "5", "23", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and r.stderr.count("from the packed genome") == 1, r.stdout + r.stderr
+    assert (d / "pr.txt").read_text() == mo.process_ref_only(ref_sam, bed, records, tus, False)[0]
+
+
+@pytest.mark.parametrize("evaluation", ["mit", "prob", "class"])
+def test_driver_in_one_process_equals_the_staged_tools(scenario, tmp_path, evaluation):
+    """The driver's default route (varscot_pipeline: on-targets from the packed genome, search, windows straight from the planes,
+    merge, scores, forest and the final sort in ONE process - no SAM text, no SNP-genome FASTA, no feature matrix parsed back)
+    against the staged route (VARSCOT_STAGED=1: fasta_writer | bidir_mapping | vcf_loader | bidir_index | bidir_mapping |
+    bam_merger[_ref_only] | classification_pipeline | sort, as VARSCOT:260-357 chains them): result and feature matrix byte for
+    byte, without a VCF, with one sample column and with two."""
+    d, records, bed, tus, targets = scenario
+    driver = os.path.join(ROOT, "varscot_amd", "driver", "VARSCOT")
+    lines, k = [], 0
+    other = ["0|0", "1|1", "0|1", "1|0", "./.", "1/1"]
+    for l in (d / "in.vcf").read_text().splitlines():
+        if l.startswith("##"):
+            lines.append(l)
+        elif l.startswith("#CHROM"):
+            lines.append(l + "\tS1")
+        else:
+            lines.append(l + "\t" + other[k % len(other)])
+            k += 1
+    vcf2 = tmp_path / "two.vcf"
+    vcf2.write_text("\n".join(lines) + "\n")
+    for case, extra in (("ref", []), ("one", ["-f", str(d / "in.vcf"), "-s", "0"]), ("two", ["-f", str(vcf2), "-s", "all"]), ("pam", ["-p", "AG"])):
+        got = {}
+        for route in ("inproc", "staged"):
+            out = tmp_path / ("%s_%s.txt" % (case, route))
+            cmd = ["bash", driver, "-b", str(d / "targets.bed"), "-o", str(out), "-g", str(d / "genome.fa"), "-i", str(tmp_path / "idx"),
+                   "-m", "5", "-t", "2", "-T", str(tmp_path / ("tmp_" + route)), "-a", str(d / "activity.txt"), "-e", evaluation] + extra
+            env = dict(os.environ)
+            if route == "staged":
+                env["VARSCOT_STAGED"] = "1"
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0, r.stdout + r.stderr
+            stems = ["%s_sample%d" % (str(out)[:-4], k) for k in (0, 1)] if case == "two" else [str(out)[:-4]]
+            files = {}
+            for stem in stems:
+                files[os.path.basename(stem).replace(route, "")] = open(stem + ".txt", "rb").read()
+                if evaluation != "mit":
+                    files[os.path.basename(stem).replace(route, "") + "_fm"] = open(stem + "_feature_matrix.txt", "rb").read()
+                else:
+                    assert not os.path.exists(stem + "_feature_matrix.txt")
+            got[route] = files
+        assert got["inproc"] == got["staged"], case
+        first = next(iter(got["inproc"].values())).decode().splitlines()
+        assert len(first) > 20 and first[0].split("\t")[3] == ("Targetsite" if evaluation == "mit" else "Name")
+        if case != "ref" and case != "pam":
+            assert any(l.endswith("REF") for l in first[1:]) and any("VAR_" in l.split("\t")[-1] for l in first[1:])
+
+
 def test_driver_end_to_end(scenario, tmp_path):
     """The VARSCOT driver (same flags as the reference's) over the drop-in tools, with and without a
     VCF; its TSV must equal the merger's rows sorted on the name column."""

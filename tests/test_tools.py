@@ -47,6 +47,63 @@ def test_bidir_index_cli(workdir):
     assert run("bidir_index", "--help").returncode == 0
 
 
+def test_tools_take_reference_bases_from_the_packed_genome(workdir):
+    """`fasta_writer` and `vcf_loader` read their reference bases from <prefix>.vsc (a few mapped pages
+    per region, the part the .fai index plays in the reference: extract_fasta_ontargets.h:33-76, write_fasta.h:245-271) when it
+    was packed from the FASTA they are given - found through VARSCOT_PACKED_GENOME, as <fasta>.vsc or as <fasta minus its
+    extension>.vsc - and from the FASTA text otherwise (no packed genome, or one whose FASTA has changed since).  Same output
+    files every way: lower-case and IUPAC letters, flanks that run over a contig end, '-' records."""
+    import shutil
+    d, names, contigs, gnames, guides = workdir
+    # a genome with soft-masked and ambiguous stretches, ids with descriptions
+    seqs = [contigs[0][:300] + contigs[0][300:600].lower() + "RYKM" + contigs[0][604:], contigs[1], contigs[2], contigs[3]]
+    write_fasta(d / "g.fa", names, seqs)
+    bed = ("chr1\t500\t523\tt0\t0\t+\nchr1\t2\t25\tt1\t0\t-\nchr2\t4977\t5000\tt2\t0\t+\ntiny\t3\t26\tt3\t0\t-\n"
+           "chrUn_gl000220\t590\t613\tt4\t0\t+\nchr1\t590\t613\tt5\t0\t-\n")
+    (d / "t.bed").write_text(bed)
+    vcf = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n"
+    for c, name in ((0, "chr1"), (1, "chr2"), (3, "chrUn_gl000220")):
+        for pos in (7, 310, 598, 603, 1200, len(seqs[c]) - 5):
+            ref = seqs[c][pos - 1].upper()
+            if ref in "ACGT":
+                vcf += "%s\t%d\t.\t%s\t%s\t.\t.\t.\tGT\t0|1\n" % (name, pos, ref, "A" if ref != "A" else "C")
+    (d / "v.vcf").write_text(vcf)
+
+    def outputs(env, tag):
+        e = dict(os.environ, VARSCOT_TRACE="1", **env)
+        r1 = subprocess.run([os.path.join(BIN, "fasta_writer"), str(d / ("o1_%s.fa" % tag)), str(d / ("o2_%s.fa" % tag)), str(d / "t.bed"),
+                             str(d / "g.fa")], capture_output=True, text=True, env=e)
+        r2 = subprocess.run([os.path.join(BIN, "vcf_loader"), str(d / "v.vcf"), str(d / ("snp_%s.fa" % tag)), str(d / "g.fa"), "0", "23", "2"],
+                            capture_output=True, text=True, env=e)
+        assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr + r1.stdout + r2.stdout
+        return [(d / (n % tag)).read_bytes() for n in ("o1_%s.fa", "o2_%s.fa", "snp_%s.fa")], r1.stderr + r2.stderr
+
+    text, trace = outputs({}, "text")
+    assert trace.count("from the FASTA text") == 2 and len(text[2]) > 500
+    assert run("bidir_index", "-G", str(d / "g.fa"), "-I", str(d / "pk")).returncode == 0
+    packed, trace = outputs({"VARSCOT_PACKED_GENOME": str(d / "pk")}, "env")
+    assert trace.count("from the packed genome") == 2 and packed == text
+    shutil.copy(d / "pk.vsc", d / "g.fa.vsc")          # sidecar next to the FASTA
+    side, trace = outputs({}, "side")
+    assert trace.count("from the packed genome") == 2 and side == text
+    os.remove(d / "g.fa.vsc")
+    shutil.copy(d / "pk.vsc", d / "g.vsc")             # the FASTA's name with .vsc in place of its extension
+    side, trace = outputs({}, "stem")
+    assert trace.count("from the packed genome") == 2 and side == text
+    os.remove(d / "g.vsc")
+    # the FASTA changes after packing (one base; the size stays): the packed genome is no longer taken
+    seqs[0] = seqs[0][:511] + ("A" if seqs[0][511] != "A" else "C") + seqs[0][512:]
+    write_fasta(d / "g.fa", names, seqs)
+    os.utime(d / "g.fa", ns=(os.stat(d / "g.fa").st_atime_ns, os.stat(d / "g.fa").st_mtime_ns + 5_000_000_000))
+    stale, trace = outputs({"VARSCOT_PACKED_GENOME": str(d / "pk")}, "stale")
+    assert "not used" in trace and trace.count("from the FASTA text") == 2
+    assert stale[0] != text[0] and stale[0] == outputs({}, "text2")[0][0]
+    # an index file of the older layout (no source stamp) is still read by bidir_mapping's loader, but stands for no FASTA
+    import varscot_amd as va
+    pg = va.PackedGenome.from_index_file(str(d / "pk"))
+    assert pg.names == names and pg.contig_sequence(1) == contigs[1]
+
+
 def test_bidir_mapping_cli_errors(workdir):
     d, *_ = workdir
     run("bidir_index", "-G", str(d / "genome.fa"), "-I", str(d / "idx"))

@@ -67,13 +67,19 @@ class PackedGenome:
     def from_index_file(cls, prefix):
         """Reads <prefix>.vsc as written by the bidir_index tool (tools/vsc_host.hpp)."""
         with open(prefix + ".vsc", "rb") as f:
-            assert f.read(8) == b"VSCIDX01", "not a packed genome"
+            magic = f.read(8)
+            assert magic in (b"VSCIDX01", b"VSCIDX02"), "not a packed genome"
             nc, nw = (int(x) for x in np.frombuffer(f.read(16), dtype="<u8"))
+            if magic == b"VSCIDX02":
+                f.read(16)  # size and modification time of the FASTA it was packed from
             table = np.frombuffer(f.read(nc * CONTIG_DTYPE.itemsize), dtype=CONTIG_DTYPE).copy()
-            names = []
+            names, name_bytes = [], 0
             for _ in range(nc):
                 ln = int(np.frombuffer(f.read(4), dtype="<u4")[0])
                 names.append(f.read(ln).decode())
+                name_bytes += 4 + ln
+            if magic == b"VSCIDX02":
+                f.read((8 - name_bytes % 8) % 8)  # the planes start 8-byte aligned
             hi = np.frombuffer(f.read(nw * 4), dtype="<u4").copy()
             lo = np.frombuffer(f.read(nw * 4), dtype="<u4").copy()
             nm = np.frombuffer(f.read(nw * 4), dtype="<u4").copy()

@@ -31,9 +31,9 @@ int main(int argc, char **argv)
         }
     const unsigned seq_len = vals[1], mit = vals[3];
     try {
-        const Genome snp(argv[7]);
+        const Genome snp(argv[7], "VARSCOT_PACKED_SNP_GENOME");
         const Genome ref(argv[6]);
-        const WindowIndex windows(snp.recs);  // getSnpInfoTable + sortSnpRegionsByChr
+        const WindowIndex windows(snp);  // getSnpInfoTable + sortSnpRegionsByChr
         std::map<std::string, OffTarget> on;
         std::map<std::string, unsigned> count;
         read_ontargets(argv[5], ref, on, count);

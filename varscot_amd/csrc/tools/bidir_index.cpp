@@ -37,7 +37,10 @@ int main(int argc, char **argv)
             std::fprintf(stderr, "ERROR: the FASTA file may not contain more than 4 giga bases in total.\n");
             return 1;
         }
-        const PackedIndex ix = pack_records(recs);
+        PackedIndex ix = pack_records(recs);
+        // the FASTA this was packed from: the other tools take their reference bases from <prefix>.vsc instead of parsing the
+        // FASTA again as long as size and modification time still match (vsc_host.hpp, open_packed_for)
+        (void)file_stamp(genome, &ix.src_size, &ix.src_mtime);
         write_index(prefix, ix);
         // a seed index file of an earlier genome under this prefix must not outlive the planes it was built from
         // (bidir_mapping loads <prefix>.vsi whenever it exists; -S below writes the new one)

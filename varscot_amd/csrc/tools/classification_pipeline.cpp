@@ -17,47 +17,10 @@
 
 #include <unistd.h>
 
+#include "forest_host.hpp"
 #include "merge_host.hpp"
 
-struct Forest {
-    uint32_t n_trees = 0, n_nodes = 0;
-    std::vector<std::string> names;
-    std::vector<int8_t> status;
-    std::vector<uint8_t> best_var, node_class;
-    std::vector<uint16_t> left, right, feature;
-    std::vector<double> split;
-};
-
-static Forest load_forest(const std::string &path)
-{
-    std::ifstream in(path, std::ios::binary);
-    if (!in) throw std::runtime_error("Error: could not open the classifier " + path);
-    char magic[8];
-    uint32_t hdr[3];
-    in.read(magic, 8);
-    in.read((char *)hdr, 12);
-    if (!in || std::memcmp(magic, "VSCRF001", 8) != 0) throw std::runtime_error("Error: " + path + " is not a forest file");
-    Forest f;
-    f.n_trees = hdr[0];
-    f.n_nodes = hdr[1];
-    f.names.resize(hdr[2]);
-    for (auto &n : f.names) {
-        uint16_t l = 0;
-        in.read((char *)&l, 2);
-        n.resize(l);
-        in.read(&n[0], l);
-    }
-    const size_t n = (size_t)f.n_trees * f.n_nodes;
-    f.status.resize(n), f.best_var.resize(n), f.left.resize(n), f.right.resize(n), f.split.resize(n), f.node_class.resize(n);
-    in.read((char *)f.status.data(), n);
-    in.read((char *)f.best_var.data(), n);
-    in.read((char *)f.left.data(), 2 * n);
-    in.read((char *)f.right.data(), 2 * n);
-    in.read((char *)f.split.data(), 8 * n);
-    in.read((char *)f.node_class.data(), n);
-    if (!in) throw std::runtime_error("Error: truncated forest file " + path);
-    return f;
-}
+using vsc_forest::Forest;
 
 static std::vector<std::string> split_tabs(const std::string &line)
 {
@@ -81,15 +44,7 @@ int main(int argc, char **argv)
     }
     try {
         const bool prob = std::string(argv[3]) == "TRUE" || std::string(argv[3]) == "true" || std::string(argv[3]) == "T";
-        std::string model = std::getenv("VARSCOT_RF_MODEL") ? std::getenv("VARSCOT_RF_MODEL") : "";
-        if (model.empty()) {
-            char exe[4096];
-            ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
-            std::string dir = n > 0 ? std::string(exe, (size_t)n) : std::string(argv[0]);
-            dir = dir.substr(0, dir.find_last_of('/'));
-            model = dir + "/../models/rfClassifier.vscrf";
-        }
-        Forest forest = load_forest(model);
+        Forest forest = vsc_forest::load_forest(vsc_forest::default_model_path(argv[0]));
 
         // feature matrix: header with 443 names, then row name + 442 integers + activity
         std::ifstream fin(argv[2]);
@@ -101,17 +56,7 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < header.size(); ++i) col[header[i]] = i;
         if (header.size() != VSC_N_FEATURES + 1 || !col.count("ontargetActivity"))
             throw std::runtime_error("Error: the feature matrix does not have the 443 expected columns");
-        const auto names = vsc_merge::feature_names();
-        forest.feature.assign(forest.status.size(), 0);
-        std::vector<uint16_t> col_of_var(forest.names.size());
-        for (size_t v = 0; v < forest.names.size(); ++v) {
-            size_t c = 0;
-            while (c < names.size() && names[c] != forest.names[v]) ++c;
-            if (c == names.size() || !col.count(forest.names[v])) throw std::runtime_error("Error: variables in the training data missing in newdata");
-            col_of_var[v] = (uint16_t)c;
-        }
-        for (size_t i = 0; i < forest.status.size(); ++i)
-            if (forest.best_var[i]) forest.feature[i] = col_of_var[forest.best_var[i] - 1];
+        vsc_forest::bind_features(forest, [&](const std::string &name) { return col.count(name) != 0; });
         // the rows: name, 442 small integers, activity.  Read in pieces that end at a line break, every piece parsed
         // by all host threads (a stream-and-split loop took 12 s for 2.6 M rows)
         std::vector<uint8_t> feat;
@@ -206,8 +151,7 @@ int main(int argc, char **argv)
             vsc_ctx *ctx = nullptr;
             int st = vsc_ctx_create(0, &ctx);
             if (st != VSC_OK) throw std::runtime_error(st == VSC_ERR_NODEVICE ? "Error: no HIP device available (there is no CPU fallback)." : "Error: could not create the device context.");
-            vsc_rf_model m{forest.n_trees, forest.n_nodes, forest.status.data(), forest.feature.data(), forest.left.data(),
-                           forest.right.data(), forest.split.data(), forest.node_class.data()};
+            const vsc_rf_model m = vsc_forest::model_of(forest);
             st = vsc_rf_predict(ctx, &m, feat.data(), act.data(), n, p.data(), cls.data(), tie.data());
             const std::string err = st == VSC_OK ? "" : vsc_last_error(ctx);
             vsc_ctx_destroy(ctx);

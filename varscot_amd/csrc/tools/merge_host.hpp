@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -37,39 +38,63 @@ inline bool same(const OffTarget &a, const OffTarget &b)  // comp(), :40-49
            a.mm == b.mm && a.snp_type == b.snp_type;
 }
 
-// Sequences of a FASTA addressable by full id and by first word (FAI rule).
+inline void revcomp_in_place(std::string &s)
+{
+    std::reverse(s.begin(), s.end());
+    for (auto &c : s) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+}
+
+// Sequences of a FASTA addressable by full id and by first word (FAI rule).  The bases come from the packed genome that
+// stands for the FASTA when there is one (<prefix>.vsc of `bidir_index`, found by vsc_host::open_packed_for: a few mapped
+// pages per region) - the part the FAI index plays in the reference (extract_fasta_ontargets.h:33-76,
+// filter_output_bam.h:399) - and from the parsed FASTA text otherwise; same answers either way.
 struct Genome {
-    std::vector<vsc_host::FastaRecord> recs;
+    std::vector<vsc_host::FastaRecord> recs;  // text backend
+    vsc_host::PackedView packed;              // packed backend
+    bool from_packed = false;
     std::unordered_map<std::string, size_t> by_name;
-    explicit Genome(const std::string &path) : recs(vsc_host::read_fasta(path))
+    explicit Genome(const std::string &path, const char *packed_env = "VARSCOT_PACKED_GENOME")
     {
-        for (size_t i = 0; i < recs.size(); ++i) {
-            by_name.emplace(recs[i].id, i);
-            by_name.emplace(recs[i].id.substr(0, recs[i].id.find_first_of(" \t")), i);
+        from_packed = vsc_host::open_packed_for(path, packed_env, packed);
+        if (!from_packed) recs = vsc_host::read_fasta(path);
+        by_name.reserve(2 * size());
+        for (size_t i = 0; i < size(); ++i) {
+            const std::string &name = id(i);
+            by_name.emplace(name, i);
+            by_name.emplace(name.substr(0, name.find_first_of(" \t")), i);
         }
     }
+    size_t size() const { return from_packed ? packed.names.size() : recs.size(); }
+    const std::string &id(size_t i) const { return from_packed ? packed.names[i] : recs[i].id; }
+    uint64_t length(size_t i) const { return from_packed ? packed.contigs[i].length : recs[i].seq.size(); }
     // extractSequenceFromIndex(..., flanking = false), extract_fasta_ontargets.h:33-76
     std::string region(const std::string &chr, uint32_t start, uint32_t end, char strand) const
     {
         auto it = by_name.find(chr);
         if (it == by_name.end()) throw std::out_of_range("ERROR: Index out of range.");
-        const std::string &s = recs[it->second].seq;
-        uint64_t b = std::min<uint64_t>(start, s.size()), e = std::min<uint64_t>(end, s.size());
+        return region_at(it->second, start, end, strand);
+    }
+    std::string region_at(size_t contig, uint32_t start, uint32_t end, char strand) const
+    {
+        const uint64_t len = length(contig);
+        uint64_t b = std::min<uint64_t>(start, len), e = std::min<uint64_t>(end, len);
         if (b > e) e = b;
-        std::string out = s.substr(b, e - b);
-        for (auto &c : out) {
-            switch (c) {
-            case 'A': case 'a': c = 'A'; break;
-            case 'C': case 'c': c = 'C'; break;
-            case 'G': case 'g': c = 'G'; break;
-            case 'T': case 't': c = 'T'; break;
-            default: c = 'N';
+        std::string out;
+        if (from_packed) {
+            out = packed.bases((uint32_t)contig, b, e - b);
+        } else {
+            out = recs[contig].seq.substr(b, e - b);
+            for (auto &c : out) {
+                switch (c) {
+                case 'A': case 'a': c = 'A'; break;
+                case 'C': case 'c': c = 'C'; break;
+                case 'G': case 'g': c = 'G'; break;
+                case 'T': case 't': c = 'T'; break;
+                default: c = 'N';
+                }
             }
         }
-        if (strand == '-') {
-            std::reverse(out.begin(), out.end());
-            for (auto &c : out) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
-        }
+        if (strand == '-') revcomp_in_place(out);
         return out;
     }
 };
@@ -187,17 +212,23 @@ struct WindowIndex {
         std::vector<int64_t> start, max_end;
     };
     std::unordered_map<std::string, Chr> chrs;
-    explicit WindowIndex(const std::vector<vsc_host::FastaRecord> &snp)
+    // the windows: id(i) = chr_start_..., length(i) = bases of the FASTA record (:443)
+    template <class Id, class Len> WindowIndex(size_t n, Id &&id, Len &&length)
     {
         std::unordered_map<std::string, std::vector<std::pair<int64_t, int64_t>>> tmp;
-        for (const auto &r : snp) {
-            const auto parts = split_id(r.id);
-            if (parts.size() < 2) continue;
-            const int s = c_atoi(parts[1]);
+        for (size_t i = 0; i < n; ++i) {
+            // chr = the id up to its first '_', start = the number behind it (split on '_', :292,441)
+            size_t len = 0;
+            const char *name = id(i, &len);
+            const char *u1 = (const char *)std::memchr(name, '_', len);
+            if (!u1) continue;
+            const char *rest = u1 + 1, *const end = name + len;
+            const char *u2 = (const char *)std::memchr(rest, '_', (size_t)(end - rest));
+            const int s = c_atoi(std::string(rest, u2 ? u2 : end));
             // `pos >= atoi(start)` (:102) compares unsigned with int: a negative start (a window whose
             // start wrapped around the contig start) is huge as unsigned and never <= pos
             if (s < 0) continue;
-            tmp[parts[0]].push_back({(int64_t)s, (int64_t)s + (int64_t)r.seq.size()});
+            tmp[std::string(name, u1)].push_back({(int64_t)s, (int64_t)s + (int64_t)length(i)});
         }
         for (auto &kv : tmp) {
             std::sort(kv.second.begin(), kv.second.end());
@@ -210,6 +241,11 @@ struct WindowIndex {
             }
             chrs.emplace(kv.first, std::move(c));
         }
+    }
+    explicit WindowIndex(const Genome &snp)
+        : WindowIndex(snp.size(), [&](size_t i, size_t *len) { *len = snp.id(i).size(); return snp.id(i).data(); },
+                      [&](size_t i) { return snp.length(i); })
+    {
     }
     bool shadows(const std::string &chr, uint32_t pos, unsigned seq_len) const
     {
@@ -305,17 +341,34 @@ inline std::vector<std::string> feature_names()
     return n;
 }
 
+// What write_outputs may do beyond the two mergers' own output (all off by default = exactly the mergers' files):
+struct OutputOptions {
+    vsc_ctx *ctx = nullptr;  // score on this context (the caller's) instead of one created on `device` for the call
+    // the random forest instead of "." in the Score column - what `classification_pipeline OUT FEATURES TRUE|FALSE` does to
+    // the merger's files afterwards (classification/classificationPipeline.R:21-49): header "Name" instead of "Targetsite",
+    // Score = probability of class "1" (prob) or the class
+    const vsc_rf_model *forest = nullptr;
+    bool prob = false;
+    // rows in the order of the name column, byte-wise - what the driver's `LC_ALL=C sort -t TAB -k4,4` leaves (VARSCOT:355-357);
+    // the feature matrix keeps the merge order
+    bool sort_by_name = false;
+};
+
 // Scores rows on the GPU and writes TSV (+ feature matrix) text.  `merged` selects the 10-column
 // layout of mergeResults (Variants column) over the 9-column one of processRefOnly.
 inline void write_outputs(const std::string &out_path, const std::string *feature_path, bool merged,
                           const std::vector<const OffTarget *> &rows, const std::map<std::string, OffTarget> &on,
-                          std::map<std::string, unsigned> &count, const std::map<std::string, double> &activity, int device)
+                          std::map<std::string, unsigned> &count, const std::map<std::string, double> &activity, int device,
+                          const OutputOptions &opt = OutputOptions())
 {
     std::ofstream out(out_path);
     std::ofstream fout;
     if (feature_path) fout.open(*feature_path);
     if (!out.is_open() || (feature_path && !fout.is_open())) throw std::runtime_error("ERROR: Could not open output file.");
-    out << "#Chr\tStart\tEnd\tTargetsite\tScore\tStrand\tSequence\tMismatch_Number\tMismatch_Positions" << (merged ? "\tVariants\n" : "\n");
+    if (opt.forest && !feature_path) throw std::runtime_error("ERROR: the classifier needs the feature matrix.");
+    out << (opt.forest ? "#Chr\tStart\tEnd\tName\tScore\tStrand\tSequence\tMismatch_Number\tMismatch_Positions"
+                       : "#Chr\tStart\tEnd\tTargetsite\tScore\tStrand\tSequence\tMismatch_Number\tMismatch_Positions")
+        << (merged ? "\tVariants\n" : "\n");
     if (feature_path) {
         const auto names = feature_names();
         for (size_t i = 0; i + 1 < names.size(); ++i) fout << names[i] << "\t";
@@ -324,6 +377,12 @@ inline void write_outputs(const std::string &out_path, const std::string *featur
     const size_t n = rows.size();
     std::vector<double> mit(n);
     std::vector<uint8_t> feat(feature_path ? n * VSC_N_FEATURES : 0);
+    std::unordered_map<std::string, std::string> activity_text;
+    if (feature_path)
+        for (size_t i = 0; i < n; ++i)
+            if (!activity_text.count(rows[i]->target)) activity_text[rows[i]->target] = fmt_double(activity.at(rows[i]->target));
+    std::vector<double> forest_prob;
+    std::vector<uint8_t> forest_cls;
     if (n) {
         std::vector<uint64_t> on_codes(n), off_codes(n);
         std::vector<uint32_t> masks(n);
@@ -339,13 +398,25 @@ inline void write_outputs(const std::string &out_path, const std::string *featur
             off_codes[i] = vsc_pack_guide(b.c_str());
             masks[i] = mm_mask(p);
         }
-        vsc_ctx *ctx = nullptr;
-        int st = vsc_ctx_create(device, &ctx);
+        vsc_ctx *ctx = opt.ctx;
+        int st = VSC_OK;
+        if (!ctx) st = vsc_ctx_create(device, &ctx);
         if (st != VSC_OK) throw std::runtime_error(st == VSC_ERR_NODEVICE ? "ERROR: no HIP device available (there is no CPU fallback)." : "ERROR: could not create the device context.");
         st = vsc_score_pairs(ctx, on_codes.data(), off_codes.data(), masks.data(), n, feature_path ? nullptr : mit.data(), nullptr,
                              feature_path ? feat.data() : nullptr);
+        if (st == VSC_OK && opt.forest) {
+            // the activity the classifier sees is the one the feature matrix carries: six significant digits
+            std::vector<double> act(n);
+            std::unordered_map<std::string, double> rounded;
+            for (const auto &kv : activity_text) rounded[kv.first] = std::strtod(kv.second.c_str(), nullptr);
+            for (size_t i = 0; i < n; ++i) act[i] = rounded.at(rows[i]->target);
+            forest_prob.resize(n);
+            forest_cls.resize(n);
+            std::vector<uint8_t> tie(n);
+            st = vsc_rf_predict(ctx, opt.forest, feat.data(), act.data(), n, forest_prob.data(), forest_cls.data(), tie.data());
+        }
         const std::string err = st == VSC_OK ? "" : vsc_last_error(ctx);
-        vsc_ctx_destroy(ctx);
+        if (!opt.ctx) vsc_ctx_destroy(ctx);
         if (st != VSC_OK) throw std::runtime_error("ERROR: " + err);
     }
     // Text: the names carry running numbers per target (sequential), the rows themselves are formatted in blocks
@@ -353,37 +424,56 @@ inline void write_outputs(const std::string &out_path, const std::string *featur
     // took 20 s for 2.6 M rows.
     std::vector<uint32_t> number(n);
     for (size_t i = 0; i < n; ++i) number[i] = ++count.at(rows[i]->target);
-    std::unordered_map<std::string, std::string> activity_text;
-    if (feature_path)
-        for (size_t i = 0; i < n; ++i)
-            if (!activity_text.count(rows[i]->target)) activity_text[rows[i]->target] = fmt_double(activity.at(rows[i]->target));
     char small[256][4];  // "0" .. "255"
     uint8_t small_len[256];
     for (int v = 0; v < 256; ++v) small_len[v] = (uint8_t)std::snprintf(small[v], sizeof small[v], "%d", v);
-    auto format_block = [&](size_t b, size_t e, std::string &tsv, std::string &fm) {
+    auto score_text = [&](size_t i) -> std::string {
+        if (opt.forest) {
+            if (!opt.prob) return forest_cls[i] ? "1" : "0";  // an exact 500/500 vote (R: random) is reported as "0"
+            char buf[64];
+            std::snprintf(buf, sizeof buf, "%.15g", forest_prob[i]);
+            return buf;
+        }
+        return feature_path ? std::string(".") : fmt_double(mit[i]);
+    };
+    auto tsv_row = [&](size_t i, const std::string &name, std::string &tsv) {
+        const OffTarget &p = *rows[i];
+        tsv += p.chr;
+        tsv += '\t';
+        tsv += std::to_string(p.pos);
+        tsv += '\t';
+        tsv += std::to_string(p.pos + 23);
+        tsv += '\t';
+        tsv += name;
+        tsv += '\t';
+        tsv += score_text(i);
+        tsv += '\t';
+        tsv += p.strand;
+        tsv += '\t';
+        tsv += p.sequence;
+        tsv += '\t';
+        tsv += mm_columns(p, merged);
+        if (merged) tsv += p.snp_type;
+        tsv += '\n';
+    };
+    // sorted output: every row's text is kept, with where its name starts and ends (the sort key)
+    struct Placed { uint32_t block; uint32_t begin, name_b, name_e, end; };
+    std::vector<Placed> placed(opt.sort_by_name ? n : 0);
+    auto format_block = [&](size_t b, size_t e, std::string &tsv, std::string &fm, uint32_t block_id) {
         tsv.clear();
         fm.clear();
         if (feature_path) fm.reserve((e - b) * (2 * VSC_N_FEATURES + 64));
         for (size_t i = b; i < e; ++i) {
             const OffTarget &p = *rows[i];
             const std::string name = p.target + "_" + std::to_string(number[i]);
-            tsv += p.chr;
-            tsv += '\t';
-            tsv += std::to_string(p.pos);
-            tsv += '\t';
-            tsv += std::to_string(p.pos + 23);
-            tsv += '\t';
-            tsv += name;
-            tsv += '\t';
-            tsv += feature_path ? std::string(".") : fmt_double(mit[i]);
-            tsv += '\t';
-            tsv += p.strand;
-            tsv += '\t';
-            tsv += p.sequence;
-            tsv += '\t';
-            tsv += mm_columns(p, merged);
-            if (merged) tsv += p.snp_type;
-            tsv += '\n';
+            const size_t at = tsv.size();
+            tsv_row(i, name, tsv);
+            if (opt.sort_by_name) {
+                size_t nb = at;
+                for (int tabs = 0; tabs < 3; ++nb)
+                    if (tsv[nb] == '\t') ++tabs;
+                placed[i] = Placed{block_id, (uint32_t)at, (uint32_t)nb, (uint32_t)(nb + name.size()), (uint32_t)tsv.size()};
+            }
             if (feature_path) {
                 fm += name;
                 fm += '\t';
@@ -399,19 +489,49 @@ inline void write_outputs(const std::string &out_path, const std::string *featur
     };
     const unsigned n_threads = vsc_host::host_threads();
     const size_t block = 16384;
+    std::vector<std::string> kept;  // sorted output: the TSV text of every block
+    if (opt.sort_by_name) kept.resize((n + block - 1) / block);
     std::vector<std::string> tsv(n_threads), fm(n_threads);
     for (size_t base = 0; base < n; base += block * n_threads) {
         std::vector<std::thread> workers;
         unsigned used = 0;
         for (unsigned t = 0; t < n_threads && base + t * block < n; ++t, ++used) {
             const size_t b = base + t * block, e = std::min(n, b + block);
-            workers.emplace_back(format_block, b, e, std::ref(tsv[t]), std::ref(fm[t]));
+            std::string &dst = opt.sort_by_name ? kept[b / block] : tsv[t];
+            workers.emplace_back(format_block, b, e, std::ref(dst), std::ref(fm[t]), (uint32_t)(b / block));
         }
         for (auto &w : workers) w.join();
         for (unsigned t = 0; t < used; ++t) {
-            out.write(tsv[t].data(), (std::streamsize)tsv[t].size());
+            if (!opt.sort_by_name) out.write(tsv[t].data(), (std::streamsize)tsv[t].size());
             if (feature_path) fout.write(fm[t].data(), (std::streamsize)fm[t].size());
         }
+    }
+    if (opt.sort_by_name) {
+        // `sort -k4,4` under LC_ALL=C: the name field byte-wise, ties (there are none: names are unique) by the whole line
+        std::vector<uint32_t> order(n);
+        for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+        auto key_less = [&](uint32_t x, uint32_t y) {
+            const Placed &a = placed[x], &b = placed[y];
+            const std::string &sa = kept[a.block], &sb = kept[b.block];
+            const size_t la = a.name_e - a.name_b, lb = b.name_e - b.name_b;
+            int c = std::memcmp(sa.data() + a.name_b, sb.data() + b.name_b, std::min(la, lb));
+            if (c == 0 && la != lb) c = la < lb ? -1 : 1;
+            if (c != 0) return c < 0;
+            const size_t ra = a.end - a.begin, rb = b.end - b.begin;
+            c = std::memcmp(sa.data() + a.begin, sb.data() + b.begin, std::min(ra, rb));
+            return c != 0 ? c < 0 : ra < rb;
+        };
+        std::sort(order.begin(), order.end(), key_less);
+        std::string text;
+        for (size_t k = 0; k < n; ++k) {
+            const Placed &a = placed[order[k]];
+            text.append(kept[a.block], a.begin, a.end - a.begin);
+            if (text.size() > ((size_t)32 << 20)) {
+                out.write(text.data(), (std::streamsize)text.size());
+                text.clear();
+            }
+        }
+        out.write(text.data(), (std::streamsize)text.size());
     }
     if (!out || (feature_path && !fout)) throw std::runtime_error("ERROR: Could not write the output file.");
 }

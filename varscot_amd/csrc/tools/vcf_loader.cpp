@@ -8,6 +8,7 @@
 #include <fstream>
 #include <iostream>
 
+#include "merge_host.hpp"
 #include "vcf_expand.hpp"
 #include "vsc_host.hpp"
 
@@ -42,19 +43,10 @@ int main(int argc, char **argv)
         auto chrs = vsc_vcf::read_vcf(vcf, sample);
 
         std::cout << "Compute overlap sequences" << std::endl;
-        // reference bases: the genome FASTA in memory, addressed by the first word of each id (FAI rule)
-        const auto genome = vsc_host::read_fasta(argv[3]);
-        std::unordered_map<std::string, const std::string *> by_name;
-        for (const auto &r : genome) by_name.emplace(r.id.substr(0, r.id.find_first_of(" \t")), &r.seq);
-        auto fetch = [&](const std::string &chr, uint32_t b, uint32_t e) -> std::string {
-            auto it = by_name.find(chr);
-            if (it == by_name.end()) throw std::out_of_range("ERROR: Index out of range.");
-            const std::string &s = *it->second;
-            b = std::min<uint64_t>(b, s.size());  // write_fasta.h:255-260
-            e = std::min<uint64_t>(e, s.size());
-            if (b > e) e = b;
-            return vsc_vcf::dna5(s.substr(b, e - b));
-        };
+        // reference bases, addressed by the first word of each id (FAI rule; region clamped as write_fasta.h:255-260): from
+        // the packed genome that stands for the FASTA when there is one, else from the FASTA text in memory
+        const vsc_merge::Genome genome(argv[3]);
+        auto fetch = [&](const std::string &chr, uint32_t b, uint32_t e) -> std::string { return genome.region(chr, b, e, '+'); };
 
         std::cout << "Write fasta" << std::endl;
         std::ofstream out(argv[2]);

@@ -3,7 +3,13 @@
 // (include/varscot_hip.h).
 #pragma once
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -74,12 +80,18 @@ inline std::vector<FastaRecord> read_fasta(const std::string &path)
 }
 
 // ---- packed genome on disk: <prefix>.vsc -------------------------------------------------------
-// magic "VSCIDX01" | u64 n_contigs | u64 n_words | contig table | names (u32 length + bytes) |
-// hi plane | lo plane | N plane.  Replaces the SeqAn index files of read_mapping/bidir_index.cpp:45-47.
+// magic "VSCIDX02" | u64 n_contigs | u64 n_words | u64 size and i64 mtime (ns) of the FASTA it was packed from (0: unknown) |
+// contig table | names (u32 length + bytes) | zero padding to a multiple of 8 bytes | hi plane | lo plane | N plane.
+// ("VSCIDX01", rounds 1-3: no source fields, no padding - still read.)  Replaces the SeqAn index files of
+// read_mapping/bidir_index.cpp:45-47 AND the .fai index the reference's other stages open next to the FASTA
+// (variant_processing/extract_fasta_ontargets.h:33-76, filter_output_bam.h:399, write_fasta.h:245-271): every tool takes
+// its reference bases from this file when it is there and belongs to the FASTA it was given (PackedView below).
 struct PackedIndex {
     std::vector<vsc_contig> contigs;
     std::vector<std::string> names;
     std::vector<uint32_t> hi, lo, nm;
+    uint64_t src_size = 0;   // the FASTA this was packed from: its size ...
+    int64_t src_mtime = 0;   // ... and modification time in nanoseconds (0: unknown)
 };
 
 // worker threads for host-side text work: OMP_NUM_THREADS if the driver set it (VARSCOT:257), else all cores
@@ -93,6 +105,15 @@ inline unsigned host_threads()
 
 inline std::string index_path(const std::string &prefix) { return prefix + ".vsc"; }
 inline std::string seed_index_path(const std::string &prefix) { return prefix + ".vsi"; }  // optional: bidir_index -S
+
+inline bool file_stamp(const std::string &path, uint64_t *size, int64_t *mtime_ns)
+{
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0) return false;
+    *size = (uint64_t)st.st_size;
+    *mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec;
+    return true;
+}
 
 inline PackedIndex pack_records(const std::vector<FastaRecord> &recs)
 {
@@ -110,9 +131,43 @@ inline PackedIndex pack_records(const std::vector<FastaRecord> &recs)
     ix.lo.resize(n_words);
     ix.nm.resize(n_words);
     vsc_planes_init(ix.hi.data(), ix.lo.data(), ix.nm.data(), n_words);
-    for (size_t i = 0; i < recs.size(); ++i)
-        vsc_pack_bases(recs[i].seq.data(), recs[i].seq.size(), ix.contigs[i].offset, ix.hi.data(), ix.lo.data(),
-                       ix.nm.data());
+    // packed on all host threads: vsc_pack_bases only writes the bits of the range it is given, so whole words can be
+    // handed out freely
+    const unsigned n_threads = std::min<unsigned>(host_threads(), (unsigned)std::max<size_t>(1, recs.size()));
+    if (n_threads <= 1 || recs.size() < 2) {
+        for (size_t i = 0; i < recs.size(); ++i)
+            vsc_pack_bases(recs[i].seq.data(), recs[i].seq.size(), ix.contigs[i].offset, ix.hi.data(), ix.lo.data(), ix.nm.data());
+    } else {
+        // whole words belong to one worker: a contig is cut at word boundaries, the (at most two) partial words at its ends
+        // are packed afterwards, one contig after the other
+        struct Piece { size_t rec; uint64_t b, e; };
+        std::vector<Piece> whole, edge;
+        for (size_t i = 0; i < recs.size(); ++i) {
+            const uint64_t o = ix.contigs[i].offset, n = recs[i].seq.size();
+            const uint64_t wb = (o + 31) / 32 * 32, we = (o + n) / 32 * 32;
+            if (we <= wb) {
+                if (n) edge.push_back({i, 0, n});
+                continue;
+            }
+            if (wb > o) edge.push_back({i, 0, wb - o});
+            if (o + n > we) edge.push_back({i, we - o, n});
+            const uint64_t step = (uint64_t)1 << 24;  // 16 M bases per piece
+            for (uint64_t b = wb; b < we; b += step) whole.push_back({i, b - o, std::min(we, b + step) - o});
+        }
+        std::vector<std::thread> pool;
+        std::atomic<size_t> next{0};
+        for (unsigned t = 0; t < n_threads; ++t)
+            pool.emplace_back([&] {
+                for (size_t k; (k = next.fetch_add(1)) < whole.size();) {
+                    const Piece &pc = whole[k];
+                    vsc_pack_bases(recs[pc.rec].seq.data() + pc.b, pc.e - pc.b, ix.contigs[pc.rec].offset + pc.b, ix.hi.data(), ix.lo.data(),
+                                   ix.nm.data());
+                }
+            });
+        for (auto &th : pool) th.join();
+        for (const Piece &pc : edge)
+            vsc_pack_bases(recs[pc.rec].seq.data() + pc.b, pc.e - pc.b, ix.contigs[pc.rec].offset + pc.b, ix.hi.data(), ix.lo.data(), ix.nm.data());
+    }
     return ix;
 }
 
@@ -121,49 +176,174 @@ inline void write_index(const std::string &prefix, const PackedIndex &ix)
     std::ofstream out(index_path(prefix), std::ios::binary);
     if (!out) throw std::runtime_error("Could not open " + index_path(prefix) + " for writing");
     const uint64_t nc = ix.contigs.size(), nw = ix.hi.size();
-    out.write("VSCIDX01", 8);
+    out.write("VSCIDX02", 8);
     out.write((const char *)&nc, 8);
     out.write((const char *)&nw, 8);
+    out.write((const char *)&ix.src_size, 8);
+    out.write((const char *)&ix.src_mtime, 8);
     out.write((const char *)ix.contigs.data(), (std::streamsize)(nc * sizeof(vsc_contig)));
+    uint64_t name_bytes = 0;
     for (const auto &n : ix.names) {
         const uint32_t l = (uint32_t)n.size();
         out.write((const char *)&l, 4);
         out.write(n.data(), l);
+        name_bytes += 4 + l;
     }
+    const char zeros[8] = {0};
+    out.write(zeros, (std::streamsize)((8 - name_bytes % 8) % 8));  // the planes start 8-byte aligned (mapped readers)
     out.write((const char *)ix.hi.data(), (std::streamsize)(nw * 4));
     out.write((const char *)ix.lo.data(), (std::streamsize)(nw * 4));
     out.write((const char *)ix.nm.data(), (std::streamsize)(nw * 4));
     if (!out) throw std::runtime_error("Write error on " + index_path(prefix));
 }
 
+// A packed genome file mapped read-only: nothing is read until it is touched - the few regions fasta_writer or a merger
+// asks for cost a few pages, not a pass over 3 GB of FASTA text.  (Files of the older layout are read into memory.)
+class PackedView {
+public:
+    std::vector<vsc_contig> contigs;
+    std::vector<std::string> names;
+    const uint32_t *hi = nullptr, *lo = nullptr, *nm = nullptr;
+    uint64_t n_words = 0;
+    uint64_t src_size = 0;
+    int64_t src_mtime = 0;
+
+    PackedView() = default;
+    PackedView(const PackedView &) = delete;
+    PackedView &operator=(const PackedView &) = delete;
+    ~PackedView()
+    {
+        if (map_) ::munmap(map_, map_len_);
+    }
+    // false: no such file; throws on a file that is there but is not a packed genome
+    bool open(const std::string &path)
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (::fstat(fd, &st) != 0 || st.st_size < 24) {
+            ::close(fd);
+            throw std::runtime_error("Not a packed genome: " + path);
+        }
+        map_len_ = (size_t)st.st_size;
+        map_ = ::mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (map_ == MAP_FAILED) {
+            map_ = nullptr;
+            throw std::runtime_error("Could not map " + path);
+        }
+        const char *p = (const char *)map_, *const end = p + map_len_;
+        const bool v2 = std::memcmp(p, "VSCIDX02", 8) == 0;
+        if (!v2 && std::memcmp(p, "VSCIDX01", 8) != 0) throw std::runtime_error("Not a packed genome: " + path);
+        auto need = [&](uint64_t bytes) {
+            if ((uint64_t)(end - p) < bytes) throw std::runtime_error("Truncated index " + path);
+        };
+        uint64_t nc = 0;
+        need(v2 ? 40 : 24);
+        std::memcpy(&nc, p + 8, 8);
+        std::memcpy(&n_words, p + 16, 8);
+        if (v2) {
+            std::memcpy(&src_size, p + 24, 8);
+            std::memcpy(&src_mtime, p + 32, 8);
+        }
+        p += v2 ? 40 : 24;
+        if (nc > (1ull << 32)) throw std::runtime_error("Truncated index " + path);
+        need(nc * sizeof(vsc_contig));
+        contigs.resize(nc);
+        std::memcpy(contigs.data(), p, nc * sizeof(vsc_contig));
+        p += nc * sizeof(vsc_contig);
+        names.resize(nc);
+        uint64_t name_bytes = 0;
+        for (auto &n : names) {
+            uint32_t l = 0;
+            need(4);
+            std::memcpy(&l, p, 4);
+            need(4 + (uint64_t)l);
+            n.assign(p + 4, l);
+            p += 4 + l;
+            name_bytes += 4 + l;
+        }
+        if (v2) p += (8 - name_bytes % 8) % 8;
+        need(n_words * 12);
+        if (((uintptr_t)p & 3u) == 0) {
+            hi = (const uint32_t *)p;
+            lo = hi + n_words;
+            nm = lo + n_words;
+        } else {  // an older file whose names left the planes unaligned: one copy
+            own_.resize(n_words * 3);
+            std::memcpy(own_.data(), p, n_words * 12);
+            hi = own_.data();
+            lo = hi + n_words;
+            nm = lo + n_words;
+        }
+        return true;
+    }
+    // does this file belong to the FASTA at `fasta` (same size and modification time as when it was packed)?
+    bool matches(const std::string &fasta) const
+    {
+        uint64_t size = 0;
+        int64_t mtime = 0;
+        return src_size != 0 && file_stamp(fasta, &size, &mtime) && size == src_size && mtime == src_mtime;
+    }
+    std::string bases(uint32_t contig, uint64_t begin, uint64_t n) const  // upper-case ACGT, everything else N
+    {
+        std::string out(n, 'N');
+        if (n) vsc_unpack_bases(hi, lo, nm, contigs[contig].offset + begin, n, &out[0]);
+        return out;
+    }
+
+private:
+    void *map_ = nullptr;
+    size_t map_len_ = 0;
+    std::vector<uint32_t> own_;
+};
+
 inline PackedIndex read_index(const std::string &prefix)
 {
-    std::ifstream in(index_path(prefix), std::ios::binary);
-    if (!in) throw std::runtime_error("Could not open index " + index_path(prefix));
-    char magic[8];
-    uint64_t nc = 0, nw = 0;
-    in.read(magic, 8);
-    in.read((char *)&nc, 8);
-    in.read((char *)&nw, 8);
-    if (!in || std::memcmp(magic, "VSCIDX01", 8) != 0) throw std::runtime_error("Not a packed genome: " + index_path(prefix));
+    PackedView v;
+    if (!v.open(index_path(prefix))) throw std::runtime_error("Could not open index " + index_path(prefix));
     PackedIndex ix;
-    ix.contigs.resize(nc);
-    in.read((char *)ix.contigs.data(), (std::streamsize)(nc * sizeof(vsc_contig)));
-    ix.names.resize(nc);
-    for (auto &n : ix.names) {
-        uint32_t l = 0;
-        in.read((char *)&l, 4);
-        n.resize(l);
-        in.read(&n[0], l);
-    }
-    ix.hi.resize(nw);
-    ix.lo.resize(nw);
-    ix.nm.resize(nw);
-    in.read((char *)ix.hi.data(), (std::streamsize)(nw * 4));
-    in.read((char *)ix.lo.data(), (std::streamsize)(nw * 4));
-    in.read((char *)ix.nm.data(), (std::streamsize)(nw * 4));
-    if (!in) throw std::runtime_error("Truncated index " + index_path(prefix));
+    ix.contigs = v.contigs;
+    ix.names = v.names;
+    ix.hi.assign(v.hi, v.hi + v.n_words);
+    ix.lo.assign(v.lo, v.lo + v.n_words);
+    ix.nm.assign(v.nm, v.nm + v.n_words);
+    ix.src_size = v.src_size;
+    ix.src_mtime = v.src_mtime;
     return ix;
+}
+
+// The packed genome that stands for the FASTA at `fasta`, if there is one: the prefix in the environment variable `env`
+// (the driver exports the -i prefix as VARSCOT_PACKED_GENOME, the SNP genome's as VARSCOT_PACKED_SNP_GENOME), else
+// <fasta>.vsc, else the FASTA's name with .vsc in place of its extension - taken only if the file says it was packed from
+// a FASTA of this size and modification time.  Returns false when there is none (the caller parses the FASTA).
+inline bool open_packed_for(const std::string &fasta, const char *env, PackedView &view)
+{
+    std::vector<std::string> tries;
+    const char *e = env ? std::getenv(env) : nullptr;
+    if (e && *e) tries.push_back(index_path(e));
+    tries.push_back(fasta + ".vsc");
+    const size_t dot = fasta.rfind('.');
+    if (dot != std::string::npos && fasta.find('/', dot) == std::string::npos) tries.push_back(fasta.substr(0, dot) + ".vsc");
+    const char *trace = std::getenv("VARSCOT_TRACE");  // tests: say on stderr where the reference bases come from
+    for (const auto &path : tries) {
+        PackedView v;
+        try {
+            if (!v.open(path)) continue;
+            if (!v.matches(fasta)) {
+                if (trace) std::fprintf(stderr, "[varscot] %s was not packed from %s as it is now: not used\n", path.c_str(), fasta.c_str());
+                continue;
+            }
+        } catch (const std::exception &) {
+            continue;
+        }
+        if (view.open(path)) {  // (`view` is a fresh object: nothing mapped yet)
+            if (trace) std::fprintf(stderr, "[varscot] reference bases of %s from the packed genome %s\n", fasta.c_str(), path.c_str());
+            return true;
+        }
+    }
+    if (trace) std::fprintf(stderr, "[varscot] reference bases of %s from the FASTA text\n", fasta.c_str());
+    return false;
 }
 
 // ---- SAM text (read_mapping/bidir_mapping.cpp:88-123) -----------------------------

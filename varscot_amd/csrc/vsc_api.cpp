@@ -205,7 +205,7 @@ int vsc_ctx_release_scratch(vsc_ctx *ctx)
     if (!ctx) return VSC_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a,
+    for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->score_guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a,
                          &ctx->score_mit, &ctx->score_flags, &ctx->score_feat, &ctx->score_sched, &ctx->sort_segs, &ctx->sort_tabs,
                          &ctx->sort_over, &ctx->seed_off,
                          &ctx->seed_poff, &ctx->seed_lrest})
@@ -883,8 +883,33 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
         }
         const size_t n_segs = segs.size();
         const size_t n_bins = n_segs << bits;
-        bool use_slots = level == 1 && bits && slots && other_buf && (dbg.sort_optimistic == 1 || (dbg.sort_optimistic != 0 && *slots)) &&
-                         (uint64_t)n_bins * slot_cap < (1ull << 34);
+        bool use_slots = level == 1 && bits && slots && other_buf && (dbg.sort_optimistic == 1 || (dbg.sort_optimistic != 0 && *slots));
+        if (level == 1 && bits && other_buf) {
+            // the level's destination is sized here, once, for the layout that will be used: fixed slots (n_bins x slot
+            // capacity: 1.8 - 3.6 x the records with average bins at 70 % of the finalize kernel's capacity) when they are
+            // allowed and fit the device beside everything else, the compact layout otherwise
+            uint64_t span = 1;
+            for (const SortSeg &sg : segs) span = std::max<uint64_t>(span, sg.out_off + sg.n_in);
+            const uint64_t slot_records = (uint64_t)n_bins * slot_cap;
+            if (use_slots && dbg.sort_optimistic != 1) {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+                const uint64_t room = (uint64_t)free_b + other_buf->cap;  // (the buffer's present allocation is given back first)
+                if (slot_records > 4 * n_all + (1ull << 20) || slot_records * sizeof(uint64_t) + (1ull << 30) > room) {
+                    use_slots = false;
+                    *slots = false;  // remembered per genome and budget: later searches do not ask again
+                }
+            }
+            hipError_t ge = other_buf->ensure((size_t)(use_slots ? slot_records : span) * sizeof(uint64_t));
+            if (ge == hipErrorOutOfMemory && use_slots) {
+                (void)hipGetLastError();
+                use_slots = false;
+                *slots = false;
+                ge = other_buf->ensure((size_t)span * sizeof(uint64_t));
+            }
+            if (ge != hipSuccess) return ge;
+            other = (uint64_t *)other_buf->p;
+        }
         std::vector<uint32_t> &tile0 = ctx->host_tile0;
         tile0.assign(n_segs + 1, 0);
         uint64_t tiles = 0;
@@ -916,20 +941,6 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             f.n_segs = (uint32_t)n_segs;
             f.src = src;
             if (bits) {
-                if (use_slots) {
-                    hipError_t ge = other_buf->ensure((size_t)n_bins * slot_cap * sizeof(uint64_t));
-                    if (ge == hipErrorOutOfMemory) {
-                        // no room for the slot layout beside everything else: the exact way needs the compact layout only
-                        (void)hipGetLastError();
-                        uint64_t span = 1;
-                        for (const SortSeg &sg : segs) span = std::max<uint64_t>(span, sg.out_off + sg.n_in);
-                        VSC_TRY(other_buf->ensure(span * sizeof(uint64_t)));
-                        use_slots = false;
-                    } else if (ge != hipSuccess) {
-                        return ge;
-                    }
-                    other = (uint64_t *)other_buf->p;
-                }
                 SortArgs a{};
                 a.segs = d_segs;
                 a.seg_tile0 = d_tile0;
@@ -1001,22 +1012,27 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             f.n_contigs = genome->n_contigs;
             f.out = out;
             VSC_TRY(launch_bin_finalize(f, 2 * ctx->n_cus, st));  // two workgroups fit a CU (LDS)
+            if (bits) {
+                VSC_TRY(hipMemcpyAsync(flags, d_n_over, sizeof flags, hipMemcpyDeviceToHost, st));
+                VSC_TRY(hipStreamSynchronize(st));
+                if (use_slots && flags[2]) {
+                    // a bin outgrew its slot: the source is untouched, nothing was finalized (the finalize kernel left at
+                    // once) - the same level again, exactly.  What the failed attempt moved: the partition's read + write
+                    use_slots = false;
+                    *slots = false;
+                    if (info) {
+                        info->slot_fallbacks++;
+                        info->bytes += 16 * n_all;
+                    }
+                    continue;
+                }
+            }
             if (info && bits) {
                 if (info->levels == 0) info->bin_bits = bits;
                 info->levels++;
                 info->bytes += (use_slots ? 16 : 24) * n_all;  // (histogram read,) partition read + write
             }
             if (info) info->bytes += 24 * n_all;  // finalize: 8-byte read, 16-byte write
-            if (!bits) break;  // every segment fitted: nothing can come back
-            VSC_TRY(hipMemcpyAsync(flags, d_n_over, sizeof flags, hipMemcpyDeviceToHost, st));
-            VSC_TRY(hipStreamSynchronize(st));
-            if (use_slots && flags[2]) {
-                // a bin outgrew its slot: the source is untouched, nothing was finalized - the same level again, exactly
-                use_slots = false;
-                *slots = false;
-                if (info) info->slot_fallbacks++;
-                continue;
-            }
             break;
         }
         if (!bits) break;
@@ -1284,10 +1300,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
             n += real;
         }
         const_cast<vsc_genome *>(genome)->seen_rate[params->max_mismatches] = fullest;
-        if (n > 0) {
-            VSC_HIP_H(ctx->keys_b.ensure(cap * sizeof(uint64_t)));
-            other = (uint64_t *)ctx->keys_b.p;
-        }
+        // (the sort's second buffer, ctx->keys_b, is sized by bin_sort for the layout its first level uses)
     }
     t.hits += n;
     if (n > 0) {
@@ -1705,13 +1718,43 @@ hipError_t score_scratch(vsc_ctx *ctx, uint64_t count, size_t mit_bytes, size_t 
     return hipSuccess;
 }
 
+// Word-wise hash of a host array (four independent multiply-xorshift lanes over its 8-byte words + the tail bytes): what the
+// caches below key on - an order of magnitude cheaper than walking the bytes, and called once per scoring call.
+uint64_t hash_words(const void *p, size_t bytes, uint64_t seed)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    uint64_t h[4] = {seed, seed ^ 0x9E3779B97F4A7C15ull, seed + 0xBF58476D1CE4E5B9ull, ~seed};
+    const size_t nw = bytes / 8;
+    size_t i = 0;
+    for (; i + 4 <= nw; i += 4)
+        for (int k = 0; k < 4; ++k) {
+            uint64_t w;
+            std::memcpy(&w, b + 8 * (i + k), 8);
+            h[k] = (h[k] ^ w) * 0x100000001b3ull;
+            h[k] ^= h[k] >> 29;
+        }
+    uint64_t tail = 0xcbf29ce484222325ull;
+    for (size_t q = 8 * i; q < bytes; ++q) tail = (tail ^ b[q]) * 0x100000001b3ull;
+    uint64_t r = tail ^ (uint64_t)bytes;
+    for (int k = 0; k < 4; ++k) r = (r ^ h[k]) * 0xff51afd7ed558ccdull, r ^= r >> 33;
+    return r;
+}
+
+// The reads as (hi, lo) plane pairs for the scoring kernels, in a buffer of their own (ctx->guides is the search passes'
+// and changes with every batch of a streamed search): uploaded when the read set differs from the last call's.
 hipError_t upload_read_planes(vsc_ctx *ctx, const uint64_t *guides, uint32_t n_guides)
 {
+    const uint64_t h = hash_words(guides, (size_t)n_guides * sizeof(uint64_t), 0x5c0 + n_guides);
+    if (ctx->score_guides.p && ctx->score_guides_n == n_guides && ctx->score_guides_hash == h) return hipSuccess;
+    ctx->score_guides_n = ~0u;
     std::vector<uint32_t> gp((size_t)std::max<uint32_t>(n_guides, 1) * 2, 0);
     for (uint32_t i = 0; i < n_guides; ++i) guide_planes(guides[i], &gp[2 * (size_t)i], &gp[2 * (size_t)i + 1]);
-    VSC_TRY(ctx->guides.ensure(gp.size() * sizeof(uint32_t)));
-    VSC_TRY(hipMemcpyAsync(ctx->guides.p, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    return hipStreamSynchronize(ctx->stream);  // gp goes out of scope
+    VSC_TRY(ctx->score_guides.ensure(gp.size() * sizeof(uint32_t)));
+    VSC_TRY(hipMemcpyAsync(ctx->score_guides.p, gp.data(), gp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    VSC_TRY(hipStreamSynchronize(ctx->stream));  // gp goes out of scope
+    ctx->score_guides_n = n_guides;
+    ctx->score_guides_hash = h;
+    return hipSuccess;
 }
 
 void fill_score_args(ScoreArgs &s, vsc_ctx *ctx, const vsc_genome *genome)
@@ -1720,7 +1763,7 @@ void fill_score_args(ScoreArgs &s, vsc_ctx *ctx, const vsc_genome *genome)
     s.first_pos = (uint32_t)(genome->first_word * 32);
     s.n_plane_words = genome->dev_words;
     s.contig_off = genome->d_contig_off;
-    s.guides = (const uint2 *)ctx->guides.p;
+    s.guides = (const uint2 *)ctx->score_guides.p;
 }
 
 }  // namespace
@@ -1893,13 +1936,6 @@ namespace {
 // The forest on the device (vsc_rf_predict*, vsc_score_classify_hits): 8-byte integer nodes over the forest's own
 // compact column numbering + the sorted distinct activity thresholds.  Kept on the context until a call brings
 // another forest (fingerprint of the model's arrays): a streamed search classifies batch after batch.
-uint64_t fnv(const void *p, size_t n, uint64_t h)
-{
-    const unsigned char *b = (const unsigned char *)p;
-    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
-    return h;
-}
-
 // Where column `col` (0..441; 442 = the activity rank) sits in the row the kernel extracts tests from
 // (rf_row_words in vsc_kernels.hip; the packed layout is feature_row_packed's)
 void row_field(uint32_t col, uint8_t *word, uint8_t *shift, uint8_t *width)
@@ -1932,12 +1968,12 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
         return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": a tree has more nodes than the kernel stages at once").c_str());
     if (model->n_trees > 65535u) return fail(ctx, VSC_ERR_RANGE, (std::string(who) + ": more than 65 535 trees").c_str());
     uint64_t h = 0xcbf29ce484222325ull ^ ((uint64_t)model->n_trees << 32 | model->n_nodes);
-    h = fnv(model->node_status, nn, h);
-    h = fnv(model->feature, nn * 2, h);
-    h = fnv(model->left, nn * 2, h);
-    h = fnv(model->right, nn * 2, h);
-    h = fnv(model->split, nn * 8, h);
-    h = fnv(model->node_class, nn, h);
+    h = hash_words(model->node_status, nn, h);
+    h = hash_words(model->feature, nn * 2, h);
+    h = hash_words(model->left, nn * 2, h);
+    h = hash_words(model->right, nn * 2, h);
+    h = hash_words(model->split, nn * 8, h);
+    h = hash_words(model->node_class, nn, h);
     vsc_ctx::Forest &f = ctx->forest;
     if (f.nodes.p && f.fingerprint == h && f.n_trees == model->n_trees && f.n_nodes == model->n_nodes) return VSC_OK;
     f.fingerprint = 0;
@@ -2167,10 +2203,19 @@ int vsc_score_classify_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hi
     VSC_HIP(ctx, hipSetDevice(ctx->device));
     VSC_HIP(ctx, upload_read_planes(ctx, guides, n_guides));
     VSC_HIP(ctx, ensure_hl(ctx, genome));
-    std::vector<uint8_t> ranks(std::max<uint32_t>(n_guides, 1));
-    for (uint32_t g = 0; g < n_guides; ++g) ranks[g] = activity_rank(ctx->forest.thresholds, guide_activity[g]);
-    VSC_HIP(ctx, ctx->forest.ranks.ensure(ranks.size()));
-    VSC_HIP(ctx, hipMemcpyAsync(ctx->forest.ranks.p, ranks.data(), ranks.size(), hipMemcpyHostToDevice, ctx->stream));
+    // the reads' activity ranks: uploaded when the activities or the forest differ from the last call's (a streamed search
+    // classifies batch after batch with the same ones)
+    const uint64_t rank_key = hash_words(guide_activity, (size_t)n_guides * sizeof(double), ctx->forest.fingerprint ^ n_guides);
+    if (!ctx->forest.ranks.p || ctx->forest.ranks_key != rank_key || ctx->forest.ranks_n != n_guides) {
+        std::vector<uint8_t> ranks(std::max<uint32_t>(n_guides, 1));
+        for (uint32_t g = 0; g < n_guides; ++g) ranks[g] = activity_rank(ctx->forest.thresholds, guide_activity[g]);
+        ctx->forest.ranks_n = ~0u;
+        VSC_HIP(ctx, ctx->forest.ranks.ensure(ranks.size()));
+        VSC_HIP(ctx, hipMemcpyAsync(ctx->forest.ranks.p, ranks.data(), ranks.size(), hipMemcpyHostToDevice, ctx->stream));
+        VSC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `ranks` goes out of scope
+        ctx->forest.ranks_key = rank_key;
+        ctx->forest.ranks_n = n_guides;
+    }
     // 2 bytes (+ 8 with the MIT score) per hit of scratch: one pass for any result that fits the device at all
     uint64_t rows = 0;
     VSC_HIP(ctx, score_scratch(ctx, count, mit_host ? sizeof(double) : 0, votes_dev ? 0 : sizeof(uint16_t), 0, &rows));

@@ -409,8 +409,9 @@ __global__ __launch_bounds__(256) void merge_packed_kernel(const uint64_t *in, c
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         const uint64_t x = in[src + i];
         const uint32_t gpos = (uint32_t)(x >> kRecPosShift), mask = (uint32_t)x & kMask23;
+        // (the neighbour's record: loaded by the neighbouring lane anyway, one more hit on the same line)
+        if (i > 0 && (uint32_t)(in[src + i - 1] >> kRecPosShift) >= gpos) ++n_bad;  // not strictly ascending inside the segment
         if (!placed || gpos < prev) {
-            n_bad += placed;  // descending inside a segment
             uint32_t lo = 0, hi = n_contigs;  // last contig that starts at or before gpos
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;

@@ -67,6 +67,10 @@ struct vsc_ctx {
     vsc_debug_params dbg = vsc::default_debug_params();  // test / experiment hooks (include/varscot_hip_debug.h)
     // keys_a / keys_b: the two record buffers the bin sort alternates between (keys_a + vals_a: the scan's (key, value) pairs)
     vsc::DeviceBuf counters, guides, keys_a, keys_b, vals_a, score_mit, score_flags, score_feat;
+    // the read planes of the scoring calls (their own buffer: `guides` is the search passes'), kept while the read set stays the same
+    vsc::DeviceBuf score_guides;
+    uint64_t score_guides_hash = 0;
+    uint32_t score_guides_n = ~0u;
     vsc::DeviceBuf sort_segs, sort_tabs, sort_over, score_sched;
     // host staging of the sort's segment tables: uploaded with hipMemcpyAsync, so they must outlive the call that enqueues them
     std::vector<vsc::SortSeg> host_segs;
@@ -80,6 +84,8 @@ struct vsc_ctx {
         bool compact = false;           // node form (vsc_internal.h)
         std::vector<double> thresholds;  // distinct activity splits, ascending
         uint64_t fingerprint = 0;
+        uint64_t ranks_key = 0;  // activities + forest the resident ranks were made from
+        uint32_t ranks_n = ~0u;
     } forest;
     // record buffers of freed results, kept for the next search: hipMalloc / hipFree of tens of GB
     // cost hundreds of milliseconds each
