@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VSC_ABI_VERSION 3
+#define VSC_ABI_VERSION 4
 
 #define VSC_OK 0
 #define VSC_ERR_INVALID (-22)  /* EINVAL: bad argument (e.g. mismatches outside 0..8)          */
@@ -299,10 +299,10 @@ int vsc_score_pairs(vsc_ctx *ctx, const uint64_t *on_targets, const uint64_t *of
  * the 8 GPUs of one node by genome shard with a single RCCL gather of candidate hits"): one vsc_ctx per
  * entry of device_ids, the planes cut into n tile-aligned position ranges (+ a one-word halo; a window
  * belongs to the shard that holds its first base), every device searching ALL reads on its shard from its own
- * host thread, then one exchange - the hit counts by ncclAllGather, the records (8-byte exchange records,
- * vsc_hits_pack_exchange) by one grouped ncclSend / ncclRecv per shard to the first device, over xGMI - and
+ * host thread, then one exchange - the records (8-byte exchange records, vsc_hits_pack_exchange) by one grouped
+ * ncclSend / ncclRecv per shard to the first device, over xGMI (the counts are known inside the process) - and
  * vsc_hits_merge_packed there.  The result is an
- * ordinary vsc_hits of the first context (vsc_multi_ctx(m, 0)): same records, same order as one device gives.
+ * ordinary vsc_hits of a context on the first device (vsc_multi_result_ctx(m)): same records, same order as one device gives.
  * This replaces, inside the bidir_mapping process, the OpenMP loop over reads and the concatenation of the
  * per-thread output buffers (read_mapping/bidir_mapping.cpp:285-295,307-308): the parallel axis is the genome.
  * RCCL is bound at run time (dlopen) and used when n > 1 distinct devices are given; device ids may repeat
@@ -312,20 +312,28 @@ int vsc_score_pairs(vsc_ctx *ctx, const uint64_t *on_targets, const uint64_t *of
 typedef struct vsc_multi vsc_multi;
 typedef struct vsc_multi_genome vsc_multi_genome;
 typedef struct {
-    double search_wall_ms;   /* host wall time until the slowest shard's search had returned */
-    double search_ms_max;    /* largest vsc_timing.total_ms among the shards */
-    double exchange_ms;      /* counts + records to the first device (host wall) */
-    double merge_ms;         /* vsc_hits_merge on the first device (host wall) */
+    double search_wall_ms;   /* host wall time until the slowest shard had searched (+ scored) and packed its last batch */
+    double search_ms_max;    /* largest sum of vsc_timing.total_ms among the shards */
+    double exchange_ms;      /* host wall time the exchange took beyond the searches: from the moment the last shard of a batch was
+                                ready until that batch's records had arrived on the first device (summed over the batches) */
+    double merge_ms;         /* vsc_hits_merge_packed on the first device (host wall, summed over the batches) */
     double total_ms;
     uint64_t hits;
-    uint64_t exchanged_bytes; /* record bytes that crossed between devices */
+    uint64_t exchanged_bytes; /* record (+ vote) bytes that crossed between devices */
     uint32_t n_devices;
     uint32_t used_rccl;      /* 1: RCCL carried the exchange, 0: device copies */
+    double score_ms_max;     /* largest sum of the shards' scoring kernels (vsc_timing.score_ms) */
+    double callback_ms;      /* host wall time inside on_batch (summed) */
+    uint32_t batches;        /* batches the reads were searched in (vsc_multi_search: 1) */
+    uint32_t reserved;
 } vsc_multi_timing;
 int vsc_multi_create(const int *device_ids, int n, vsc_multi **out);
 int vsc_multi_destroy(vsc_multi *m);
 int vsc_multi_size(const vsc_multi *m);
-vsc_ctx *vsc_multi_ctx(vsc_multi *m, int i);  /* the i-th context, e.g. for scoring the merged result on context 0 */
+vsc_ctx *vsc_multi_ctx(vsc_multi *m, int i);  /* the i-th shard's context */
+/* The context on the first device that owns the merged results (its own stream: a batch is merged there while the shards -
+ * the first device's among them - search the next one). */
+vsc_ctx *vsc_multi_result_ctx(vsc_multi *m);
 const char *vsc_multi_last_error(const vsc_multi *m);
 int vsc_multi_uses_rccl(const vsc_multi *m);
 int vsc_multi_get_timing(const vsc_multi *m, vsc_multi_timing *out);
@@ -334,9 +342,11 @@ int vsc_multi_genome_load(vsc_multi *m, const uint32_t *hi, const uint32_t *lo, 
                           const vsc_contig *contigs, uint32_t n_contigs, vsc_multi_genome **out);
 int vsc_multi_genome_free(vsc_multi_genome *g);
 int vsc_multi_genome_build_index(vsc_multi *m, vsc_multi_genome *g, const vsc_search_params *params);
-/* as vsc_search; *out belongs to the first context and is released with vsc_hits_free */
+/* as vsc_search; *out belongs to vsc_multi_result_ctx(m) and is released with vsc_hits_free.  A shard's records leave for
+ * the first device as soon as THAT shard is done (they do not wait for the slowest one). */
 int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides, uint32_t n_guides,
                      const vsc_search_params *params, vsc_hits **out);
+/* (vsc_multi_search_stream, which scores on the owning shard, is declared behind the classifier below.) */
 
 /* ---- variant windows (row R8) ------------------------------------------------------------------- */
 /*
@@ -412,6 +422,37 @@ int vsc_rf_predict_packed(vsc_ctx *ctx, const vsc_rf_model *model, const void *p
 int vsc_score_classify_hits(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hits *hits, const uint64_t *guides, uint32_t n_guides,
                             const double *guide_activity, const vsc_rf_model *model, uint64_t first, uint64_t count, void *votes_dev,
                             uint16_t *votes_host, double *mit_host);
+
+/* ---- several devices, streamed + scored on the owning shard ------------------------------------------------ */
+/*
+ * The streamed search of vsc_search_stream over the device set (BASELINE configuration 5: "100 000 guides streamed ... +
+ * per-hit classification feature scoring, 8 x MI355X"): the reads go through all shards batch by batch; what `score` asks
+ * for is computed per hit ON THE SHARD THAT FOUND IT, before the exchange; a batch's records (+ votes) travel to the first
+ * device and are merged there WHILE the shards search the next batch (two exchange buffers per shard, a merge context of its
+ * own on the first device); on_batch receives every merged batch - same records, same order, same read indices as one
+ * device's vsc_search_stream gives - and the batch is freed when it returns.
+ *   VSC_MULTI_SCORE_NONE   nothing
+ *   VSC_MULTI_SCORE_ROWS   the 64-byte packed feature rows of vsc_score_hits_packed, computed and dropped on the shard (what
+ *                          a consumer on the shard would read; a timing run like the one-device c5 bench)
+ *   VSC_MULTI_SCORE_VOTES  vsc_score_classify_hits: the forest's votes, 2 bytes per hit, travel with the 8-byte record and
+ *                          arrive merged: votes_dev[i] belongs to record i of the batch (device memory of the first device)
+ * Replaces read_mapping/bidir_mapping.cpp:285-295,307-308 (the loop over reads and the concatenation of the per-thread
+ * buffers) + variant_processing/merge_output_bam.h:696-708 + classification/classificationPipeline.R:21-49 for a read set
+ * whose result fits no device.
+ */
+#define VSC_MULTI_SCORE_NONE 0
+#define VSC_MULTI_SCORE_ROWS 1
+#define VSC_MULTI_SCORE_VOTES 2
+typedef struct {
+    uint32_t mode;                 /* VSC_MULTI_SCORE_* */
+    uint32_t reserved;
+    const double *guide_activity;  /* VOTES: on-target activity per read (n_guides values) */
+    const vsc_rf_model *model;     /* VOTES: the forest */
+} vsc_multi_score;
+typedef int (*vsc_multi_batch_fn)(void *user, vsc_hits *batch, uint32_t first_guide, uint32_t n_guides, const uint16_t *votes_dev);
+int vsc_multi_search_stream(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides, uint32_t n_guides,
+                            const vsc_search_params *params, uint32_t batch_reads, const vsc_multi_score *score,
+                            vsc_multi_batch_fn on_batch, void *user);
 
 /* ---- host-side formatting helpers (no device needed) ------------------------------------------ */
 /*

@@ -979,10 +979,101 @@ def test_multi_device_search_on_a_genome_smaller_than_the_device_list(oracle):
         m.close()
 
 
+@pytest.mark.parametrize("devices,batch,score", [([0] * 8, 16, None), ([0] * 3, 7, "rows"), ([0, 0], 25, "votes"), ([0] * 5, 64, "votes")])
+def test_multi_device_streamed_search_scored_on_the_owning_shard(ctx, oracle, devices, batch, score):
+    """vsc_multi_search_stream (BASELINE configuration 5 behind the C ABI): the reads go through all shards batch by batch, every
+    shard scores its own hits before the exchange, a batch is exchanged and merged on the first device while the shards search
+    the next one.  Every merged batch = the oracle's records of its reads (global read indices), the batches cover the read set
+    in order; with the forest on the path the votes that travelled with the records equal, record for record, what ONE context
+    computes for the same hits (vsc_score_classify_hits on the whole result) - shard boundaries and the merge keep votes and
+    records together.  Repeated device ids: 8 / 3 / 2 / 5 contexts on the one GPU of this box."""
+    import torch
+    from varscot_amd.classifier import Forest
+    rng = np.random.default_rng(4242 + len(devices))
+    guides = random_guides(rng, 50)
+    contigs = make_genome(4242 + len(devices), [90000, 30000, 700, 45000], guides[:40], 6, n_plant=500, n_runs=3)
+    packed = va.PackedGenome.from_sequences(contigs)
+    want = oracle.search_fast(contigs, guides, 6)
+    assert len(want) > 300
+    forest = Forest() if score == "votes" else None
+    act = np.random.default_rng(6).uniform(0.2, 1.8, size=len(guides))
+    want_votes = None
+    if score == "votes":  # one context, whole result
+        gen = ctx.load_genome(packed)
+        h = gen.search(guides, 6, algorithm="seed")
+        assert h.to_numpy().tobytes() == want.tobytes()
+        want_votes, _ = forest.classify_hits(h, act)
+        h.close()
+        gen.close()
+        assert 0 < (want_votes > 500).mean() < 1
+    seen, recs, votes = [], [], []
+
+    def on_batch(h, first, count, votes_dev):
+        seen.append((first, count))
+        a = h.to_numpy()
+        recs.append(a)
+        assert len(a) == 0 or (int(a["guide"].min()) >= first and int(a["guide"].max()) < first + count)
+        if score == "votes" and len(a):
+            assert votes_dev
+            from varscot_amd.dist import DeviceAlias
+            t = torch.as_tensor(DeviceAlias(votes_dev, 2 * len(a)), device="cuda:0").view(torch.int16)
+            votes.append(t.cpu().numpy().view(np.uint16).copy())
+        else:
+            assert not votes_dev or score == "votes"
+
+    m = va.MultiContext(devices)
+    try:
+        g = m.load_genome(packed)
+        g.build_index()
+        g.search_streamed(guides, 6, on_batch, batch=batch, algorithm="seed", score=score, forest=forest, guide_activity=act)
+        t = m.timing()
+        # and the plain search on the same objects afterwards (one batch through the same engine)
+        h = g.search(guides, 6, algorithm="seed")
+        assert h.to_numpy().tobytes() == want.tobytes()
+        h.close()
+        g.close()
+    finally:
+        m.close()
+    assert seen == [(b, min(batch, len(guides) - b)) for b in range(0, len(guides), batch)]
+    assert np.concatenate(recs).tobytes() == want.tobytes()
+    assert t["batches"] == len(seen) and t["hits"] == len(want) and t["n_devices"] == len(devices)
+    assert (t["score_ms_max"] > 0) == (score is not None)
+    if score == "votes":
+        assert np.array_equal(np.concatenate(votes), want_votes)
+
+
+def test_multi_device_stream_stops_when_the_callback_fails(oracle):
+    """A callback that raises in the second batch: the stream stops, the shard threads are joined, the error surfaces, and the
+    device set is usable afterwards."""
+    rng = np.random.default_rng(99)
+    guides = random_guides(rng, 30)
+    contigs = make_genome(99, [60000, 20000], guides, 5, n_plant=300, n_runs=2)
+    want = oracle.search_fast(contigs, guides, 5)
+    m = va.MultiContext([0] * 3)
+    try:
+        g = m.load_genome(va.PackedGenome.from_sequences(contigs))
+        calls = []
+
+        def on_batch(h, first, count, votes_dev):
+            calls.append(first)
+            if len(calls) == 2:
+                raise RuntimeError("stop here")
+
+        with pytest.raises(RuntimeError, match="stop here"):
+            g.search_streamed(guides, 5, on_batch, batch=5)
+        assert calls == [0, 5]
+        h = g.search(guides, 5)
+        assert h.to_numpy().tobytes() == want.tobytes()
+        h.close()
+        g.close()
+    finally:
+        m.close()
+
+
 def test_multi_device_exchange_over_rccl_with_one_rank(oracle):
     """The RCCL leg of vsc_multi_search on the one GPU of this box: the hook rccl=1 sets up a one-rank
-    communicator (ncclCommInitAll), the hit counts go through ncclAllGather and the records through a grouped
-    ncclSend / ncclRecv to the rank itself; the result is the single-context one."""
+    communicator (ncclCommInitAll) and the records go through a grouped ncclSend / ncclRecv to the rank itself; the
+    result is the single-context one."""
     rng = np.random.default_rng(808)
     guides = random_guides(rng, 40)
     contigs = make_genome(808, [50000, 20000], guides, 5, n_plant=300, n_runs=2)

@@ -49,10 +49,19 @@ class Timing(C.Structure):
 class MultiTiming(C.Structure):
     _fields_ = [("search_wall_ms", C.c_double), ("search_ms_max", C.c_double), ("exchange_ms", C.c_double),
                 ("merge_ms", C.c_double), ("total_ms", C.c_double), ("hits", C.c_uint64), ("exchanged_bytes", C.c_uint64),
-                ("n_devices", C.c_uint32), ("used_rccl", C.c_uint32)]
+                ("n_devices", C.c_uint32), ("used_rccl", C.c_uint32), ("score_ms_max", C.c_double), ("callback_ms", C.c_double),
+                ("batches", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class MultiScore(C.Structure):
+    """vsc_multi_score: what every shard computes per hit before the exchange (vsc_multi_search_stream)."""
+    _fields_ = [("mode", C.c_uint32), ("reserved", C.c_uint32), ("guide_activity", C.c_void_p), ("model", C.POINTER(RfModel))]
+
+
+MULTI_SCORE_NONE, MULTI_SCORE_ROWS, MULTI_SCORE_VOTES = 0, 1, 2
 
 
 class DebugParams(C.Structure):
@@ -77,6 +86,7 @@ class MultiDebugParams(C.Structure):
 
 
 BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32)  # vsc_batch_fn
+MULTI_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)  # vsc_multi_batch_fn
 
 # every symbol include/varscot_hip.h declares: (name, restype, argtypes)
 _u32p = C.POINTER(C.c_uint32)
@@ -120,6 +130,7 @@ SYMBOLS = [
     ("vsc_multi_destroy", C.c_int, [_vp]),
     ("vsc_multi_size", C.c_int, [_vp]),
     ("vsc_multi_ctx", _vp, [_vp, C.c_int]),
+    ("vsc_multi_result_ctx", _vp, [_vp]),
     ("vsc_multi_last_error", C.c_char_p, [_vp]),
     ("vsc_multi_uses_rccl", C.c_int, [_vp]),
     ("vsc_multi_get_timing", C.c_int, [_vp, C.POINTER(MultiTiming)]),
@@ -127,6 +138,7 @@ SYMBOLS = [
     ("vsc_multi_genome_free", C.c_int, [_vp]),
     ("vsc_multi_genome_build_index", C.c_int, [_vp, _vp, C.POINTER(SearchParams)]),
     ("vsc_multi_search", C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(SearchParams), C.POINTER(_vp)]),
+    ("vsc_multi_search_stream", C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(SearchParams), C.c_uint32, C.POINTER(MultiScore), MULTI_BATCH_FN, _vp]),
     ("vsc_windows_build", C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, C.c_uint32,
                                     C.POINTER(_vp), C.c_char_p, C.c_size_t]),
     ("vsc_windows_count", C.c_uint32, [_vp]),

@@ -484,9 +484,55 @@ class MultiGenome:
         p = Genome._params(max_mismatches, extra_pam, algorithm)
         h = C.c_void_p()
         self.multi._check(lib().vsc_multi_search(self.multi._h, self._h, ptr(codes), len(codes), C.byref(p), C.byref(h)))
-        res = MergedHits(_BorrowedContext(C.c_void_p(lib().vsc_multi_ctx(self.multi._h, 0))), h)
+        res = MergedHits(_BorrowedContext(C.c_void_p(lib().vsc_multi_result_ctx(self.multi._h))), h)
         self.multi._results.add(res)
         return res
+
+    def search_streamed(self, guides, max_mismatches, on_batch, batch=0, extra_pam=None, algorithm="auto", score=None,
+                        forest=None, guide_activity=None):
+        """vsc_multi_search_stream: the reads go through all shards in batches of `batch`; what `score` names is computed
+        per hit on the shard that found it, before the exchange ("rows": the packed feature rows, computed and dropped;
+        "votes": `forest` walked per hit with the reads' `guide_activity`, 2 bytes per hit travel with the record); every
+        merged batch is handed to on_batch(hits, first_guide, n_guides, votes_dev) - votes_dev: device address (first
+        device) of one uint16 per record, or None - and freed afterwards.  The exchange and merge of a batch run while the
+        shards search the next one."""
+        codes = guides if isinstance(guides, np.ndarray) else pack_guides(guides)
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        p = Genome._params(max_mismatches, extra_pam, algorithm)
+        sc, keep = None, []
+        if score:
+            sc = _lib.MultiScore()
+            sc.mode = {"rows": _lib.MULTI_SCORE_ROWS, "votes": _lib.MULTI_SCORE_VOTES}[score]
+            if score == "votes":
+                act = np.ascontiguousarray(guide_activity, dtype=np.float64)
+                assert len(act) == len(codes)
+                model = _lib.RfModel(forest.n_trees, forest.n_nodes, ptr(forest.status), ptr(forest.feature), ptr(forest.left),
+                                     ptr(forest.right), ptr(forest.split), ptr(forest.node_class))
+                keep += [act, model]
+                sc.guide_activity = act.ctypes.data
+                sc.model = C.pointer(model)
+        failure = []
+        rctx = _BorrowedContext(C.c_void_p(lib().vsc_multi_result_ctx(self.multi._h)))
+
+        def trampoline(_user, handle, first, count, votes_dev):
+            try:
+                h = MergedHits(rctx, C.c_void_p(handle))
+                h._owned = False  # the batch belongs to the library
+                try:
+                    on_batch(h, int(first), int(count), votes_dev)
+                finally:
+                    h.close()
+                return 0
+            except BaseException as e:  # no exception may cross the C boundary
+                failure.append(e)
+                return -5
+
+        cb = _lib.MULTI_BATCH_FN(trampoline)
+        rc = lib().vsc_multi_search_stream(self.multi._h, self._h, ptr(codes), len(codes), C.byref(p), int(batch),
+                                           C.byref(sc) if sc is not None else None, cb, None)
+        if failure:
+            raise failure[0]
+        self.multi._check(rc)
 
     def close(self):
         if self._h:

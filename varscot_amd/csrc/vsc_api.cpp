@@ -1601,26 +1601,61 @@ int vsc_hits_merge_packed(vsc_ctx *ctx, const vsc_genome *genome, const void *re
         return fail(ctx, VSC_ERR_INVALID, "vsc_hits_merge_packed: null argument or genome of another context");
     if ((uint64_t)first_key + n_keys > (1ull << 31) || (uint64_t)n_keys * n_shards >= (1ull << 31))
         return fail(ctx, VSC_ERR_RANGE, "vsc_hits_merge_packed: too many keys");
-    // where every (key, shard) segment lies in the concatenation of the shards' records, and where it goes
-    const size_t n_segs = (size_t)n_keys * n_shards;
-    std::vector<uint64_t> seg_src(n_segs), seg_dst(n_segs);
-    std::vector<uint32_t> seg_n(n_segs);
+    uint64_t n = 0;
+    std::vector<uint64_t> shard_n(n_shards, 0);
+    for (uint32_t s = 0; s < n_shards; ++s) {
+        for (uint32_t k = 0; k < n_keys; ++k) shard_n[s] += key_counts[(size_t)s * n_keys + k];
+        n += shard_n[s];
+    }
+    if (n && !records) return fail(ctx, VSC_ERR_INVALID, "vsc_hits_merge_packed: null records");
+    VSC_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t *records_dev = (const uint64_t *)records;
+    if (n && !records_on_device) {
+        VSC_HIP(ctx, ctx->score_feat.ensure(n * sizeof(uint64_t)));  // staging buffer for host input
+        VSC_HIP(ctx, hipMemcpyAsync(ctx->score_feat.p, records, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        records_dev = (const uint64_t *)ctx->score_feat.p;
+    }
+    std::vector<const void *> shard_ptr(n_shards);
     uint64_t at = 0;
-    for (uint32_t s = 0; s < n_shards; ++s)
+    for (uint32_t s = 0; s < n_shards; ++s) {
+        shard_ptr[s] = records_dev + at;
+        at += shard_n[s];
+    }
+    return vsc::merge_packed_shards(ctx, genome, shard_ptr.data(), nullptr, key_counts, n_shards, first_key, n_keys, out, nullptr);
+    });
+}
+
+}  // extern "C"
+
+// The merge of vsc_hits_merge_packed over per-shard record buffers (device memory of ctx's device, shard s's records for the
+// keys [first_key, first_key + n_keys) at shard_records[s]) - what the multi-device search hands over: every shard's records
+// arrive in a buffer of their own, whenever that shard is done.  shard_side (optional): 2 bytes per record that travel with
+// it (the shard's classifier votes); they arrive in side_out, in the order of the merged records.
+int vsc::merge_packed_shards(vsc_ctx *ctx, const vsc_genome *genome, const void *const *shard_records, const void *const *shard_side,
+                             const uint32_t *key_counts, uint32_t n_shards, uint32_t first_key, uint32_t n_keys, vsc_hits **out,
+                             DeviceBuf *side_out)
+{
+    // where every (key, shard) segment lies, and where it goes
+    const size_t n_segs = (size_t)n_keys * n_shards;
+    std::vector<uint64_t> seg_src(n_segs), seg_dst(n_segs), seg_side(shard_side ? n_segs : 0);
+    std::vector<uint32_t> seg_n(n_segs);
+    for (uint32_t s = 0; s < n_shards; ++s) {
+        uint64_t at = 0;
         for (uint32_t k = 0; k < n_keys; ++k) {
-            seg_src[(size_t)k * n_shards + s] = at;
+            const size_t seg = (size_t)k * n_shards + s;
+            seg_src[seg] = (uint64_t)(uintptr_t)shard_records[s] + at * sizeof(uint64_t);
+            if (shard_side) seg_side[seg] = (uint64_t)(uintptr_t)shard_side[s] + at * sizeof(uint16_t);
             at += key_counts[(size_t)s * n_keys + k];
         }
-    const uint64_t n = at;
-    at = 0;
+    }
+    uint64_t n = 0;
     for (uint32_t k = 0; k < n_keys; ++k)
         for (uint32_t s = 0; s < n_shards; ++s) {
             const size_t seg = (size_t)k * n_shards + s;
             seg_n[seg] = key_counts[(size_t)s * n_keys + k];
-            seg_dst[seg] = at;
-            at += seg_n[seg];
+            seg_dst[seg] = n;
+            n += seg_n[seg];
         }
-    if (n && !records) return fail(ctx, VSC_ERR_INVALID, "vsc_hits_merge_packed: null records");
     VSC_HIP(ctx, hipSetDevice(ctx->device));
     vsc_hits *hits = new (std::nothrow) vsc_hits();
     if (!hits) return fail(ctx, VSC_ERR_NOMEM, "vsc_hits_merge_packed: out of host memory");
@@ -1635,26 +1670,23 @@ int vsc_hits_merge_packed(vsc_ctx *ctx, const vsc_genome *genome, const void *re
     auto step = [&](hipError_t r) {
         if (e == hipSuccess) e = r;
     };
-    const size_t tab_bytes = n_segs * (2 * sizeof(uint64_t) + sizeof(uint32_t)) + 2 * sizeof(uint32_t);
+    const size_t tab_bytes = n_segs * (3 * sizeof(uint64_t) + sizeof(uint32_t)) + 2 * sizeof(uint32_t);
     step(ctx->keys_b.ensure(tab_bytes));
     step(take_records(ctx, hits, n));
-    const uint64_t *records_dev = (const uint64_t *)records;
-    if (!records_on_device) {
-        step(ctx->score_feat.ensure(n * sizeof(uint64_t)));  // staging buffer for host input
-        if (e == hipSuccess) step(hipMemcpyAsync(ctx->score_feat.p, records, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-        records_dev = (const uint64_t *)ctx->score_feat.p;
-    }
-    uint64_t *d_src = (uint64_t *)ctx->keys_b.p, *d_dst = d_src + n_segs;
-    uint32_t *d_n = (uint32_t *)(d_dst + n_segs);
-    uint32_t *d_bad = d_n + n_segs;  // records whose position lies in no contig or that descend inside a segment
+    if (side_out) step(side_out->ensure(n * sizeof(uint16_t)));
+    uint64_t *d_src = (uint64_t *)ctx->keys_b.p, *d_dst = d_src + n_segs, *d_side = d_dst + n_segs;
+    uint32_t *d_n = (uint32_t *)(d_side + n_segs);
+    uint32_t *d_bad = d_n + n_segs;  // records whose position lies in no contig or that do not ascend inside a segment
     uint32_t n_bad = 0;
     if (e == hipSuccess) {
         step(hipMemcpyAsync(d_src, seg_src.data(), n_segs * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
         step(hipMemcpyAsync(d_dst, seg_dst.data(), n_segs * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        if (shard_side) step(hipMemcpyAsync(d_side, seg_side.data(), n_segs * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
         step(hipMemcpyAsync(d_n, seg_n.data(), n_segs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         step(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream));
-        step(launch_merge_packed(records_dev, d_src, d_dst, d_n, (uint32_t)n_segs, n_shards, first_key, genome->d_contig_off,
-                                 genome->d_contig_end, genome->n_contigs, hits->d_records, d_bad, ctx->stream));
+        step(launch_merge_packed(d_src, d_dst, d_n, (uint32_t)n_segs, n_shards, first_key, genome->d_contig_off, genome->d_contig_end,
+                                 genome->n_contigs, hits->d_records, d_bad, shard_side ? d_side : nullptr,
+                                 shard_side && side_out ? (uint16_t *)side_out->p : nullptr, ctx->stream));
         step(hipMemcpyAsync(&n_bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         step(hipStreamSynchronize(ctx->stream));  // (the host tables go out of scope)
     }
@@ -1665,12 +1697,13 @@ int vsc_hits_merge_packed(vsc_ctx *ctx, const vsc_genome *genome, const void *re
     if (n_bad) {  // what a peer or the caller sent is not a sorted shard result of this genome
         vsc_hits_free(hits);
         return fail(ctx, VSC_ERR_INVALID, ("vsc_hits_merge_packed: " + std::to_string(n_bad) +
-                    " exchange records lie in no contig of the genome or descend inside their (key, shard) segment").c_str());
+                    " exchange records lie in no contig of the genome or do not ascend inside their (key, shard) segment").c_str());
     }
     *out = hits;
     return VSC_OK;
-    });
 }
+
+extern "C" {
 
 int vsc_hits_free(vsc_hits *hits)
 {

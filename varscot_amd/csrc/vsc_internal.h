@@ -289,9 +289,10 @@ hipError_t launch_score_pairs(const uint2 *on, const uint2 *off, const uint32_t 
 hipError_t launch_xpack(const vsc_hit *in, uint64_t n, const uint32_t *contig_off, uint64_t *out, hipStream_t stream);
 // bound[k] = first record of in[range_dev[0] .. range_dev[1]) whose key (guide << 1 | strand) is >= k, k = 0 .. K
 hipError_t launch_key_bounds(const vsc_hit *in, const uint64_t *range_dev, uint32_t K, uint64_t *bound, hipStream_t stream);
-hipError_t launch_merge_packed(const uint64_t *in, const uint64_t *seg_src, const uint64_t *seg_dst, const uint32_t *seg_n,
-                               uint32_t n_segs, uint32_t n_shards, uint32_t first_key, const uint32_t *contig_off,
-                               const uint32_t *contig_end, uint32_t n_contigs, vsc_hit *out, uint32_t *bad /* zeroed */, hipStream_t stream);
+// seg_src / seg_side: ADDRESSES of every (key, shard) segment's records / 16-bit side values (seg_side, side_out: null = none)
+hipError_t launch_merge_packed(const uint64_t *seg_src, const uint64_t *seg_dst, const uint32_t *seg_n, uint32_t n_segs, uint32_t n_shards,
+                               uint32_t first_key, const uint32_t *contig_off, const uint32_t *contig_end, uint32_t n_contigs, vsc_hit *out,
+                               uint32_t *bad /* zeroed */, const uint64_t *seg_side, uint16_t *side_out, hipStream_t stream);
 // *out += fingerprint of words [0, n_words) of the three planes (zero *out first)
 hipError_t launch_plane_hash(const uint32_t *hi, const uint32_t *lo, const uint32_t *nm, uint64_t n_words, unsigned long long *out,
                              hipStream_t stream);

@@ -386,31 +386,38 @@ __global__ __launch_bounds__(256) void xpack_kernel(const vsc_hit *in, uint64_t 
     out[i] = ((uint64_t)(contig_off[r.y] + r.z) << kRecPosShift) | VSC_HIT_MASK(r.w);
 }
 
-// one workgroup per (key, shard) segment: seg = k * n_shards + s; records [seg_src, seg_src + seg_n) of `in` become
-// vsc_hit records [seg_dst, ...) of `out` with guide / strand of key first_key + k
-__global__ __launch_bounds__(256) void merge_packed_kernel(const uint64_t *in, const uint64_t *seg_src, const uint64_t *seg_dst,
-                                                           const uint32_t *seg_n, uint32_t n_shards, uint32_t first_key,
-                                                           const uint32_t *contig_off, const uint32_t *contig_end, uint32_t n_contigs,
-                                                           vsc_hit *out, uint32_t *bad)
+// one workgroup per (key, shard) segment: seg = k * n_shards + s; the seg_n[seg] records at ADDRESS seg_src[seg] (every shard's
+// records may lie in a buffer of their own) become vsc_hit records [seg_dst, ...) of `out` with guide / strand of key
+// first_key + k; seg_side (optional): the address of the segment's 16-bit side values (one per record: the votes of the shard's
+// classifier), copied to side_out at the same places
+__global__ __launch_bounds__(256) void merge_packed_kernel(const uint64_t *seg_src, const uint64_t *seg_dst, const uint32_t *seg_n,
+                                                           uint32_t n_shards, uint32_t first_key, const uint32_t *contig_off,
+                                                           const uint32_t *contig_end, uint32_t n_contigs, vsc_hit *out, uint32_t *bad,
+                                                           const uint64_t *seg_side, uint16_t *side_out)
 {
     const uint32_t seg = blockIdx.x;
     const uint32_t n = seg_n[seg];
     if (n == 0) return;
     const uint32_t key = first_key + seg / n_shards;
-    const uint64_t src = seg_src[seg], dst = seg_dst[seg];
+    const uint64_t *in = (const uint64_t *)seg_src[seg];
+    const uint64_t dst = seg_dst[seg];
     uint4 *o = (uint4 *)out;
+    if (seg_side) {
+        const uint16_t *side = (const uint16_t *)seg_side[seg];
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) side_out[dst + i] = side[i];
+    }
     // A segment's records ascend in position, and so do the records a thread takes (every blockDim-th): the contig of
     // a record is found by one binary search for the thread's first record and a forward walk from there on (a few
     // contigs per segment: the walk almost never moves).  The records come from a peer or from the caller: one whose
-    // window lies in no contig, or that descends, is counted in *bad (the host refuses the result) and the walk is
+    // window lies in no contig, or that does not ascend, is counted in *bad (the host refuses the result) and the walk is
     // bounded by the contig table whatever the position says.
     uint32_t c = 0, c_start = 0, c_next = 0, prev = 0, n_bad = 0;
     bool placed = false;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint64_t x = in[src + i];
+        const uint64_t x = in[i];
         const uint32_t gpos = (uint32_t)(x >> kRecPosShift), mask = (uint32_t)x & kMask23;
         // (the neighbour's record: loaded by the neighbouring lane anyway, one more hit on the same line)
-        if (i > 0 && (uint32_t)(in[src + i - 1] >> kRecPosShift) >= gpos) ++n_bad;  // not strictly ascending inside the segment
+        if (i > 0 && (uint32_t)(in[i - 1] >> kRecPosShift) >= gpos) ++n_bad;  // not strictly ascending inside the segment
         if (!placed || gpos < prev) {
             uint32_t lo = 0, hi = n_contigs;  // last contig that starts at or before gpos
             while (hi - lo > 1) {
@@ -447,13 +454,13 @@ hipError_t launch_key_bounds(const vsc_hit *in, const uint64_t *range_dev, uint3
     return hipGetLastError();
 }
 
-hipError_t launch_merge_packed(const uint64_t *in, const uint64_t *seg_src, const uint64_t *seg_dst, const uint32_t *seg_n,
-                               uint32_t n_segs, uint32_t n_shards, uint32_t first_key, const uint32_t *contig_off,
-                               const uint32_t *contig_end, uint32_t n_contigs, vsc_hit *out, uint32_t *bad, hipStream_t stream)
+hipError_t launch_merge_packed(const uint64_t *seg_src, const uint64_t *seg_dst, const uint32_t *seg_n, uint32_t n_segs, uint32_t n_shards,
+                               uint32_t first_key, const uint32_t *contig_off, const uint32_t *contig_end, uint32_t n_contigs, vsc_hit *out,
+                               uint32_t *bad, const uint64_t *seg_side, uint16_t *side_out, hipStream_t stream)
 {
     if (n_segs == 0) return hipSuccess;
-    hipLaunchKernelGGL(merge_packed_kernel, dim3(n_segs), dim3(256), 0, stream, in, seg_src, seg_dst, seg_n, n_shards, first_key,
-                       contig_off, contig_end, n_contigs, out, bad);
+    hipLaunchKernelGGL(merge_packed_kernel, dim3(n_segs), dim3(256), 0, stream, seg_src, seg_dst, seg_n, n_shards, first_key, contig_off,
+                       contig_end, n_contigs, out, bad, seg_side, side_out);
     return hipGetLastError();
 }
 

@@ -8,10 +8,19 @@
 // RCCL is bound at run time (dlopen): the library loads and works on one device without it, and in a Python
 // process it shares the copy PyTorch has already loaded.  Devices may repeat in the list (several contexts on
 // one GPU - how the tests run N shards on a one-GPU box); the exchange then is plain device copies.
+//
+// One engine serves vsc_multi_search (one batch) and vsc_multi_search_stream: a host thread per shard searches (and scores)
+// batch after batch into one of two exchange slots; the calling thread sends every shard's records to the first device the
+// moment THAT shard is ready, merges the batch on a context of its own there and hands it to the caller - while the shards
+// are already searching the next batch.
 #include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,7 +54,10 @@ struct Rccl {
     {
         if (lib) return true;
         std::string last;
-        for (const char *name : {only ? only : "librccl.so.1", only ? only : "librccl.so"}) {
+        std::vector<const char *> names;
+        if (only) names = {only};
+        else names = {"librccl.so.1", "librccl.so"};
+        for (const char *name : names) {
             lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (lib) break;
             const char *e = dlerror();  // (one call: dlerror() clears the state it reports)
@@ -78,13 +90,16 @@ struct Rccl {
 struct vsc_multi {
     std::vector<int> device;
     std::vector<vsc_ctx *> ctx;
+    vsc_ctx *merge_ctx = nullptr;       // on device[0]: owns the merged results; its stream is not a shard's
     std::vector<hipStream_t> xstream;   // exchange streams, one per context (RCCL's streams)
-    std::vector<uint64_t *> d_count;    // per context: [1 + n] 64-bit words - own count, then the all-gathered counts
     bool use_rccl = false;
     Rccl rccl;
     std::vector<ncclComm_t> comm;
-    DeviceBuf gather;                   // on device[0]: the exchange records of all shards in shard order
-    std::vector<DeviceBuf> xbuf;        // per context: its shard's 8-byte exchange records
+    // exchange buffers: two slots per shard on the shard's device (records, votes) - a shard fills one while the other is
+    // being sent - and one landing buffer per shard on device[0]
+    std::vector<DeviceBuf> xbuf[2], vbuf[2];
+    std::vector<DeviceBuf> gbuf, gvotes;
+    DeviceBuf votes_out;                // on device[0]: the merged batch's votes
     std::string err;
     vsc_multi_timing timing{};
 };
@@ -92,7 +107,7 @@ struct vsc_multi {
 struct vsc_multi_genome {
     vsc_multi *multi = nullptr;
     std::vector<vsc_genome *> shard;    // null: the shard owns no words of this (small) genome
-    vsc_genome *table0 = nullptr;       // the contig table on the first device when shard[0] is null (for the merge)
+    vsc_genome *table = nullptr;        // the contig table on the first device, for the merge context
 };
 
 namespace {
@@ -151,25 +166,26 @@ int vsc_multi_create_debug(const int *device_ids, int n, const vsc_multi_debug_p
     if (!out) return VSC_ERR_INVALID;
     *out = nullptr;
     if (!device_ids || n <= 0 || n > 64) return VSC_ERR_INVALID;
-    vsc_multi *m = new (std::nothrow) vsc_multi();
+    // (held by a smart pointer until it is handed over: an exception half-way releases the contexts and streams made so far)
+    std::unique_ptr<vsc_multi, int (*)(vsc_multi *)> holder(new (std::nothrow) vsc_multi(), vsc_multi_destroy);
+    vsc_multi *m = holder.get();
     if (!m) return VSC_ERR_NOMEM;
     m->device.assign(device_ids, device_ids + n);
     m->ctx.assign(n, nullptr);
     m->xstream.assign(n, nullptr);
-    m->d_count.assign(n, nullptr);
-    m->xbuf.assign(n, DeviceBuf{});
+    for (int k = 0; k < 2; ++k) {
+        m->xbuf[k].assign(n, DeviceBuf{});
+        m->vbuf[k].assign(n, DeviceBuf{});
+    }
+    m->gbuf.assign(n, DeviceBuf{});
+    m->gvotes.assign(n, DeviceBuf{});
     for (int i = 0; i < n; ++i) {
         const int rc = vsc_ctx_create(device_ids[i], &m->ctx[i]);
-        if (rc != VSC_OK) {
-            vsc_multi_destroy(m);
-            return rc;
-        }
-        if (hipSetDevice(device_ids[i]) != hipSuccess || hipStreamCreate(&m->xstream[i]) != hipSuccess ||
-            hipMalloc((void **)&m->d_count[i], (size_t)(1 + n) * sizeof(uint64_t)) != hipSuccess) {
-            vsc_multi_destroy(m);
-            return VSC_ERR_DEVICE;
-        }
+        if (rc != VSC_OK) return rc;
+        if (hipSetDevice(device_ids[i]) != hipSuccess || hipStreamCreate(&m->xstream[i]) != hipSuccess) return VSC_ERR_DEVICE;
     }
+    const int mrc = vsc_ctx_create(device_ids[0], &m->merge_ctx);
+    if (mrc != VSC_OK) return mrc;
     // RCCL needs one communicator rank per DISTINCT device; a list with repeats (tests, rehearsals) exchanges by
     // device copies.  Hooks (varscot_hip_debug.h): rccl = 0 forces copies, 1 insists on RCCL (an error if it
     // cannot be set up).
@@ -191,17 +207,15 @@ int vsc_multi_create_debug(const int *device_ids, int n, const vsc_multi_debug_p
         }
         if (!ok && forced) {
             std::fprintf(stderr, "vsc_multi_create: %s\n", why.c_str());
-            vsc_multi_destroy(m);
             return VSC_ERR_DEVICE;
         }
         m->use_rccl = ok;  // not forced and unavailable: peer copies carry the records instead
         if (!ok) m->err = why;  // (vsc_multi_last_error says why the copies are in use)
     } else if (forced) {
         std::fprintf(stderr, "vsc_multi_create: RCCL was asked for but needs distinct devices\n");
-        vsc_multi_destroy(m);
         return VSC_ERR_INVALID;
     }
-    *out = m;
+    *out = holder.release();
     return VSC_OK;
     });
 }
@@ -214,13 +228,18 @@ int vsc_multi_destroy(vsc_multi *m)
             if (c) (void)m->rccl.CommDestroy(c);
     if (!m->device.empty()) {
         (void)hipSetDevice(m->device[0]);
-        m->gather.release();
+        for (auto &b : m->gbuf) b.release();
+        for (auto &b : m->gvotes) b.release();
+        m->votes_out.release();
+        if (m->merge_ctx) vsc_ctx_destroy(m->merge_ctx);
     }
     for (size_t i = 0; i < m->ctx.size(); ++i) {
         (void)hipSetDevice(m->device[i]);
-        if (m->d_count[i]) (void)hipFree(m->d_count[i]);
-        if (i < m->xbuf.size()) m->xbuf[i].release();
-        if (m->xstream[i]) (void)hipStreamDestroy(m->xstream[i]);
+        for (int k = 0; k < 2; ++k) {
+            if (i < m->xbuf[k].size()) m->xbuf[k][i].release();
+            if (i < m->vbuf[k].size()) m->vbuf[k][i].release();
+        }
+        if (i < m->xstream.size() && m->xstream[i]) (void)hipStreamDestroy(m->xstream[i]);
         if (m->ctx[i]) vsc_ctx_destroy(m->ctx[i]);
     }
     delete m;
@@ -229,6 +248,7 @@ int vsc_multi_destroy(vsc_multi *m)
 
 int vsc_multi_size(const vsc_multi *m) { return m ? (int)m->ctx.size() : 0; }
 vsc_ctx *vsc_multi_ctx(vsc_multi *m, int i) { return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[i] : nullptr; }
+vsc_ctx *vsc_multi_result_ctx(vsc_multi *m) { return m ? m->merge_ctx : nullptr; }
 const char *vsc_multi_last_error(const vsc_multi *m) { return m ? m->err.c_str() : "null multi-device context"; }
 int vsc_multi_uses_rccl(const vsc_multi *m) { return m && m->use_rccl; }
 
@@ -267,13 +287,11 @@ int vsc_multi_genome_load(vsc_multi *m, const uint32_t *hi, const uint32_t *lo, 
             vsc_multi_genome_free(g);
             return mfail(m, rc[r], "shard " + std::to_string(r) + ": " + why);
         }
-    if (!g->shard[0]) {
-        const int trc = genome_table_only(m->ctx[0], contigs, n_contigs, &g->table0);
-        if (trc != VSC_OK) {
-            const std::string why = vsc_last_error(m->ctx[0]);
-            vsc_multi_genome_free(g);
-            return mfail(m, trc, "contig table on the first device: " + why);
-        }
+    const int trc = genome_table_only(m->merge_ctx, contigs, n_contigs, &g->table);
+    if (trc != VSC_OK) {
+        const std::string why = vsc_last_error(m->merge_ctx);
+        vsc_multi_genome_free(g);
+        return mfail(m, trc, "contig table on the first device: " + why);
     }
     *out = g;
     return VSC_OK;
@@ -285,7 +303,7 @@ int vsc_multi_genome_free(vsc_multi_genome *g)
     if (!g) return VSC_OK;
     for (vsc_genome *s : g->shard)
         if (s) vsc_genome_free(s);
-    if (g->table0) vsc_genome_free(g->table0);
+    if (g->table) vsc_genome_free(g->table);
     delete g;
     return VSC_OK;
 }
@@ -306,6 +324,287 @@ int vsc_multi_genome_build_index(vsc_multi *m, vsc_multi_genome *g, const vsc_se
     });
 }
 
+}  // extern "C"
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+double ms_between(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+// on_batch(hits, first read, reads, votes on the first device or null) -> status; *keep = true: the callback took the hits over
+typedef std::function<int(vsc_hits *, uint32_t, uint32_t, const uint16_t *, bool *)> BatchSink;
+
+// The engine behind vsc_multi_search and vsc_multi_search_stream (see the head of this file).
+int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides, uint32_t n_guides, const vsc_search_params *params,
+                uint32_t batch, const vsc_multi_score *score, const BatchSink &sink)
+{
+    const size_t n = m->ctx.size();
+    const uint32_t mode = score ? score->mode : VSC_MULTI_SCORE_NONE;
+    const bool votes = mode == VSC_MULTI_SCORE_VOTES;
+    if (batch == 0 || batch > n_guides) batch = std::max<uint32_t>(n_guides, 1);
+    const uint32_t n_batches = std::max<uint32_t>(1, (n_guides + batch - 1) / batch);
+    const uint32_t k_max = 2 * batch;  // keys of a batch: read << 1 | strand
+    const auto t0 = clk::now();
+
+    // what the shard threads hand to the exchange thread, per slot
+    struct Slot {
+        std::vector<uint64_t> count;       // records of shard r
+        std::vector<uint32_t> key_counts;  // [r * K + k], K = 2 x the batch's reads
+    } slot[2];
+    for (auto &s : slot) {
+        s.count.assign(n, 0);
+        s.key_counts.assign(n * (size_t)k_max, 0);
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<uint32_t> produced(n, 0);  // batches shard r has searched, scored and packed
+    uint32_t transferred = 0;              // batches whose exchange slots have been read out
+    int failed = VSC_OK;
+    std::string why;
+    std::vector<double> search_ms(n, 0), score_ms(n, 0);
+    std::vector<uint64_t> shard_hits(n, 0);
+    std::vector<clk::time_point> finished(n, t0);
+    auto fail_all = [&](int code, const std::string &text) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (failed == VSC_OK) {
+            failed = code;
+            why = text;
+        }
+        cv.notify_all();
+    };
+
+    auto shard_loop = [&](size_t r) {
+        if (hipSetDevice(m->device[r]) != hipSuccess) return fail_all(VSC_ERR_DEVICE, "shard " + std::to_string(r) + ": hipSetDevice failed");
+        for (uint32_t b = 0; b < n_batches; ++b) {
+            {
+                std::unique_lock<std::mutex> lk(mu);  // this batch's slot was batch b - 2's: wait until that one has been sent
+                cv.wait(lk, [&] { return failed != VSC_OK || transferred + 2 > b; });
+                if (failed != VSC_OK) return;
+            }
+            const uint32_t first = b * batch, cnt = std::min<uint32_t>(batch, n_guides - std::min(n_guides, first)), K = 2 * cnt;
+            Slot &s = slot[b & 1];
+            s.count[r] = 0;
+            std::fill(s.key_counts.begin() + r * (size_t)K, s.key_counts.begin() + (r + 1) * (size_t)K, 0u);
+            if (g->shard[r]) {
+                vsc_ctx *ctx = m->ctx[r];
+                vsc_hits *part = nullptr;
+                int rc = vsc_search(ctx, g->shard[r], guides + first, cnt, params, &part);
+                if (rc == VSC_OK) {
+                    vsc_timing t{};
+                    (void)vsc_ctx_timing(ctx, &t);
+                    search_ms[r] += t.total_ms;
+                    shard_hits[r] += t.hits;
+                    const uint64_t c = vsc_hits_count(part);
+                    s.count[r] = c;
+                    // what the caller wants of every hit is computed here, on the device that found it
+                    if (rc == VSC_OK && c && mode == VSC_MULTI_SCORE_ROWS)
+                        rc = vsc_score_hits_packed(ctx, g->shard[r], part, guides + first, cnt, 0, c, nullptr, nullptr, nullptr);
+                    if (rc == VSC_OK && c && votes) {
+                        if (m->vbuf[b & 1][r].ensure(c * sizeof(uint16_t)) != hipSuccess) {
+                            ctx->err = "vote buffer allocation failed";
+                            rc = VSC_ERR_NOMEM;
+                        } else {
+                            rc = vsc_score_classify_hits(ctx, g->shard[r], part, guides + first, cnt, score->guide_activity + first, score->model,
+                                                         0, c, m->vbuf[b & 1][r].p, nullptr, nullptr);
+                        }
+                    }
+                    if (rc == VSC_OK && mode != VSC_MULTI_SCORE_NONE && c) {
+                        (void)vsc_ctx_timing(ctx, &t);
+                        score_ms[r] += t.score_ms;
+                    }
+                    if (rc == VSC_OK) {
+                        if (m->xbuf[b & 1][r].ensure(std::max<uint64_t>(c, 1) * VSC_XREC_BYTES) != hipSuccess) {
+                            ctx->err = "exchange buffer allocation failed";
+                            rc = VSC_ERR_NOMEM;
+                        } else {
+                            rc = vsc_hits_pack_exchange(ctx, g->shard[r], part, cnt, m->xbuf[b & 1][r].p, 1, s.key_counts.data() + r * (size_t)K);
+                        }
+                    }
+                    vsc_hits_free(part);  // the 8-byte records carry everything the merge needs
+                }
+                if (rc != VSC_OK) return fail_all(rc, "shard " + std::to_string(r) + ": " + vsc_last_error(ctx));
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                produced[r] = b + 1;
+                finished[r] = clk::now();
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t r = 0; r < n; ++r) pool.emplace_back(shard_loop, r);
+    struct Joiner {
+        std::vector<std::thread> &p;
+        ~Joiner()
+        {
+            for (auto &t : p)
+                if (t.joinable()) t.join();
+        }
+    } joiner{pool};
+
+    // ---- the exchange thread: this one ---------------------------------------------------------------------------
+    vsc_multi_timing mt{};
+    auto hip_fail = [&](const char *what, hipError_t e) {
+        fail_all(e == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+        return false;
+    };
+#define VSC_X(call)                                            \
+    do {                                                       \
+        const hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) return hip_fail(#call, e_);      \
+    } while (0)
+    // Inside an RCCL group nothing may return early: an open group makes every later call on these communicators queue
+    // forever.  The first failure is kept, the group is closed, and the communicators are given up (a half-issued
+    // send / receive pairing cannot be repaired): later searches use device copies.
+    auto give_up_rccl = [&](const char *where, ncclResult_t bad) {
+        for (ncclComm_t &c : m->comm) {
+            if (c && m->rccl.CommAbort) (void)m->rccl.CommAbort(c);
+            c = nullptr;
+        }
+        m->comm.clear();
+        m->use_rccl = false;
+        fail_all(VSC_ERR_DEVICE, std::string(where) + ": " + m->rccl.GetErrorString(bad) + " (RCCL given up, later searches copy)");
+        return false;
+    };
+    // shard r's records (+ votes) of the batch in `s` to the first device
+    auto transfer = [&](size_t r, uint32_t b, const Slot &s) -> bool {
+        const uint64_t c = s.count[r];
+        if (!c) return true;
+        const size_t rec_bytes = c * VSC_XREC_BYTES, vote_bytes = votes ? c * sizeof(uint16_t) : 0;
+        VSC_X(hipSetDevice(m->device[0]));
+        VSC_X(m->gbuf[r].ensure(rec_bytes));
+        if (votes) VSC_X(m->gvotes[r].ensure(vote_bytes));
+        const void *src = m->xbuf[b & 1][r].p, *vsrc = m->vbuf[b & 1][r].p;
+        // (RCCL with ONE device - the hook rccl = 1 / 2 on a one-GPU box - sends to itself, so that the calls are exercised there)
+        if (m->device[r] == m->device[0] && !(m->use_rccl && n == 1)) {
+            VSC_X(hipMemcpyAsync(m->gbuf[r].p, src, rec_bytes, hipMemcpyDeviceToDevice, m->xstream[0]));
+            if (votes) VSC_X(hipMemcpyAsync(m->gvotes[r].p, vsrc, vote_bytes, hipMemcpyDeviceToDevice, m->xstream[0]));
+            if (r != 0) mt.exchanged_bytes += rec_bytes + vote_bytes;  // (another context on the same device: a rehearsal)
+        } else if (m->use_rccl) {
+            ncclResult_t bad = ncclSuccess;
+            auto in_group = [&](ncclResult_t x) {
+                if (bad == ncclSuccess && x != ncclSuccess) bad = x;
+            };
+            in_group(m->rccl.GroupStart());
+            if (bad == ncclSuccess) {
+                in_group(m->rccl.Recv(m->gbuf[r].p, rec_bytes, ncclUint8, (int)r, m->comm[0], m->xstream[0]));
+                in_group(m->rccl.Send(src, rec_bytes, ncclUint8, 0, m->comm[r], m->xstream[r]));
+                if (votes) {
+                    in_group(m->rccl.Recv(m->gvotes[r].p, vote_bytes, ncclUint8, (int)r, m->comm[0], m->xstream[0]));
+                    in_group(m->rccl.Send(vsrc, vote_bytes, ncclUint8, 0, m->comm[r], m->xstream[r]));
+                }
+                in_group(m->rccl.GroupEnd());
+            }
+            if (bad != ncclSuccess) return give_up_rccl("send / receive of the hit records", bad);
+            if (r != 0) mt.exchanged_bytes += rec_bytes + vote_bytes;
+        } else {
+            VSC_X(hipMemcpyPeerAsync(m->gbuf[r].p, m->device[0], src, m->device[r], rec_bytes, m->xstream[0]));
+            if (votes) VSC_X(hipMemcpyPeerAsync(m->gvotes[r].p, m->device[0], vsrc, m->device[r], vote_bytes, m->xstream[0]));
+            mt.exchanged_bytes += rec_bytes + vote_bytes;
+        }
+        return true;
+    };
+    auto finish_transfers = [&]() -> bool {  // everything issued for this batch has arrived / left
+        VSC_X(hipSetDevice(m->device[0]));
+        VSC_X(hipStreamSynchronize(m->xstream[0]));
+        if (m->use_rccl)
+            for (size_t r = 1; r < n; ++r) {
+                VSC_X(hipSetDevice(m->device[r]));
+                VSC_X(hipStreamSynchronize(m->xstream[r]));
+            }
+        return true;
+    };
+#undef VSC_X
+
+    for (uint32_t b = 0; b < n_batches && failed == VSC_OK; ++b) {
+        const uint32_t first = b * batch, cnt = std::min<uint32_t>(batch, n_guides - std::min(n_guides, first)), K = 2 * cnt;
+        const Slot &s = slot[b & 1];
+        std::vector<char> sent(n, 0);
+        size_t n_sent = 0;
+        bool ok = true;
+        clk::time_point all_ready = clk::now();
+        while (n_sent < n && ok) {
+            std::vector<size_t> ready;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] {
+                    if (failed != VSC_OK) return true;
+                    for (size_t r = 0; r < n; ++r)
+                        if (!sent[r] && produced[r] > b) return true;
+                    return false;
+                });
+                if (failed != VSC_OK) break;
+                for (size_t r = 0; r < n; ++r)
+                    if (!sent[r] && produced[r] > b) ready.push_back(r);
+            }
+            all_ready = clk::now();
+            for (size_t r : ready) {  // a shard's records leave the moment it is done - the others are still sorting
+                ok = ok && transfer(r, b, s);
+                sent[r] = 1;
+                ++n_sent;
+            }
+        }
+        if (failed != VSC_OK || !ok) break;
+        if (!finish_transfers()) break;
+        const auto t_arrived = clk::now();
+        mt.exchange_ms += ms_between(all_ready, t_arrived);
+        std::vector<uint32_t> kc(s.key_counts.begin(), s.key_counts.begin() + n * (size_t)K);  // (the slot is reused two batches on)
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            transferred = b + 1;
+        }
+        cv.notify_all();
+        // ---- merge on the first device: shards partition the positions in ascending order ------------------------------
+        std::vector<const void *> rec_ptr(n), vote_ptr(n);
+        for (size_t r = 0; r < n; ++r) {
+            rec_ptr[r] = m->gbuf[r].p;
+            vote_ptr[r] = m->gvotes[r].p;
+        }
+        vsc_hits *merged = nullptr;
+        const int mrc = merge_packed_shards(m->merge_ctx, g->table, rec_ptr.data(), votes ? vote_ptr.data() : nullptr, kc.data(), (uint32_t)n,
+                                            2 * first, K, &merged, votes ? &m->votes_out : nullptr);
+        if (mrc != VSC_OK) {
+            fail_all(mrc, std::string("merge: ") + vsc_last_error(m->merge_ctx));
+            break;
+        }
+        const auto t_merged = clk::now();
+        mt.merge_ms += ms_between(t_arrived, t_merged);
+        bool keep = false;
+        const int crc = sink(merged, first, cnt, votes && vsc_hits_count(merged) ? (const uint16_t *)m->votes_out.p : nullptr, &keep);
+        if (!keep) vsc_hits_free(merged);
+        mt.callback_ms += ms_between(t_merged, clk::now());
+        if (crc != VSC_OK) {
+            fail_all(crc, "the batch callback stopped the stream");
+            break;
+        }
+        mt.batches++;
+    }
+    for (auto &t : pool) t.join();
+    // (landing buffers of a large search are not kept beside the merged result)
+    (void)hipSetDevice(m->device[0]);
+    for (auto &bfr : m->gbuf)
+        if (bfr.cap > (64u << 20)) bfr.release();
+    if (failed != VSC_OK) return mfail(m, failed, why);
+    clk::time_point last = t0;
+    for (size_t r = 0; r < n; ++r) {
+        last = std::max(last, finished[r]);
+        mt.search_ms_max = std::max(mt.search_ms_max, search_ms[r]);
+        mt.score_ms_max = std::max(mt.score_ms_max, score_ms[r]);
+        mt.hits += shard_hits[r];
+    }
+    mt.search_wall_ms = ms_between(t0, last);
+    mt.total_ms = ms_between(t0, clk::now());
+    mt.n_devices = (uint32_t)n;
+    mt.used_rccl = m->use_rccl;
+    m->timing = mt;
+    return VSC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides, uint32_t n_guides,
                      const vsc_search_params *params, vsc_hits **out)
 {
@@ -314,137 +613,30 @@ int vsc_multi_search(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *gu
     *out = nullptr;
     m->err.clear();
     if (!g || g->multi != m || !params || (n_guides && !guides)) return mfail(m, VSC_ERR_INVALID, "vsc_multi_search: null argument");
-    const size_t n = m->ctx.size();
-    using clock = std::chrono::steady_clock;
-    const auto t0 = clock::now();
-    // ---- every device searches all reads on its shard and packs its records for the exchange ---------------------
-    const uint32_t K = 2 * n_guides;
-    std::vector<uint64_t> count(n, 0), off(n + 1, 0);
-    std::vector<uint32_t> key_counts((size_t)n * K, 0);
-    std::vector<int> rc(n, VSC_OK);
-    std::vector<vsc_timing> st(n);
-    on_all(n, [&](size_t r) {
-        if (!g->shard[r]) return;
-        vsc_hits *part = nullptr;
-        rc[r] = vsc_search(m->ctx[r], g->shard[r], guides, n_guides, params, &part);
-        if (rc[r] != VSC_OK) return;
-        (void)vsc_ctx_timing(m->ctx[r], &st[r]);
-        count[r] = vsc_hits_count(part);
-        if (hipSetDevice(m->device[r]) != hipSuccess || m->xbuf[r].ensure(std::max<uint64_t>(count[r], 1) * VSC_XREC_BYTES) != hipSuccess) {
-            m->ctx[r]->err = "exchange buffer allocation failed";
-            rc[r] = VSC_ERR_NOMEM;
-        } else {
-            rc[r] = vsc_hits_pack_exchange(m->ctx[r], g->shard[r], part, n_guides, m->xbuf[r].p, 1, key_counts.data() + r * K);
-        }
-        vsc_hits_free(part);  // the 8-byte records carry everything the merge needs
+    // one batch = one exchange; a read set beyond one search pass is handled inside every shard's vsc_search
+    return run_batches(m, g, guides, n_guides, params, 0, nullptr, [&](vsc_hits *h, uint32_t, uint32_t, const uint16_t *, bool *keep) {
+        *out = h;
+        *keep = true;
+        return VSC_OK;
     });
-    for (size_t r = 0; r < n; ++r)
-        if (rc[r] != VSC_OK) return mfail(m, rc[r], "shard " + std::to_string(r) + ": " + vsc_last_error(m->ctx[r]));
-    const auto t1 = clock::now();
-    vsc_multi_timing mt{};
-    for (size_t r = 0; r < n; ++r) {
-        off[r + 1] = off[r] + count[r];
-        if (g->shard[r]) {
-            mt.search_ms_max = std::max(mt.search_ms_max, st[r].total_ms);
-            mt.hits += st[r].hits;
-        }
-    }
-    const uint64_t total = off[n];
-#define VSC_M(call)                                                                                                  \
-    do {                                                                                                             \
-        const hipError_t e_ = (call);                                                                                \
-        if (e_ != hipSuccess)                                                                                        \
-            return mfail(m, e_ == hipErrorOutOfMemory ? VSC_ERR_NOMEM : VSC_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-#define VSC_N(call)                                                                                       \
-    do {                                                                                                  \
-        const ncclResult_t r_ = (call);                                                                   \
-        if (r_ != ncclSuccess) return mfail(m, VSC_ERR_DEVICE, std::string(#call) + ": " + m->rccl.GetErrorString(r_)); \
-    } while (0)
-    // ---- the one exchange: all records to the first device ------------------------------------------------
-    VSC_M(hipSetDevice(m->device[0]));
-    VSC_M(m->gather.ensure(std::max<uint64_t>(total, 1) * VSC_XREC_BYTES));
-    char *const dst = (char *)m->gather.p;
-    if (m->use_rccl) {
-        // hit counts by all-gather (one 64-bit word per rank), checked against what this process already knows;
-        // then one grouped send / receive per shard
-        for (size_t r = 0; r < n; ++r) {
-            VSC_M(hipSetDevice(m->device[r]));
-            VSC_M(hipMemcpyAsync(m->d_count[r], &count[r], sizeof(uint64_t), hipMemcpyHostToDevice, m->xstream[r]));
-        }
-        // Inside a group nothing may return early: an open group makes every later RCCL call on these communicators
-        // queue forever.  The first failure is kept, the group is closed, and the communicators are given up
-        // (a half-issued send / receive pairing cannot be repaired): later searches use device copies.
-        ncclResult_t bad = ncclSuccess;
-        auto in_group = [&](ncclResult_t r) {
-            if (bad == ncclSuccess && r != ncclSuccess) bad = r;
-        };
-        auto give_up_rccl = [&](const char *where) {
-            for (ncclComm_t &c : m->comm) {
-                if (c && m->rccl.CommAbort) (void)m->rccl.CommAbort(c);
-                c = nullptr;
-            }
-            m->comm.clear();
-            m->use_rccl = false;
-            return mfail(m, VSC_ERR_DEVICE, std::string(where) + ": " + m->rccl.GetErrorString(bad) + " (RCCL given up, later searches copy)");
-        };
-        VSC_N(m->rccl.GroupStart());
-        for (size_t r = 0; r < n && bad == ncclSuccess; ++r)
-            in_group(m->rccl.AllGather(m->d_count[r], m->d_count[r] + 1, 1, ncclUint64, m->comm[r], m->xstream[r]));
-        in_group(m->rccl.GroupEnd());
-        if (bad != ncclSuccess) return give_up_rccl("all-gather of the hit counts");
-        std::vector<uint64_t> seen(n, 0);
-        VSC_M(hipSetDevice(m->device[0]));
-        VSC_M(hipMemcpyAsync(seen.data(), m->d_count[0] + 1, n * sizeof(uint64_t), hipMemcpyDeviceToHost, m->xstream[0]));
-        VSC_M(hipStreamSynchronize(m->xstream[0]));
-        if (seen != count) return mfail(m, VSC_ERR_DEVICE, "vsc_multi_search: the all-gathered hit counts differ from the shards' counts");
-        VSC_N(m->rccl.GroupStart());
-        for (size_t r = 0; r < n && bad == ncclSuccess; ++r) {
-            if (!count[r]) continue;
-            in_group(m->rccl.Recv(dst + off[r] * VSC_XREC_BYTES, count[r] * VSC_XREC_BYTES, ncclUint8, (int)r, m->comm[0], m->xstream[0]));
-            in_group(m->rccl.Send(m->xbuf[r].p, count[r] * VSC_XREC_BYTES, ncclUint8, 0, m->comm[r], m->xstream[r]));
-        }
-        in_group(m->rccl.GroupEnd());
-        if (bad != ncclSuccess) return give_up_rccl("send / receive of the hit records");
-        for (size_t r = 0; r < n; ++r) {
-            VSC_M(hipSetDevice(m->device[r]));
-            VSC_M(hipStreamSynchronize(m->xstream[r]));
-        }
-    } else {
-        VSC_M(hipSetDevice(m->device[0]));
-        for (size_t r = 0; r < n; ++r) {
-            if (!count[r]) continue;
-            if (m->device[r] == m->device[0])
-                VSC_M(hipMemcpyAsync(dst + off[r] * VSC_XREC_BYTES, m->xbuf[r].p, count[r] * VSC_XREC_BYTES, hipMemcpyDeviceToDevice, m->xstream[0]));
-            else
-                VSC_M(hipMemcpyPeerAsync(dst + off[r] * VSC_XREC_BYTES, m->device[0], m->xbuf[r].p, m->device[r], count[r] * VSC_XREC_BYTES,
-                                         m->xstream[0]));
-        }
-        VSC_M(hipStreamSynchronize(m->xstream[0]));
-    }
-    const auto t2 = clock::now();
-    // ---- merge on the first device: shards partition the positions in ascending order ------------------------
-    const vsc_genome *table = g->shard[0] ? g->shard[0] : g->table0;
-    const int mrc = vsc_hits_merge_packed(m->ctx[0], table, dst, 1, key_counts.data(), (uint32_t)n, 0, K, out);
-    // (the gathered records are not kept beside the merged result)
-    if (total * VSC_XREC_BYTES > (64u << 20)) {
-        (void)hipSetDevice(m->device[0]);
-        m->gather.release();
-    }
-    if (mrc != VSC_OK) return mfail(m, mrc, std::string("merge: ") + vsc_last_error(m->ctx[0]));
-    const auto t3 = clock::now();
-    auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    mt.search_wall_ms = ms(t0, t1);
-    mt.exchange_ms = ms(t1, t2);
-    mt.merge_ms = ms(t2, t3);
-    mt.total_ms = ms(t0, t3);
-    mt.exchanged_bytes = (total - count[0]) * VSC_XREC_BYTES + (uint64_t)(n - 1) * K * sizeof(uint32_t);
-    mt.n_devices = (uint32_t)n;
-    mt.used_rccl = m->use_rccl;
-    m->timing = mt;
-    return VSC_OK;
-#undef VSC_M
-#undef VSC_N
+    });
+}
+
+int vsc_multi_search_stream(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides, uint32_t n_guides,
+                            const vsc_search_params *params, uint32_t batch_reads, const vsc_multi_score *score,
+                            vsc_multi_batch_fn on_batch, void *user)
+{
+    return mguarded(m, [&]() -> int {
+    if (!m) return VSC_ERR_INVALID;
+    m->err.clear();
+    if (!g || g->multi != m || !params || (n_guides && !guides) || !on_batch)
+        return mfail(m, VSC_ERR_INVALID, "vsc_multi_search_stream: null argument");
+    if (score && score->mode > VSC_MULTI_SCORE_VOTES) return mfail(m, VSC_ERR_INVALID, "vsc_multi_search_stream: unknown scoring mode");
+    if (score && score->mode == VSC_MULTI_SCORE_VOTES && (!score->model || (n_guides && !score->guide_activity)))
+        return mfail(m, VSC_ERR_INVALID, "vsc_multi_search_stream: the votes need a forest and the reads' activities");
+    if (batch_reads == 0 || batch_reads > (uint32_t)kMaxPassReads) batch_reads = kMaxPassReads;
+    return run_batches(m, g, guides, n_guides, params, batch_reads, score,
+                       [&](vsc_hits *h, uint32_t first, uint32_t cnt, const uint16_t *votes_dev, bool *) { return on_batch(user, h, first, cnt, votes_dev); });
     });
 }
 

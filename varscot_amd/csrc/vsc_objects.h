@@ -136,4 +136,9 @@ namespace vsc {
 // A genome object that only carries the contig table (no planes, nothing to search): what vsc_hits_merge_packed
 // needs on a device whose shard of a tiny genome is empty (vsc_multi.cpp).  Freed with vsc_genome_free.
 int genome_table_only(vsc_ctx *ctx, const vsc_contig *contigs, uint32_t n_contigs, vsc_genome **out);
+// vsc_hits_merge_packed over per-shard record buffers on ctx's device, with optional 16-bit side values per record that
+// arrive in side_out in merged order (vsc_api.cpp)
+int merge_packed_shards(vsc_ctx *ctx, const vsc_genome *genome, const void *const *shard_records, const void *const *shard_side,
+                        const uint32_t *key_counts, uint32_t n_shards, uint32_t first_key, uint32_t n_keys, vsc_hits **out,
+                        DeviceBuf *side_out);
 }  // namespace vsc
