@@ -248,6 +248,13 @@ int vsc_hits_pack_exchange(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hit
                            int records_on_device, uint32_t *key_counts);
 int vsc_hits_merge_packed(vsc_ctx *ctx, const vsc_genome *genome, const void *records, int records_on_device,
                           const uint32_t *key_counts, uint32_t n_shards, uint32_t first_key, uint32_t n_keys, vsc_hits **out);
+/* vsc_hits_merge_packed for records that carry 2 bytes of per-hit results each (the votes of the shard's classifier,
+ * vsc_score_classify_hits: computed where the hit was found, before the exchange): `votes` = one uint16 per exchange record, same
+ * order and the same memory space as `records`; votes_out (count of the merged records x 2 bytes; device memory when
+ * votes_out_on_device != 0) receives them in the order of the merged records. */
+int vsc_hits_merge_packed_votes(vsc_ctx *ctx, const vsc_genome *genome, const void *records, const void *votes, int on_device,
+                                const uint32_t *key_counts, uint32_t n_shards, uint32_t first_key, uint32_t n_keys, vsc_hits **out,
+                                void *votes_out, int votes_out_on_device);
 int vsc_hits_free(vsc_hits *hits);
 
 /*

@@ -401,6 +401,30 @@ def _rank_worker(rank, world, port, q, exchange="root"):
             c.close()
             dist.barrier()
             return
+        if exchange == "stream":
+            # configuration 5 with one process per GPU: batches of 5 reads, the forest's votes computed on the owning rank
+            # (device memory, host tensors for the gloo transport), gathered to rank 0 beside the records
+            import torch
+            from varscot_amd.classifier import Forest
+            forest = Forest()
+            act = np.random.default_rng(6).uniform(0.2, 1.8, size=len(guides))
+            out = []
+
+            def score(hits, first, count):
+                v, _ = forest.classify_hits(hits, act[first:first + count])
+                return torch.from_numpy(v.view(np.int16).copy())
+
+            def on_batch(m, first, count, votes):
+                if m is not None:
+                    out.append((first, count, m.to_numpy().tobytes(), votes.numpy().view(np.uint16).tobytes()))
+
+            vdist.sharded_search_stream(c, shard, va.pack_guides(guides), 7, on_batch, 5, algorithm="seed", score=score)
+            if rank == 0:
+                q.put(out)
+            shard.close()
+            c.close()
+            dist.barrier()
+            return
         merged, local = vdist.sharded_search(c, shard, va.pack_guides(guides), 7, exchange=exchange)
         if exchange == "reads":
             q.put((rank, merged.to_numpy().tobytes()))
@@ -444,6 +468,43 @@ def test_sharded_search_over_gloo(oracle):
     want = oracle.search_fast(contigs, guides, 7)
     assert len(want) > 300
     assert got.tobytes() == want.tobytes()
+
+
+def test_sharded_search_stream_with_votes_over_gloo(ctx, oracle):
+    """varscot_amd.dist.sharded_search_stream on two ranks (one GPU, gloo): batches of 5 reads searched on each rank's genome
+    shard, the forest's votes computed there, records + votes gathered to rank 0 while the next batch is searched, merged by
+    vsc_hits_merge_packed_votes.  The batches are the oracle's records of their reads; the votes are, record for record, what one
+    context computes on the whole result."""
+    import socket
+    import torch.multiprocessing as mp
+    from varscot_amd.classifier import Forest
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_rank_worker, args=(r, 2, port, q, "stream")) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=180)
+    assert isinstance(out, list), out
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(4242)
+    guides = random_guides(rng, 16)
+    contigs = make_genome(4242, [300000, 120000, 70000, 23], guides, 7, n_plant=400, n_runs=6)
+    want = oracle.search_fast(contigs, guides, 7)
+    assert [(f, n) for f, n, _, _ in out] == [(0, 5), (5, 5), (10, 5), (15, 1)]
+    got = np.concatenate([np.frombuffer(b, dtype=va.HIT_DTYPE) for _, _, b, _ in out])
+    assert len(want) > 300 and got.tobytes() == want.tobytes()
+    gen = ctx.load_genome(va.PackedGenome.from_sequences(contigs))
+    h = gen.search(guides, 7, algorithm="seed")
+    want_votes, _ = Forest().classify_hits(h, np.random.default_rng(6).uniform(0.2, 1.8, size=len(guides)))
+    h.close()
+    gen.close()
+    assert np.array_equal(np.concatenate([np.frombuffer(v, dtype=np.uint16) for _, _, _, v in out]), want_votes)
 
 
 def test_sharded_search_exchange_by_reads_over_gloo(oracle):

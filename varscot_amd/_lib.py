@@ -121,6 +121,7 @@ SYMBOLS = [
     ("vsc_hits_merge", C.c_int, [_vp, _vp, C.c_int, _vp, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
     ("vsc_hits_pack_exchange", C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, C.c_int, _vp]),
     ("vsc_hits_merge_packed", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    ("vsc_hits_merge_packed_votes", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_vp), _vp, C.c_int]),
     ("vsc_hits_free", C.c_int, [_vp]),
     ("vsc_score_hits", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
     ("vsc_score_hits_packed", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),

@@ -380,15 +380,23 @@ def merge_shard_records(ctx, records_ptr, on_device, shard_counts, n_guides):
     return MergedHits(ctx, h)
 
 
-def merge_packed_records(ctx, genome, records_ptr, on_device, key_counts, first_key=0):
+def merge_packed_records(ctx, genome, records_ptr, on_device, key_counts, first_key=0, votes_ptr=None, votes_out_ptr=None,
+                         votes_out_on_device=False):
     """vsc_hits_merge_packed: records_ptr = the 8-byte exchange records of all shards concatenated in shard order,
     key_counts = uint32[n_shards, n_keys] (records of shard s with key first_key + k); `genome` = any shard of the
-    genome on `ctx` (contig table).  Returns the merged vsc_hit records (guide = key >> 1)."""
+    genome on `ctx` (contig table).  Returns the merged vsc_hit records (guide = key >> 1).
+    votes_ptr / votes_out_ptr (vsc_hits_merge_packed_votes): one uint16 per exchange record, in the memory space of the
+    records, that travelled with them (the votes of the shard's classifier) -> the same values in merged order."""
     kc = np.ascontiguousarray(key_counts, dtype=np.uint32)
     assert kc.ndim == 2
     h = C.c_void_p()
-    check(lib().vsc_hits_merge_packed(ctx._h, genome._h, C.c_void_p(records_ptr), int(bool(on_device)), ptr(kc), kc.shape[0],
-                                      int(first_key), kc.shape[1], C.byref(h)), ctx._h)
+    if votes_ptr is None:
+        check(lib().vsc_hits_merge_packed(ctx._h, genome._h, C.c_void_p(records_ptr), int(bool(on_device)), ptr(kc), kc.shape[0],
+                                          int(first_key), kc.shape[1], C.byref(h)), ctx._h)
+    else:
+        check(lib().vsc_hits_merge_packed_votes(ctx._h, genome._h, C.c_void_p(records_ptr), C.c_void_p(votes_ptr), int(bool(on_device)),
+                                                ptr(kc), kc.shape[0], int(first_key), kc.shape[1], C.byref(h), C.c_void_p(votes_out_ptr),
+                                                int(bool(votes_out_on_device))), ctx._h)
     return MergedHits(ctx, h)
 
 

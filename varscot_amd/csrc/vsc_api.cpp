@@ -1590,38 +1590,86 @@ int vsc_hits_pack_exchange(vsc_ctx *ctx, const vsc_genome *genome, const vsc_hit
     });
 }
 
-int vsc_hits_merge_packed(vsc_ctx *ctx, const vsc_genome *genome, const void *records, int records_on_device, const uint32_t *key_counts,
-                          uint32_t n_shards, uint32_t first_key, uint32_t n_keys, vsc_hits **out)
+}  // extern "C"
+
+namespace {
+// the common body of vsc_hits_merge_packed / _votes: records (and votes) of all shards concatenated, host or device
+int merge_packed_concat(vsc_ctx *ctx, const vsc_genome *genome, const void *records, const void *votes, int on_device, const uint32_t *key_counts,
+                        uint32_t n_shards, uint32_t first_key, uint32_t n_keys, vsc_hits **out, void *votes_out, int votes_out_on_device,
+                        const char *who)
 {
-    return guarded(ctx, [&]() -> int {
     if (!ctx || !out) return VSC_ERR_INVALID;
     *out = nullptr;
     ctx->err.clear();
+    const std::string w(who);
     if (!genome || genome->ctx != ctx || n_shards == 0 || (n_keys && !key_counts))
-        return fail(ctx, VSC_ERR_INVALID, "vsc_hits_merge_packed: null argument or genome of another context");
+        return fail(ctx, VSC_ERR_INVALID, (w + ": null argument or genome of another context").c_str());
     if ((uint64_t)first_key + n_keys > (1ull << 31) || (uint64_t)n_keys * n_shards >= (1ull << 31))
-        return fail(ctx, VSC_ERR_RANGE, "vsc_hits_merge_packed: too many keys");
+        return fail(ctx, VSC_ERR_RANGE, (w + ": too many keys").c_str());
     uint64_t n = 0;
     std::vector<uint64_t> shard_n(n_shards, 0);
     for (uint32_t s = 0; s < n_shards; ++s) {
         for (uint32_t k = 0; k < n_keys; ++k) shard_n[s] += key_counts[(size_t)s * n_keys + k];
         n += shard_n[s];
     }
-    if (n && !records) return fail(ctx, VSC_ERR_INVALID, "vsc_hits_merge_packed: null records");
+    if (n && (!records || (votes_out && !votes))) return fail(ctx, VSC_ERR_INVALID, (w + ": null records").c_str());
     VSC_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t *records_dev = (const uint64_t *)records;
-    if (n && !records_on_device) {
-        VSC_HIP(ctx, ctx->score_feat.ensure(n * sizeof(uint64_t)));  // staging buffer for host input
+    const uint16_t *votes_dev = (const uint16_t *)votes;
+    if (n && !on_device) {  // staging buffers for host input
+        VSC_HIP(ctx, ctx->score_feat.ensure(n * sizeof(uint64_t)));
         VSC_HIP(ctx, hipMemcpyAsync(ctx->score_feat.p, records, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
         records_dev = (const uint64_t *)ctx->score_feat.p;
+        if (votes) {
+            VSC_HIP(ctx, ctx->score_flags.ensure(n * sizeof(uint16_t)));
+            VSC_HIP(ctx, hipMemcpyAsync(ctx->score_flags.p, votes, n * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+            votes_dev = (const uint16_t *)ctx->score_flags.p;
+        }
     }
-    std::vector<const void *> shard_ptr(n_shards);
+    std::vector<const void *> shard_ptr(n_shards), side_ptr(n_shards);
     uint64_t at = 0;
     for (uint32_t s = 0; s < n_shards; ++s) {
         shard_ptr[s] = records_dev + at;
+        side_ptr[s] = votes_dev ? votes_dev + at : nullptr;
         at += shard_n[s];
     }
-    return vsc::merge_packed_shards(ctx, genome, shard_ptr.data(), nullptr, key_counts, n_shards, first_key, n_keys, out, nullptr);
+    DeviceBuf side;  // the merged votes, before they go where the caller wants them
+    const int rc = vsc::merge_packed_shards(ctx, genome, shard_ptr.data(), votes ? side_ptr.data() : nullptr, key_counts, n_shards, first_key,
+                                            n_keys, out, votes && votes_out ? &side : nullptr);
+    if (rc == VSC_OK && n && votes && votes_out) {
+        hipError_t e = hipMemcpyAsync(votes_out, side.p, n * sizeof(uint16_t), votes_out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                      ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            side.release();
+            vsc_hits_free(*out);
+            *out = nullptr;
+            return fail(ctx, VSC_ERR_DEVICE, who, e);
+        }
+    }
+    side.release();
+    return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int vsc_hits_merge_packed(vsc_ctx *ctx, const vsc_genome *genome, const void *records, int records_on_device, const uint32_t *key_counts,
+                          uint32_t n_shards, uint32_t first_key, uint32_t n_keys, vsc_hits **out)
+{
+    return guarded(ctx, [&]() -> int {
+        return merge_packed_concat(ctx, genome, records, nullptr, records_on_device, key_counts, n_shards, first_key, n_keys, out, nullptr, 0,
+                                   "vsc_hits_merge_packed");
+    });
+}
+
+int vsc_hits_merge_packed_votes(vsc_ctx *ctx, const vsc_genome *genome, const void *records, const void *votes, int on_device,
+                                const uint32_t *key_counts, uint32_t n_shards, uint32_t first_key, uint32_t n_keys, vsc_hits **out,
+                                void *votes_out, int votes_out_on_device)
+{
+    return guarded(ctx, [&]() -> int {
+        return merge_packed_concat(ctx, genome, records, votes, on_device, key_counts, n_shards, first_key, n_keys, out, votes_out,
+                                   votes_out_on_device, "vsc_hits_merge_packed_votes");
     });
 }
 

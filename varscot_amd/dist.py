@@ -51,15 +51,16 @@ def all_gather_key_counts(key_counts, device, group=None):
     return torch.stack(rows).cpu().numpy().view(np.uint32)
 
 
-def start_gather_to_root(local, all_counts, group=None, dst=0):
+def start_gather_to_root(local, all_counts, group=None, dst=0, item_bytes=XREC_BYTES):
     """Issues the root gather of the exchange records: returns (receive buffer on dst | None, requests).
-    local: this rank's records (uint8 tensor, 8 bytes per record); all_counts: uint32[world, K]."""
+    local: this rank's records (uint8 tensor, 8 bytes per record); all_counts: uint32[world, K].
+    item_bytes: bytes per record of `local` (2: the votes that travel beside the records, same cuts)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     totals = all_counts.astype(np.int64).sum(axis=1)
     if rank == dst:
-        out = torch.empty(int(totals.sum()) * XREC_BYTES, dtype=torch.uint8, device=local.device)
-        offs = np.concatenate([[0], np.cumsum(totals)]) * XREC_BYTES
+        out = torch.empty(int(totals.sum()) * item_bytes, dtype=torch.uint8, device=local.device)
+        offs = np.concatenate([[0], np.cumsum(totals)]) * item_bytes
         out[offs[dst]:offs[dst + 1]] = local
         ops = [dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], r, group) for r in range(world) if r != dst and totals[r] > 0]
     else:
@@ -195,3 +196,66 @@ def sharded_search_pipelined(ctx, genome_shard, codes, max_mismatches, extra_pam
     if pending is not None:
         finish(pending)
     return out
+
+
+def sharded_search_stream(ctx, genome_shard, codes, max_mismatches, on_batch, batch, extra_pam=None, group=None, device=None,
+                          algorithm="auto", score=None, produce=None, merge=None):
+    """BASELINE configuration 5 with one process per GPU: the reads go through this rank's shard in batches of `batch`; what
+    `score` computes per hit - score(hits, first_read, n_reads) -> uint16 tensor of one value per hit (the forest's votes,
+    Forest.classify_hits into device memory) or None - is computed HERE, on the rank that found the hit, before the exchange;
+    records (and votes, 2 bytes each, with the same cuts) are gathered to rank 0 - the north star's single gather - WHILE the
+    next batch is searched; rank 0 merges and calls on_batch(merged hits | None on other ranks, first_read, n_reads, votes in
+    merged order | None).  The same shape as vsc_multi_search_stream gives one process over N devices.
+    produce / merge: the two GPU steps, replaceable (tests/test_dist.py rehearses the protocol on CPU with the oracle's hits):
+      produce(first, part_codes) -> (records uint8 tensor, uint32 per-key counts, votes uint8 tensor | None)
+      merge(records, votes | None, all_counts, first) -> (merged, votes in merged order | None)      [rank 0 only]"""
+    rank = dist.get_rank(group)
+    on_device = device is not None and torch.device(device).type == "cuda"
+
+    def gpu_produce(first, part):
+        hits = genome_shard.search(part, max_mismatches, extra_pam, algorithm=algorithm)
+        v = score(hits, first, len(part)) if score is not None else None
+        local, counts = packed_records(hits, device)
+        hits.close()
+        return local, counts, (v.view(torch.uint8) if v is not None else None)
+
+    def gpu_merge(recv, vrecv, all_counts, first):
+        if vrecv is None:
+            return merge_packed_records(ctx, genome_shard, recv.data_ptr(), recv.is_cuda, all_counts, 2 * first), None
+        out = torch.empty(max(1, vrecv.numel() // 2), dtype=torch.int16, device=vrecv.device)
+        m = merge_packed_records(ctx, genome_shard, recv.data_ptr(), recv.is_cuda, all_counts, 2 * first, votes_ptr=vrecv.data_ptr(),
+                                 votes_out_ptr=out.data_ptr(), votes_out_on_device=out.is_cuda)
+        return m, out[:vrecv.numel() // 2]
+
+    produce = produce or gpu_produce
+    merge = merge or gpu_merge
+    pending = None
+
+    def finish(p):
+        first, count, keep, recv, rreqs, vrecv, vreqs, all_counts = p
+        _wait(rreqs, recv)
+        _wait(vreqs, vrecv)
+        if rank == 0:
+            merged, votes = merge(recv, vrecv, all_counts, first)
+            try:
+                on_batch(merged, first, count, votes)
+            finally:
+                if hasattr(merged, "close"):
+                    merged.close()
+        else:
+            on_batch(None, first, count, None)
+
+    n = len(codes)
+    for first in range(0, max(n, 1), max(batch, 1)):
+        part = codes[first:first + batch]
+        local, counts, votes = produce(first, part)  # (overlaps the pending gather of the batch before)
+        if pending is not None:
+            finish(pending)
+        all_counts = all_gather_key_counts(counts, device if on_device else None, group)
+        recv, rreqs = start_gather_to_root(local, all_counts, group)
+        vrecv, vreqs = (None, [])
+        if votes is not None:
+            vrecv, vreqs = start_gather_to_root(votes, all_counts, group, item_bytes=2)
+        pending = (first, len(part), (local, votes), recv, rreqs, vrecv, vreqs, all_counts)
+    if pending is not None:
+        finish(pending)
