@@ -9,10 +9,16 @@
 One "step" = one pass of the hot path over one batch of synthetic input: all reads of the workload
 searched (both strands) against the resident synthetic 3 Gbp genome - search kernel, bin sort of the
 hits, record assembly - and, for N > 1, ONE exchange of 8-byte hit records over RCCL plus the merge:
-both shapes are timed and reported (`exchanges`): "root" = the single gather to rank 0 (north star), "reads" =
-every rank gathers and merges its read range (result stays distributed); `value` is the one --exchange names.  Inputs (packed genome planes) are resident in HBM before the timed region starts; results
-stay in HBM.  The genome is sharded by position range across ranks (total work fixed => strong
-scaling).  Rank 0 prints ONE JSON line.
+both shapes are timed and reported (`exchanges`): "root" = the single gather to rank 0 (north star; the headline `value`),
+"reads" = every rank gathers and merges its read range (result stays distributed).  Inputs (packed genome planes) are
+resident in HBM before the timed region starts; results stay in HBM.  The genome is sharded by position range across ranks
+(total work fixed => strong scaling).  Rank 0 prints ONE JSON line.
+
+Two multi-GPU drivers share the kernels and the exchange record:
+  --multi torch   one process per GPU over torch.distributed / RCCL (varscot_amd/dist.py) - what the launcher contract starts
+  --multi abi     ONE process over the N devices behind the C ABI (vsc_multi_*: what `bidir_mapping -D 0,..,N-1` executes)
+  --multi both    (default for N > 1) the torch path is the headline; rank 0 first runs the abi path as a child process - before
+                  it touches a GPU itself - and embeds that line as `multi_abi`
 """
 import argparse
 import json
@@ -40,9 +46,21 @@ VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz (32-b
 LANE_OPS_PER_COMPARE = {"scan": 3.5,     # v_xor + v_bitop3 + v_bcnt + 1/2 v_min3 per (site, read) pair
                         "sliced": 1.875}  # 60 instructions per read and 32 sites: 15 x 2 mismatch vectors (read position 21 is the
                                           # lists' business with the GG / GA PAM set) + 22 adder tree + 5 test + 3 duplicate test
-# measured issue cost of those 60 (tools/micro/valu_rate.hip, cycles per SIMD at 2.4 GHz, 6 waves resident): the 34 that take a
-# mask of the read as SCALAR operand 4.2 each, the 26 with vector operands only 2.6 each
-SLICED_ISSUE_CYCLES_PER_READ_BLOCK = 34 * 4.2 + 26 * 2.6
+# measured issue cost of a vector instruction (tools/micro/valu_rate.hip -> profiles/r03_valu_rate_microbench.txt, cycles per
+# SIMD at 2.4 GHz with six waves resident): 2.6 with vector operands only, 4.2 with one scalar operand
+VALU_ISSUE_CYCLES = {"vector_operands": 2.6, "scalar_operand": 4.2}
+KERNEL_SOURCES = ("vsc_seed.hip", "vsc_kernels.hip", "vsc_sort.hip", "vsc_device.h", "vsc_internal.h")
+
+
+def kernel_sources_sha():
+    """What the committed counters under profiles/ are keyed by: a hash of the kernels' sources.  A lookup made with other
+    kernels than the ones that were profiled prints null instead of a stale number."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "varscot_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -66,9 +84,17 @@ def parse():
                          "process group is gloo and the records travel through host memory (use a small workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL exchange/merge path even with one rank")
-    ap.add_argument("--exchange", default="reads", choices=["reads", "root"],
-                    help="multi-rank exchange of the hit records: 'reads' = every rank gathers and merges its read "
-                         "range (all-to-all, result stays distributed), 'root' = everything to rank 0")
+    ap.add_argument("--exchange", default="root", choices=["reads", "root"],
+                    help="multi-rank exchange of the hit records that `value` reports: 'root' = everything to rank 0 (the north "
+                         "star's single gather), 'reads' = every rank gathers and merges its read range (all-to-all, result stays "
+                         "distributed); both are timed and reported")
+    ap.add_argument("--multi", default=None, choices=["torch", "abi", "both"],
+                    help="multi-GPU driver: torch = one process per GPU (torch.distributed / RCCL), abi = ONE process over the "
+                         "devices behind the C ABI (vsc_multi_*), both = torch as the headline + the abi line embedded (default "
+                         "for N > 1)")
+    ap.add_argument("--abi-devices", default=None,
+                    help="--multi abi: the device list, e.g. 0,0,0,0 (ids may repeat: a rehearsal of N shards on one GPU); "
+                         "default 0..gpus-1")
     ap.add_argument("--cpu-sample-bases", type=int, default=192_000_000)
     ap.add_argument("--master-port", type=int, default=None, help="rendezvous port when bench.py starts the ranks itself")
     ap.add_argument("--classify", action="store_true",
@@ -192,10 +218,140 @@ def sort_roofline(timing_sums, steps):
             "bytes": timing_sums["sort_bytes"] / steps}
 
 
+def run_abi_child(args):
+    """--multi both: the one-process-over-N-devices line (`bench.py --multi abi`) measured by a CHILD process that rank 0
+    starts before it has touched a GPU itself, so that the two drivers never share a process or a moment on the devices.
+    Returns the child's parsed line, or {"error": ...} - the headline does not depend on it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--multi", "abi", "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--workload", args.workload, "--algorithm", args.algorithm, "--batch", str(args.batch),
+           "--no-cpu-baseline"]
+    for flag, v in (("--guides", args.guides), ("--bases", args.bases), ("--mismatches", args.mismatches)):
+        if v is not None:
+            cmd += [flag, str(v)]
+    if args.classify:
+        cmd.append("--classify")
+    if args.abi_devices:
+        cmd += ["--abi-devices", args.abi_devices]
+    elif args.rehearse:  # a one-GPU box: N contexts on device 0
+        cmd += ["--abi-devices", ",".join(["0"] * args.gpus)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                             "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    except Exception as e:  # noqa: BLE001
+        return {"error": "child not run: %r" % (e,)}
+    lines = [l for l in child.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if child.returncode != 0 or not lines:
+        return {"error": "exit code %d: %s" % (child.returncode, child.stderr.decode(errors="replace")[-600:])}
+    try:
+        return json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": "unparsable line: %r" % (e,)}
+
+
+def main_abi(args, json_fd):
+    """--multi abi: ONE process, vsc_multi over the devices (varscot_amd.MultiContext), K timed steps of vsc_multi_search
+    (c2 / c3) or vsc_multi_search_stream with the per-hit scoring on the owning shard (c5) - what `bidir_mapping -D 0,1,...`
+    executes.  Same line as the other driver: value = reads x steps / wall, hits from the library's own counters."""
+    import varscot_amd as va
+    from varscot_amd import synth
+    n_guides, total_bases, max_mm, desc = WORKLOADS[args.workload]
+    n_guides = args.guides or n_guides
+    total_bases = args.bases or total_bases
+    max_mm = args.mismatches if args.mismatches is not None else max_mm
+    if args.workload == "c4":
+        raise SystemExit("workload c4 is a single-GPU configuration")
+    devices = [int(x) for x in args.abi_devices.split(",")] if args.abi_devices else list(range(args.gpus))
+    if va.device_count() < 1 + max(devices):
+        raise SystemExit("bench.py --multi abi: device %d asked for, %d visible" % (max(devices), va.device_count()))
+    algorithm = "seed" if args.algorithm == "auto" else args.algorithm
+    t_gen = time.perf_counter()
+    packed = synth.synthetic_genome(total_bases)
+    t_gen = time.perf_counter() - t_gen
+    ids, seqs = synth.synthetic_guides(n_guides)
+    codes = va.pack_guides(seqs)
+    m = va.MultiContext(devices)
+    g = m.load_genome(packed)
+    del packed
+    if algorithm == "seed":
+        g.build_index()
+    streamed = args.workload == "c5"
+    forest, act = None, None
+    if args.classify:
+        from varscot_amd.classifier import Forest
+        forest = Forest()
+        act = np.random.default_rng(0x5EED0004).uniform(0.2, 1.8, size=n_guides)
+    phases = dict.fromkeys(("search_wall_ms", "search_ms_max", "score_ms_max", "exchange_ms", "merge_ms", "callback_ms", "total_ms"), 0.0)
+    state = {"hits": 0, "bytes": 0, "batches": 0}
+
+    def step(timed):
+        if streamed:
+            seen = []
+            g.search_streamed(codes, max_mm, lambda h, first, count, votes: seen.append(len(h)), batch=args.batch, algorithm=algorithm,
+                              score=("votes" if forest is not None else "rows"), forest=forest, guide_activity=act)
+            n = sum(seen)
+        else:
+            h = g.search(codes, max_mm, algorithm=algorithm)
+            n = len(h)
+            h.close()
+        if timed:
+            t = m.timing()
+            for k in phases:
+                phases[k] += t[k]
+            state["hits"], state["bytes"], state["batches"] = n, t["exchanged_bytes"], t["batches"]
+
+    for _ in range(args.warmup):
+        step(False)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    dt = time.perf_counter() - t0   # (every call returns with all devices idle: the library synchronises its streams)
+    out = {
+        "metric": "guides/sec (candidate sites/sec alongside) at <=%d mismatches on a %.1f Gbp reference" % (max_mm, total_bases / 1e9),
+        "value": n_guides * args.steps / dt, "unit": "guides/s", "n_gpus": len(devices), "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": "%s: %s" % (args.workload, desc), "guides": n_guides, "genome_bases": total_bases, "max_mismatches": max_mm,
+                   "parallelism": "genome-shard x%d" % len(devices), "algorithm": algorithm,
+                   "multi_gpu_path": "ONE process over the devices behind the C ABI: vsc_multi_search%s (csrc/vsc_multi.cpp)"
+                                     % ("_stream" if streamed else ""),
+                   "devices": devices, "exchange": "root", "rccl_ranks": (len(devices) if m.uses_rccl else 0),
+                   "exchange_transport": ("RCCL ncclSend / ncclRecv over xGMI" if m.uses_rccl else
+                                          "device copies (%s)" % (m.last_error() or "repeated device ids / one device")),
+                   "hits_per_step": int(state["hits"]), "candidate_sites_per_s": state["hits"] * args.steps / dt,
+                   "batch": args.batch if streamed else n_guides, "batches": state["batches"],
+                   "per_hit_scoring": (None if not streamed else "score -> classify fused on the owning shard, 2 B of votes per hit travel"
+                                       if forest is not None else "64-byte packed feature rows on the owning shard (computed, dropped)")},
+        "vsc_multi_timing": dict({k: v / args.steps for k, v in phases.items()}, exchanged_bytes=state["bytes"],
+                                 note="host wall times per step (vsc_multi_timing): search = until the slowest shard was ready, "
+                                      "exchange = what the transfers took beyond that, merge on the first device"),
+        "setup": {"genome_generate_s": t_gen},
+        "n_gt_1_rccl_executed": bool(m.uses_rccl and len(set(devices)) > 1),
+    }
+    g.close()
+    m.close()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    under_launcher = "WORLD_SIZE" in os.environ
+    multi = args.multi or ("both" if args.gpus > 1 else "torch")
+    if multi == "abi":
+        # one process does everything: under a launcher that is rank 0, the others have nothing to do
+        if under_launcher and int(os.environ.get("RANK", "0")) != 0:
+            return
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+        return main_abi(args, json_fd)
+    if args.gpus > 1 and not under_launcher:
         launch_ranks(args)
+    abi_line = None
+    if multi == "both" and args.gpus > 1 and int(os.environ.get("RANK", "0")) == 0 and not args.dry_run:
+        abi_line = run_abi_child(args)  # before this process touches a GPU
     # stdout carries exactly one line, the JSON result: everything else that might write to fd 1
     # (RCCL prints a banner there) is sent to stderr
     sys.stdout.flush()
@@ -318,6 +474,7 @@ def main():
     # 102 ms in one piece, 116 ms in four): 4 pieces at 2 ranks (13 GB over one link), 2 at 4, 1 at 8
     sub_batches = args.sub_batches if args.sub_batches is not None else {2: 4, 3: 2, 4: 2}.get(world, 1)
     pipelined = use_dist and args.exchange == "reads" and sub_batches > 1 and args.workload in ("c2", "c3")
+    # (the headline is --exchange root unless asked otherwise: the north star's single gather; "reads" is reported beside it)
 
     # per-step sums of the library's device timings (vsc_timing): every step function returns
     # (objects to close, records of this rank's final result, sums)
@@ -377,16 +534,28 @@ def main():
             genome.search_streamed(codes, max_mm, score_batch, batch=args.batch, algorithm=algorithm)
             add_timing(acc, ctx.timing(), score=True)
             return [], acc["hits"], acc
-        total = 0
-        for b in range(0, n_guides, args.batch):
-            local, merged = search_batch(codes[b:b + args.batch], acc)
-            score_batch(local, b, len(codes[b:b + args.batch]))
+        # several ranks: every batch is scored on the rank that found the hits, then records (+ votes with the classifier)
+        # are gathered to rank 0 while the next batch is searched (varscot_amd.dist.sharded_search_stream)
+        total = [0]
+
+        def score(h, first, count):
+            add_timing(acc, ctx.timing())
+            if forest is not None:
+                votes = torch.empty(max(len(h), 1), dtype=torch.int16, device=device)
+                forest.classify_hits(h, guide_activity[first:first + count], to_host=False, dev_ptr=votes.data_ptr())
+                acc["score_ms"] += ctx.timing()["score_ms"]
+                v = votes[:len(h)]
+                return v if xdev is not None else v.cpu()
+            h.packed_features(to_host=False, mit=False)
             acc["score_ms"] += ctx.timing()["score_ms"]
-            total += len(merged) if merged is not None else 0
-            local.close()
-            if merged is not None:
-                merged.close()
-        return [], total, acc
+            return None
+
+        def on_batch(mh, first, count, votes):
+            if mh is not None:
+                total[0] += len(mh)
+
+        vdist.sharded_search_stream(ctx, genome, codes, max_mm, on_batch, args.batch, device=xdev, algorithm=algorithm, score=score)
+        return [], total[0], acc
 
     def step():
         if args.workload == "c4":
@@ -433,7 +602,8 @@ def main():
     if use_dist:
         # both shapes of the one exchange, K steps each (plain: search, pack, exchange, merge, one after the other)
         exchanges = {}
-        for ex in (("root", "reads") if args.exchange == "reads" else ("reads", "root")):
+        # (the streamed, scored workload always gathers to rank 0: one run)
+        for ex in (("root",) if streamed else ("root", "reads") if args.exchange == "reads" else ("reads", "root")):
             mode.update(exchange=ex, pipelined=False)
             dt_x, sums_x, hits_x, x = timed_run()
             exchanges[ex] = {
@@ -466,37 +636,80 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         guides_per_s = n_guides * args.steps / dt
-        # roofline of the dominant kernel (the search kernel), per step, this rank's shard
+        # ---- roofline ---------------------------------------------------------------------------------------
+        # roofline.frac is the WHOLE STEP's: the 8(d) bytes of the step (what ANY search of this shape has to move: per genome
+        # pass 0.375 B/base of planes, + 16 B per hit + 16 B per read [+ 16 + 64 B per hit with per-hit feature rows]) over the
+        # step's time and the 8 TB/s peak.  Beside it every kernel of the step on ITS OWN bytes (roofline.kernels) - the
+        # bytes its data structure makes it move - and, for the search kernel, the instruction-issue roofline from the
+        # committed counters of the same command (profiles/, keyed by a hash of the kernel sources: stale -> null).
         own_bases = (we - wb) * 32
         scan_avg_ms = sums["scan_ms"] / args.steps
         read_passes = -(-n_guides // args.batch) if streamed else max(1, sums["read_passes"])
-        # per genome pass 0.375 B/base of planes, + 16 B per hit + 16 B per read - the figure for
-        # ANY search of this shape, whatever data structure the kernel reads.  roofline.frac is this one.
-        survey_bytes = 0.375 * own_bases * read_passes + 16.0 * hits_local + 16.0 * n_guides
+        scored = streamed and forest is None
+        survey_bytes = 0.375 * own_bases * read_passes + 16.0 * hits_local + 16.0 * n_guides + (80.0 * hits_local if scored else 0.0)
         if algorithm == "scan":
             kernel, ops_per_compare = "scan_kernel", LANE_OPS_PER_COMPARE["scan"]
             structure_bytes = 0.375 * own_bases * read_passes + 12.0 * hits_local + 8.0 * n_guides
+            structure_model = "planes streamed once per pass (0.375 B/base) + 12 B per hit written + 8 B per read"
         else:
             kernel, ops_per_compare = "seed_sliced_kernel", LANE_OPS_PER_COMPARE["sliced"]
             k_seg = max_mm // 3
             list_entries = n_guides * 3 * (1, 22, 211)[k_seg]
-            # what THIS kernel has to move: bit-sliced sites of the visited buckets (4 B each, read once) + the
-            # per-bucket read lists (16 B per entry) + per hit one 8 B site record read and 8 B written
             structure_bytes = float(stream_bytes) + 16.0 * list_entries + 16.0 * hits_local
-        achieved = survey_bytes / (scan_avg_ms * 1e-3) / 1e9
+            structure_model = ("bit-sliced sites of the visited buckets (4 B each, read once) + read-list entries (16 B each) + "
+                               "per hit one 8 B site record read and one 8 B record written")
         compares = float(pairs_local)
         lane_ops = compares * ops_per_compare / (scan_avg_ms * 1e-3)
-        # HBM traffic of the same kernel from the PMC passes of tools/collect_profiles.sh (FETCH_SIZE x 2 per the
-        # guide's gfx950 correction + WRITE_SIZE, one counter group per run), looked up - not measured in this run
-        traffic, traffic_source = None, None
+        # counters of the same kernel from the PMC passes of tools/collect_profiles.sh (one counter group per run), looked
+        # up - not measured in this run - and only if they were taken with the kernels this run executes
+        traffic, traffic_source, counted = None, None, None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("%s/%s/%d" % (args.workload, algorithm, world))
-                traffic_source = tj.get("_source", "profiles/scan_traffic.json") if traffic is not None else None
+                if tj.get("_kernel_sources_sha") == kernel_sources_sha():
+                    traffic = tj.get("%s/%s/%d" % (args.workload, algorithm, world))
+                    counted = tj.get("%s/%s/%d:counters" % (args.workload, algorithm, world))
+                    traffic_source = tj.get("_source", "profiles/scan_traffic.json") if traffic is not None else None
+                else:
+                    traffic_source = ("profiles/scan_traffic.json was collected with other kernel sources (%s) than this run's (%s): "
+                                      "not reported" % (tj.get("_kernel_sources_sha"), kernel_sources_sha()))
             except Exception:
                 traffic = None
+        valu = {"pair_compares_per_s": compares / (scan_avg_ms * 1e-3), "lane_ops_per_compare": ops_per_compare,
+                "achieved_lane_ops_per_s": lane_ops, "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK, "frac": lane_ops / VALU_LANE_OPS_PEAK,
+                "issue": None}
+        if counted and counted.get("simd_cycles"):
+            v, sc = counted["SQ_INSTS_VALU"], counted["simd_cycles"]
+            valu["issue"] = {
+                "valu_wave_instructions": v, "salu_wave_instructions": counted.get("SQ_INSTS_SALU"), "simd_cycles": sc,
+                "valu_per_simd_cycle": v / sc, "issue_cycles_per_instruction": VALU_ISSUE_CYCLES,
+                # share of the SIMDs' cycles the kernel's vector instructions take at the measured issue costs: between "every
+                # instruction has vector operands only" and "every instruction has one scalar operand"
+                "frac_low": v * VALU_ISSUE_CYCLES["vector_operands"] / sc, "frac_high": v * VALU_ISSUE_CYCLES["scalar_operand"] / sc,
+                "source": "SQ_INSTS_VALU / GRBM_GUI_ACTIVE of profiles/*_seed_pmc.json x the issue costs of profiles/r03_valu_rate_microbench.txt"}
+
+        def kernel_entry(name, ms, nbytes, model, **extra):
+            d = {"kernel": name, "ms": ms, "bytes": nbytes, "bytes_model": model,
+                 "achieved": (nbytes / (ms * 1e-3) / 1e9) if ms else None, "unit": "GB/s",
+                 "frac": (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms else None}
+            d.update(extra)
+            return d
+
+        sort_ms, fin_ms, score_ms = sums["sort_ms"] / args.steps, sums["finalize_ms"] / args.steps, sums["score_ms"] / args.steps
+        fin_bytes = 24.0 * hits_local
+        part_bytes = max(0.0, sums["sort_bytes"] / args.steps - fin_bytes)
+        kernels = [kernel_entry(kernel, scan_avg_ms, structure_bytes, structure_model, valu=valu, hbm_traffic_measured=traffic),
+                   kernel_entry("bin_partition_kernel (+ bin_hist / bin_scan where a level needs them)", sort_ms, part_bytes,
+                                "8 B read + 8 B written per record and partition level (+ 8 B per record for a histogram pass)"),
+                   kernel_entry("bin_finalize_kernel", fin_ms, fin_bytes, "8 B record read + 16 B vsc_hit written per hit")]
+        if streamed:
+            kernels.append(kernel_entry("rf_predict_kernel<fused>" if forest is not None else "score_packed_kernel", score_ms,
+                                        (18.0 if forest is not None else 80.0) * hits_local,
+                                        "16 B vsc_hit read + 2 B of votes written per hit (the forest walk is LDS-bound, DESIGN.md 4.6)"
+                                        if forest is not None else "16 B vsc_hit read + 64 B packed row written per hit"))
+        whole = survey_bytes / (ms_per_step * 1e-3) / 1e9
+        dominant = max(kernels, key=lambda k: k["ms"] or 0.0)
         out = {
             "metric": "guides/sec (candidate sites/sec alongside) at <=%d mismatches on a %.1f Gbp reference" % (max_mm, total_bases / 1e9),
             "value": guides_per_s, "unit": "guides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -515,25 +728,16 @@ def main():
                        "per_hit_scoring": (None if not streamed else
                                            "score -> classify fused: rfClassifier (1000 trees) walked per hit, 2 B of votes per hit"
                                            if forest is not None else "64-byte packed feature rows (442 features) per hit")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": kernel, "launch_ms": scan_avg_ms, "algorithmic_bytes": survey_bytes,
-                         "bytes_model": "SURVEY.md 8(d): 0.375 B/base per genome pass + 16 B/hit + 16 B/read",
-                         # the bytes this kernel's own data structure makes it move, for comparison with `traffic`
-                         "structure_bytes": structure_bytes,
-                         "structure_frac": structure_bytes / (scan_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "whole_step_frac": survey_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "note": "integer/bitwise compare kernel; VALU issue is the binding resource next to HBM "
-                                 "(DESIGN.md section 4) - both are reported; valu counts the comparison only, not the hit path",
-                         "valu": dict({"pair_compares_per_s": compares / (scan_avg_ms * 1e-3),
-                                       "lane_ops_per_compare": ops_per_compare, "achieved_lane_ops_per_s": lane_ops,
-                                       "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK, "frac": lane_ops / VALU_LANE_OPS_PEAK},
-                                      **({"issue_cycles_per_read_and_block": SLICED_ISSUE_CYCLES_PER_READ_BLOCK,
-                                          "issue_frac": compares / 2048.0 * SLICED_ISSUE_CYCLES_PER_READ_BLOCK
-                                                        / (256 * 4 * 2.4e9 * scan_avg_ms * 1e-3),
-                                          "issue_note": "share of the SIMDs' vector issue cycles the comparison alone takes at its "
-                                                        "measured issue costs (the hit path, ~30 more instructions per read and "
-                                                        "block, comes on top)"} if algorithm != "scan" else {}))},
+            "roofline": {"bound": "hbm", "achieved": whole, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": whole / HBM_PEAK_GBS,
+                         "scope": "whole step: SURVEY.md 8(d) bytes of the step / ms_per_step / 8 TB/s",
+                         "algorithmic_bytes": survey_bytes,
+                         "bytes_model": "SURVEY.md 8(d): 0.375 B/base per genome pass + 16 B/hit + 16 B/read"
+                                        + (" + (16 + 64) B/hit for the per-hit feature rows" if scored else ""),
+                         "kernel": dominant["kernel"], "launch_ms": dominant["ms"],
+                         "traffic": traffic if dominant["kernel"] == kernel else None, "traffic_source": traffic_source,
+                         "kernels": kernels,
+                         "note": "the search kernel is an integer/bitwise compare kernel bound by vector-instruction issue, not by "
+                                 "HBM (DESIGN.md section 4.2): its entry carries both rooflines; the sort kernels are the HBM-bound ones"},
             # the ordering of the hits (hand-written bin sort) is the second largest share of a step at m = 8
             "roofline_sort": sort_roofline(sums, args.steps),
             "kernels_ms": {"search": scan_avg_ms, "prep": sums["prep_ms"] / args.steps, "sort": sums["sort_ms"] / args.steps,
@@ -543,8 +747,14 @@ def main():
         }
         if exchanges is not None:
             out["exchanges"] = exchanges
-            out["exchange_ms"] = exchanges[args.exchange]["exchange_ms"]
-            out["exchanged_bytes"] = exchanges[args.exchange]["exchanged_bytes"]
+            head = exchanges.get(args.exchange) or exchanges["root"]
+            out["exchange_ms"], out["exchanged_bytes"] = head["exchange_ms"], head["exchanged_bytes"]
+        if use_dist:
+            out["n_gt_1_rccl_executed"] = bool(world > 1 and dist.get_backend() == "nccl")
+        if abi_line is not None:
+            # the same workload through the product's own multi-device driver (one process over the devices, vsc_multi_*)
+            out["multi_abi"] = abi_line if "error" in abi_line else {
+                k: abi_line.get(k) for k in ("value", "unit", "ms_per_step", "n_gpus", "steps", "config", "vsc_multi_timing", "n_gt_1_rccl_executed")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(total_bases, max_mm, args.cpu_sample_bases)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

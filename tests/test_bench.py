@@ -48,6 +48,33 @@ def test_two_ranks_on_one_gpu_report_both_exchanges():
         assert ex[k]["value"] > 0 and ex[k]["exchange_ms"] >= 0 and ex[k]["record_bytes"] == 8
     assert ex["root"]["exchanged_bytes"] > 0 and line["exchange_ms"] == ex[line["config"]["exchange"]]["exchange_ms"]
     assert line["config"]["hits_per_step"] > 0
+    # the headline is the north star's single gather; the product's own multi-device driver (one process over the devices
+    # behind the C ABI) ran the same workload first, as a child of rank 0, and its line is embedded
+    assert line["config"]["exchange"] == "root" and line["value"] == ex["root"]["value"]
+    abi = line["multi_abi"]
+    assert "error" not in abi, abi
+    assert abi["n_gpus"] == 2 and abi["config"]["devices"] == [0, 0] and abi["value"] > 0
+    assert abi["config"]["hits_per_step"] == line["config"]["hits_per_step"]
+    assert abi["vsc_multi_timing"]["total_ms"] > 0 and abi["n_gt_1_rccl_executed"] is False and line["n_gt_1_rccl_executed"] is False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--classify"]])
+def test_one_process_over_several_devices_behind_the_abi(extra):
+    """`bench.py --multi abi`: vsc_multi_search (c1) and vsc_multi_search_stream with the scoring on the owning shard (a small c5)
+    over three contexts on the one GPU - same line as the other driver, the library's own phase times."""
+    r, line = _bench("--multi", "abi", "--gpus", "3", "--abi-devices", "0,0,0", "--workload", "c1", "--mismatches", "6", "--steps", "2",
+                     "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 3 and line["config"]["exchange"] == "root" and line["config"]["rccl_ranks"] == 0
+    assert "device copies" in line["config"]["exchange_transport"] and line["config"]["hits_per_step"] > 0
+    t = line["vsc_multi_timing"]
+    assert t["search_wall_ms"] > 0 and t["merge_ms"] > 0 and t["total_ms"] >= t["search_wall_ms"]
+    r, line5 = _bench("--multi", "abi", "--gpus", "2", "--abi-devices", "0,0", "--workload", "c5", "--guides", "40", "--bases", "2000000",
+                      "--batch", "16", "--steps", "1", "--warmup", "1", *extra)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line5["config"]["batches"] == 3 and line5["config"]["hits_per_step"] > 0 and line5["vsc_multi_timing"]["score_ms_max"] > 0
+    assert ("classify" in line5["config"]["per_hit_scoring"]) == bool(extra)
 
 
 @pytest.mark.gpu
@@ -57,4 +84,11 @@ def test_one_gpu_line_has_the_contract_fields():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
         assert k in line
-    assert line["n_gpus"] == 1 and "exchanges" not in line
+    assert line["n_gpus"] == 1 and "exchanges" not in line and "multi_abi" not in line
+    # roofline.frac is the whole step's; every kernel of the step is listed on its own bytes
+    roof = line["roofline"]
+    assert abs(roof["frac"] - roof["algorithmic_bytes"] / (line["ms_per_step"] * 1e-3) / 1e9 / roof["peak"]) < 1e-9
+    names = [k["kernel"] for k in roof["kernels"]]
+    assert names[0] in ("seed_sliced_kernel", "scan_kernel") and any("partition" in n for n in names) and "bin_finalize_kernel" in names
+    assert all(k["bytes"] >= 0 and k["ms"] >= 0 for k in roof["kernels"])
+    assert "issue" in roof["kernels"][0]["valu"]
