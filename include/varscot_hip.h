@@ -336,6 +336,8 @@ typedef struct {
 } vsc_multi_timing;
 int vsc_multi_create(const int *device_ids, int n, vsc_multi **out);
 int vsc_multi_destroy(vsc_multi *m);
+/* vsc_ctx_release_scratch on every context of the set + the pooled exchange buffers (they stay allocated between searches). */
+int vsc_multi_release_scratch(vsc_multi *m);
 int vsc_multi_size(const vsc_multi *m);
 vsc_ctx *vsc_multi_ctx(vsc_multi *m, int i);  /* the i-th shard's context */
 /* The context on the first device that owns the merged results (its own stream: a batch is merged there while the shards -

@@ -129,6 +129,7 @@ SYMBOLS = [
     ("vsc_score_pairs", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     ("vsc_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
     ("vsc_multi_destroy", C.c_int, [_vp]),
+    ("vsc_multi_release_scratch", C.c_int, [_vp]),
     ("vsc_multi_size", C.c_int, [_vp]),
     ("vsc_multi_ctx", _vp, [_vp, C.c_int]),
     ("vsc_multi_result_ctx", _vp, [_vp]),

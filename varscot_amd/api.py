@@ -439,6 +439,10 @@ class MultiContext:
         for i in range(len(self.devices)):
             check(lib().vsc_ctx_set_debug_params(lib().vsc_multi_ctx(self._h, i), C.byref(d) if hooks else None))
 
+    def release_scratch(self):
+        """vsc_multi_release_scratch: the pooled scratch of every context and the exchange buffers back to the devices."""
+        self._check(lib().vsc_multi_release_scratch(self._h))
+
     def timing(self):
         t = _lib.MultiTiming()
         self._check(lib().vsc_multi_get_timing(self._h, C.byref(t)))

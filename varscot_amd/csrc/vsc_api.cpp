@@ -849,7 +849,7 @@ struct SortInfo {
 // partition reserves room with the bin cursors alone; a bin that outgrows its slot (repeats) makes the level run again
 // with the histogram and clears *slots, so that later searches of this genome and budget go the exact way at once.
 hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg> segs, uint64_t *src, uint64_t *other,
-                    unsigned key_bits, unsigned pos_pad, vsc_hit *out, hipEvent_t ev_sorted, SortInfo *info,
+                    unsigned key_bits, unsigned pos_pad, uint32_t pos_base, vsc_hit *out, hipEvent_t ev_sorted, SortInfo *info,
                     DeviceBuf *other_buf = nullptr, bool *slots = nullptr)
 {
     // (key_bits counts the meaningful bits: the pos_pad zero bits at the bottom of every position field are not among them)
@@ -900,7 +900,8 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
                     *slots = false;  // remembered per genome and budget: later searches do not ask again
                 }
             }
-            hipError_t ge = other_buf->ensure((size_t)(use_slots ? slot_records : span) * sizeof(uint64_t));
+            // (never less than the compact layout: a slot partition that overflows runs again the exact way, into the same buffer)
+            hipError_t ge = other_buf->ensure((size_t)(use_slots ? std::max(slot_records, span) : span) * sizeof(uint64_t));
             if (ge == hipErrorOutOfMemory && use_slots) {
                 (void)hipGetLastError();
                 use_slots = false;
@@ -1002,6 +1003,7 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             f.sub_bits = std::min<unsigned>(kSortSubBits, rem_after);
             f.sub_shift = kRecPosShift + pos_pad + rem_after - f.sub_bits;
             f.pos_pad = pos_pad;
+            f.pos_base = pos_base;
             f.low_bits = rem_after - f.sub_bits;
             f.over = (SortSeg *)((char *)ctx->sort_over.p + 256);
             f.over_cap = (uint32_t)std::min<size_t>(n_bins, 0xFFFFFFFFu);
@@ -1107,8 +1109,10 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
     if (algo == VSC_ALGO_SCAN) cap = std::max<uint64_t>(cap, (uint64_t)(1.2 * seen_rate * n_guides) + 4096);
     unsigned long long cnt[kCntPart + 4 * kParts] = {};
     const int n_parts = (int)((n_guides + kRegionReads - 1) / kRegionReads);  // output regions of 64 reads
-    // bits the positions of this shard need; the records keep them at the top of their 32-bit position field
-    const unsigned pos_bits = std::max(1u, ceil_log2(((uint64_t)genome->first_word + genome->dev_words) * 32));
+    // bits the positions of this shard need, counted from the shard's first position (a shard of the upper part of a
+    // genome must not leave the top key bits constant); the records keep them at the top of their 32-bit position field
+    const uint32_t pos_base = (uint32_t)(genome->first_word * 32);
+    const unsigned pos_bits = std::max(1u, ceil_log2((uint64_t)genome->dev_words * 32));
     const unsigned pos_pad = pos_bits < 32 ? 32 - pos_bits : 0;
 
     ScanArgs a{};
@@ -1186,6 +1190,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         sa.reserve = 1u << sa.reserve_log2;
         sa.n_parts = (uint32_t)n_parts;
         sa.pos_pad = pos_pad;
+        sa.pos_base = pos_base;
         // a region gets its share of the expected hits + 15 % (read ranges differ) + the open blocks
         part_cap = cap / n_parts + cap / n_parts / 7 + 4096;
         part_cap = std::max<uint64_t>(part_cap, (uint64_t)(1.2 * seen_rate * std::min<uint32_t>(n_guides, kRegionReads)) + 4096);
@@ -1272,6 +1277,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
             l0.bin_bits = bits0;
             l0.bin_shift = kRecKeyBits;  // key >> 39 = read index >> 6 = region
             l0.pos_pad = pos_pad;
+            l0.pos_base = pos_base;
             VSC_HIP_H(hipMemsetAsync(l0.hist, 0, n_bins * sizeof(uint32_t), ctx->stream));
             VSC_HIP_H(launch_bin_hist(l0, ctx->stream));
             VSC_HIP_H(launch_bin_scan(l0, ctx->stream));
@@ -1311,7 +1317,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         // the seed search's regions go through the slot partition (no histogram pass) unless this genome has shown
         // bins that outgrow their slots at this budget
         bool *slots = algo == VSC_ALGO_SEED ? &const_cast<vsc_genome *>(genome)->sort_slots_ok[params->max_mismatches] : nullptr;
-        VSC_HIP_H(bin_sort(ctx, genome, std::move(segs), src, other, key_bits, pos_pad, hits->d_records, ctx->ev[3], &info,
+        VSC_HIP_H(bin_sort(ctx, genome, std::move(segs), src, other, key_bits, pos_pad, pos_base, hits->d_records, ctx->ev[3], &info,
                            algo == VSC_ALGO_SEED ? &ctx->keys_b : nullptr, slots));
     } else {
         VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));

@@ -70,9 +70,11 @@ constexpr int kCounterWords = kCursorBase + kCursors * kCursorStride;
 
 // ---- packed hit record (what the search kernels hand to the sort) --------------------------------------
 //   bits  0..22  mismatch mask in forward-genome window coordinates (NM is its popcount)
-//   bits 23..54  global position of the window start, shifted left by pos_pad = 32 - (bits the genome's positions
-//                need): the zero bits of a small genome sit at the bottom of the field, where the sort's last stage
-//                ignores them, instead of in the middle of the key, where partition levels would be spent on them
+//   bits 23..54  position of the window start RELATIVE TO THE SHARD's first position (a shard of the upper half of the
+//                genome would otherwise leave the top key bits constant: bins by the top position bits fill unevenly, slots
+//                overflow, levels are wasted), shifted left by pos_pad = 32 - (bits the shard's positions need): the zero
+//                bits of a small genome sit at the bottom of the field, where the sort's last stage ignores them, instead
+//                of in the middle of the key, where partition levels would be spent on them
 //   bit  55      strand (1 = '-')
 //   bits 56..61  read index inside its region (read & 63)
 //   bits 62, 63  0; the all-ones word is the sentinel that pads reserved-but-unused record slots
@@ -146,6 +148,7 @@ struct SortArgs {
     uint32_t *bin_start;           // [n_segs << bin_bits] first record of every bin (relative to the segment)
     uint32_t bin_bits, bin_shift;  // bin = (record >> bin_shift) & ((1 << bin_bits) - 1)
     uint32_t pos_pad;              // level 0: left shift of the position field
+    uint32_t pos_base;             // level 0: first global position of the shard (records hold positions relative to it)
     uint32_t xcd_tiles;            // partition: tiles per XCD (0: workgroup b takes tile b)
     // slot mode (no histogram pass): bin i of the level owns records [i * slot_cap, (i + 1) * slot_cap) of `out`; the
     // partition reserves room with `cursor` (zeroed) alone and raises *overflow when a bin does not fit its slot -
@@ -164,6 +167,7 @@ struct FinArgs {
     uint32_t sub_shift, sub_bits;  // LDS counting sort on (record >> sub_shift) & ((1 << sub_bits) - 1) ...
     uint32_t low_bits;             // ... then ranking on the key bits below (0: none left)
     uint32_t pos_pad;              // left shift of the records' position field
+    uint32_t pos_base;             // first global position of the shard: the records' positions count from it
     SortSeg *over;                 // bins with more than `cap` records are listed here for another level
     uint32_t over_cap;
     uint32_t cap;                  // <= kSortCap (smaller in tests only)
@@ -213,6 +217,7 @@ struct SeedArgs {
     uint32_t reserve;              // records a wave reserves per atomic on its region's cursor: a power of two, 64 .. 1024
     uint32_t reserve_log2;
     uint32_t pos_pad;              // left shift of the position field of a record
+    uint32_t pos_base;             // first global position of the shard: a record holds position - pos_base
     uint32_t n_parts;              // regions in use (region of a hit = read index >> kRegionBits)
     unsigned long long part_cap;   // records per region
     unsigned long long *counters;  // kCntPart + 4 p + {0,1,2}, kCntSites (= pairs compared), kCntVisited, kCntOverflow, cursors

@@ -246,6 +246,27 @@ int vsc_multi_destroy(vsc_multi *m)
     return VSC_OK;
 }
 
+int vsc_multi_release_scratch(vsc_multi *m)
+{
+    if (!m) return VSC_ERR_INVALID;
+    if (!m->device.empty()) {
+        (void)hipSetDevice(m->device[0]);
+        for (auto &b : m->gbuf) b.release();
+        for (auto &b : m->gvotes) b.release();
+        m->votes_out.release();
+        if (m->merge_ctx) (void)vsc_ctx_release_scratch(m->merge_ctx);
+    }
+    for (size_t i = 0; i < m->ctx.size(); ++i) {
+        (void)hipSetDevice(m->device[i]);
+        for (int k = 0; k < 2; ++k) {
+            m->xbuf[k][i].release();
+            m->vbuf[k][i].release();
+        }
+        if (m->ctx[i]) (void)vsc_ctx_release_scratch(m->ctx[i]);
+    }
+    return VSC_OK;
+}
+
 int vsc_multi_size(const vsc_multi *m) { return m ? (int)m->ctx.size() : 0; }
 vsc_ctx *vsc_multi_ctx(vsc_multi *m, int i) { return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[i] : nullptr; }
 vsc_ctx *vsc_multi_result_ctx(vsc_multi *m) { return m ? m->merge_ctx : nullptr; }
@@ -399,8 +420,15 @@ int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides,
                     // what the caller wants of every hit is computed here, on the device that found it
                     if (rc == VSC_OK && c && mode == VSC_MULTI_SCORE_ROWS)
                         rc = vsc_score_hits_packed(ctx, g->shard[r], part, guides + first, cnt, 0, c, nullptr, nullptr, nullptr);
+                    // (an exchange buffer that does not fit beside the context's pooled scratch: the scratch goes back first)
+                    auto ensure = [&](DeviceBuf &buf, size_t bytes) {
+                        if (buf.ensure(bytes) == hipSuccess) return true;
+                        (void)hipGetLastError();
+                        (void)vsc_ctx_release_scratch(ctx);
+                        return buf.ensure(bytes) == hipSuccess;
+                    };
                     if (rc == VSC_OK && c && votes) {
-                        if (m->vbuf[b & 1][r].ensure(c * sizeof(uint16_t)) != hipSuccess) {
+                        if (!ensure(m->vbuf[b & 1][r], c * sizeof(uint16_t))) {
                             ctx->err = "vote buffer allocation failed";
                             rc = VSC_ERR_NOMEM;
                         } else {
@@ -413,7 +441,7 @@ int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides,
                         score_ms[r] += t.score_ms;
                     }
                     if (rc == VSC_OK) {
-                        if (m->xbuf[b & 1][r].ensure(std::max<uint64_t>(c, 1) * VSC_XREC_BYTES) != hipSuccess) {
+                        if (!ensure(m->xbuf[b & 1][r], std::max<uint64_t>(c, 1) * VSC_XREC_BYTES)) {
                             ctx->err = "exchange buffer allocation failed";
                             rc = VSC_ERR_NOMEM;
                         } else {
@@ -581,10 +609,8 @@ int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides,
         mt.batches++;
     }
     for (auto &t : pool) t.join();
-    // (landing buffers of a large search are not kept beside the merged result)
-    (void)hipSetDevice(m->device[0]);
-    for (auto &bfr : m->gbuf)
-        if (bfr.cap > (64u << 20)) bfr.release();
+    // (the exchange and landing buffers stay pooled, like every context's scratch: hipMalloc / hipFree of 13 GB cost hundreds
+    // of milliseconds per search - vsc_multi_release_scratch gives them back)
     if (failed != VSC_OK) return mfail(m, failed, why);
     clk::time_point last = t0;
     for (size_t r = 0; r < n; ++r) {

@@ -671,7 +671,7 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
         }
     }
     const uint64_t rec = ((uint64_t)(gid_of & (uint32_t)(kRegionReads - 1)) << kRecReadShift) | ((uint64_t)strand << kRecStrandShift) |
-                         ((uint64_t)(pos << a.pos_pad) << kRecPosShift) | mask;
+                         ((uint64_t)((pos - a.pos_base) << a.pos_pad) << kRecPosShift) | mask;
     sliced_store(a, w, hit, gid_of >> kRegionBits, rec);
 }
 

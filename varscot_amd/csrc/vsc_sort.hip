@@ -97,10 +97,10 @@ __device__ __forceinline__ uint32_t segment_of_tile(const uint32_t *seg_tile0, u
 }
 
 // level 0: a (key, value) pair of the streaming scan -> packed record (the read's region is the bin, not part of it)
-__device__ __forceinline__ uint64_t pack_pair(uint64_t key, uint32_t val, uint32_t pos_pad)
+__device__ __forceinline__ uint64_t pack_pair(uint64_t key, uint32_t val, uint32_t pos_pad, uint32_t pos_base)
 {
     const uint64_t high = (key >> 32) & ((1ull << (kRecKeyBits - 32)) - 1ull);  // read inside its region, strand
-    return (((high << 32) | (uint32_t)((uint32_t)key << pos_pad)) << kRecPosShift) | (val & kMask23);
+    return (((high << 32) | (uint32_t)(((uint32_t)key - pos_base) << pos_pad)) << kRecPosShift) | (val & kMask23);
 }
 
 }  // namespace
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
         const uint64_t at = sg.in_off + first + (in_tile ? i : 0u);
         if (kPairs) {
             const uint64_t key = a.pair_keys[at];
-            r[k] = in_tile ? pack_pair(key, a.pair_vals[at], a.pos_pad) : kRecSentinel;
+            r[k] = in_tile ? pack_pair(key, a.pair_vals[at], a.pos_pad, a.pos_base) : kRecSentinel;
             bin[k] = in_tile ? (uint32_t)(key >> a.bin_shift) : 0u;
         } else {
             const uint64_t v = a.in[at];
@@ -382,10 +382,12 @@ __device__ __forceinline__ void finalize_bin(const FinArgs &a, const uint32_t wh
         // without a partition pass - has all bits set: the range then is everything, and so it is whenever those
         // fields cover the whole position)
         const uint32_t free_bits = a.sub_bits + a.low_bits;
+        // (records hold positions relative to the shard's first one: the range is turned into global positions, saturating)
         const uint32_t any = (uint32_t)(r[0] >> kRecPosShift) >> a.pos_pad;
         const uint32_t p_lo = free_bits >= 32u ? 0u : (any >> free_bits) << free_bits;
-        s_edge[0] = p_lo;
-        s_edge[1] = free_bits >= 32u ? 0xFFFFFFFFu : p_lo | ((1u << free_bits) - 1u);
+        const uint64_t p_hi = free_bits >= 32u ? 0xFFFFFFFFull : (uint64_t)(p_lo | ((1u << free_bits) - 1u)) + a.pos_base;
+        s_edge[0] = free_bits >= 32u ? 0u : (uint32_t)min((uint64_t)p_lo + a.pos_base, (uint64_t)0xFFFFFFFFull);
+        s_edge[1] = (uint32_t)min(p_hi, (uint64_t)0xFFFFFFFFull);
     }
 #pragma unroll
     for (int k = 0; k < kFinItems; ++k) {
@@ -532,7 +534,7 @@ __device__ __forceinline__ void finalize_bin(const FinArgs &a, const uint32_t wh
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (!live[u]) continue;
-            const uint32_t pos = (uint32_t)(x[u] >> kRecPosShift) >> a.pos_pad;
+            const uint32_t pos = ((uint32_t)(x[u] >> kRecPosShift) >> a.pos_pad) + a.pos_base;
             uint32_t c, start;
             if (c_n <= (uint32_t)kFinalizeNear) {
                 // the usual case: the bin's positions lie in at most four contigs - three comparisons
