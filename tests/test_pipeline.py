@@ -13,7 +13,7 @@ from oracle import variants_oracle as vo
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "varscot_amd", "bin")
+BIN = os.environ.get("VSC_TEST_BIN") or os.path.join(ROOT, "varscot_amd", "bin")  # (tools/sanitize_cpu.sh: sanitizer builds)
 
 
 def run(tool, *args):

@@ -9,7 +9,7 @@ import pytest
 from helpers import make_genome, random_guides
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "varscot_amd", "bin")
+BIN = os.environ.get("VSC_TEST_BIN") or os.path.join(ROOT, "varscot_amd", "bin")  # (tools/sanitize_cpu.sh: sanitizer builds)
 
 
 def run(tool, *args):

@@ -10,7 +10,7 @@ from helpers import random_seq
 from oracle import variants_oracle as vo
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "varscot_amd", "bin", "vcf_loader")
+BIN = os.path.join(os.environ.get("VSC_TEST_BIN") or os.path.join(ROOT, "varscot_amd", "bin"), "vcf_loader")
 
 
 def synth_vcf(seed, genome, n_records, n_samples=2, header_contigs=None, indel_rate=0.3, cluster=True):
