@@ -465,25 +465,27 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
     }
     // Temporaries: the extracted sites (sx, sl, sp), sort scratch, the bucket-ordered sites as 16-byte records
     // (full planes: what the bit-slicing pass reads) and the (bucket, strand) starts; all released before returning.
-    DeviceBuf sx, sl, sp, k1, k2, i1, i2, tmp, full, starts, rec16;
+    DeviceBuf sx, sl, sp, full, rec16;
     auto release = [&]() {
-        for (DeviceBuf *b : {&sx, &sl, &sp, &k1, &k2, &i1, &i2, &tmp, &full, &starts, &rec16}) b->release();
+        for (DeviceBuf *b : {&sx, &sl, &sp, &full, &rec16}) b->release();
     };
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t r) {
         if (e == hipSuccess) e = r;
     };
+    HostTimer ht;
     constexpr uint32_t kKeys = 2 * kBuckets;  // (bucket, strand) pairs: inside a bucket '+' sites precede '-' sites
-    // Allocations follow the phases, so that the peak stays at 84 bytes per site (all temporaries at once: 116):
-    //   extract   sx, sl, sp (12 B/site) -> rec16 (16)                      then sx, sl, sp go
-    //   order     rec16 (16) + keys / indices (16) -> full (48)             then rec16, keys, indices go
+    // Allocations follow the phases, so that the peak stays at 84 bytes per site:
+    //   extract   sx, sl, sp (12 B/site) -> rec16 (16)                          then sx, sl, sp go
+    //   order     rec16 (16) + two buffers of sort records (16: the context's pooled keys_a / keys_b, which the searches use
+    //             afterwards anyway) -> full (48)                               then rec16 goes
     //   compact   full (48) -> the resident 8-byte records (24) + edge bits
-    //   slice     full (48) + records (24) -> bit-sliced blocks (12)        then full goes
+    //   slice     full (48) + records (24) -> bit-sliced blocks (12)            then full goes
     const size_t n4 = std::max<uint64_t>(S, 1) * sizeof(uint32_t);
     for (DeviceBuf *b : {&sx, &sl, &sp}) step(b->ensure(n4));
     step(rec16.ensure(std::max<uint64_t>(S, 1) * sizeof(uint4)));
-    step(starts.ensure((kKeys + 1) * sizeof(uint32_t)));
     const size_t edge_words = (size_t)((3 * S + 31) / 32 + 1);
+    ht.lap("index: count pass + buffers");
     if (e == hipSuccess && S > 0) {
         // pass 2: emit
         a.site_x = (uint32_t *)sx.p;
@@ -496,29 +498,112 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         step(hipStreamSynchronize(st));
     }
     for (DeviceBuf *b : {&sx, &sl, &sp}) b->release();
-    for (DeviceBuf *b : {&k1, &k2, &i1, &i2}) step(b->ensure(n4));
-    size_t temp_bytes = 0;
-    step(sort32_temp_bytes(S, 2 * kSegBases + 1, &temp_bytes));
-    step(tmp.ensure(std::max<size_t>(temp_bytes, 16)));
+    ht.lap("index: emit pass");
+    // ---- the three tables: the sites ordered by (bucket of the table's segment, strand) -----------------------------------
+    // A counting sort in the shape of the memory system, by the bin sort's own partition kernels (vsc_sort.hip; rounds 1-3
+    // used rocPRIM's radix sort here): one 8-byte record (key << 32 | site index) per site, level 1 on the top 8 of the 15
+    // key bits, level 2 on the other 7 inside every level-1 bin (256 segments) - each level one read and one write of the
+    // records, a tile's records of a bin leaving as one contiguous piece.  The order inside a (bucket, strand) group is
+    // whatever the tiles' reservations give: nothing depends on it.  The level-2 histogram IS the table of group starts.
+    constexpr unsigned kKeyBits = 2 * kSegBases + 1, kBits1 = 8, kBits2 = kKeyBits - kBits1;
+    constexpr uint32_t kBins1 = 1u << kBits1, kBins2 = 1u << kBits2;
+    step(ctx->keys_a.ensure(std::max<uint64_t>(S, 1) * sizeof(uint64_t)));
+    step(ctx->keys_b.ensure(std::max<uint64_t>(S, 1) * sizeof(uint64_t)));
     step(full.ensure(std::max<uint64_t>(3 * S, 1) * sizeof(uint4)));
+    step(ctx->sort_tabs.ensure(3 * (size_t)(kBins1 * kBins2) * sizeof(uint32_t)));
+    const size_t seg_bytes = (kBins1 * sizeof(SortSeg) + 255) / 256 * 256;
+    step(ctx->sort_segs.ensure(seg_bytes + (kBins1 + 1) * sizeof(uint32_t)));
     uint4 *const sites16 = (uint4 *)full.p;
-    for (int s = 0; s < kSegments && e == hipSuccess; ++s) {
-        step(launch_seed_keys((const uint4 *)rec16.p, S, s, (uint32_t *)k1.p, (uint32_t *)i1.p, st));
-        step(launch_sort32(tmp.p, temp_bytes, (const uint32_t *)k1.p, (uint32_t *)k2.p, (const uint32_t *)i1.p,
-                           (uint32_t *)i2.p, S, 2 * kSegBases + 1, st));
-        step(launch_seed_gather16((const uint4 *)rec16.p, (const uint32_t *)i2.p, S, sites16 + (size_t)s * S, st));
-        step(launch_lower_bound((const uint32_t *)k2.p, S, 2 * kBucketsPerSeg, 0, (uint32_t)(s * S),
-                                (uint32_t *)starts.p + (size_t)s * 2 * kBucketsPerSeg, st));
+    std::vector<uint32_t> bs(kKeys + 1, 0);  // bs[2 b + strand] = first site of bucket b on that strand (over all three tables)
+    ht.lap("index: order buffers");
+    for (int s = 0; s < kSegments && e == hipSuccess && S > 0; ++s) {
+        uint64_t *ra = (uint64_t *)ctx->keys_a.p, *rb = (uint64_t *)ctx->keys_b.p;
+        SortSeg *d_segs = (SortSeg *)ctx->sort_segs.p;
+        uint32_t *d_tile0 = (uint32_t *)((char *)ctx->sort_segs.p + seg_bytes);
+        uint32_t *tabs = (uint32_t *)ctx->sort_tabs.p;
+        step(launch_seed_keys((const uint4 *)rec16.p, S, s, ra, st));
+        // level 1: one segment, 256 bins
+        std::vector<SortSeg> &segs = ctx->host_segs;
+        std::vector<uint32_t> &tile0 = ctx->host_tile0;
+        const uint32_t tiles = (uint32_t)((S + kSortTile - 1) / kSortTile);
+        segs.assign(1, SortSeg{0, 0, 0, (uint32_t)S, 0});
+        tile0.assign({0u, tiles});
+        SortArgs l1{};
+        l1.segs = d_segs;
+        l1.seg_tile0 = d_tile0;
+        l1.n_segs = 1;
+        l1.n_tiles = tiles;
+        l1.in = ra;
+        l1.out = rb;
+        l1.hist = tabs;
+        l1.cursor = tabs + kBins1;
+        l1.bin_start = tabs + 2 * kBins1;
+        l1.bin_bits = kBits1;
+        l1.bin_shift = 32 + kBits2;
+        if (tiles >= 64) l1.xcd_tiles = (tiles + 7) / 8;
+        step(hipMemcpyAsync(d_segs, segs.data(), sizeof(SortSeg), hipMemcpyHostToDevice, st));
+        step(hipMemcpyAsync(d_tile0, tile0.data(), 2 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        step(hipMemsetAsync(l1.hist, 0, kBins1 * sizeof(uint32_t), st));
+        if (e == hipSuccess) step(launch_bin_hist(l1, st));
+        if (e == hipSuccess) step(launch_bin_scan(l1, st));
+        if (e == hipSuccess) step(launch_bin_partition(l1, st));
+        std::vector<uint32_t> h1(kBins1);
+        step(hipMemcpyAsync(h1.data(), l1.hist, kBins1 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        step(hipStreamSynchronize(st));
+        if (e != hipSuccess) break;
+        // level 2: every level-1 bin is a segment of its own, 128 bins each
+        segs.assign(kBins1, SortSeg{});
+        tile0.assign(kBins1 + 1, 0);
+        uint64_t at = 0, t2 = 0;
+        for (uint32_t i = 0; i < kBins1; ++i) {
+            segs[i] = SortSeg{at, at, 0, h1[i], 0};
+            tile0[i] = (uint32_t)t2;
+            t2 += (h1[i] + kSortTile - 1) / kSortTile;
+            at += h1[i];
+        }
+        tile0[kBins1] = (uint32_t)t2;
+        SortArgs l2{};
+        l2.segs = d_segs;
+        l2.seg_tile0 = d_tile0;
+        l2.n_segs = kBins1;
+        l2.n_tiles = (uint32_t)t2;
+        l2.in = rb;
+        l2.out = ra;
+        l2.hist = tabs;
+        l2.cursor = tabs + kBins1 * kBins2;
+        l2.bin_start = tabs + 2 * kBins1 * kBins2;
+        l2.bin_bits = kBits2;
+        l2.bin_shift = 32;
+        if (t2 >= 64) l2.xcd_tiles = (uint32_t)((t2 + 7) / 8);
+        step(hipMemcpyAsync(d_segs, segs.data(), kBins1 * sizeof(SortSeg), hipMemcpyHostToDevice, st));
+        step(hipMemcpyAsync(d_tile0, tile0.data(), (kBins1 + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        step(hipMemsetAsync(l2.hist, 0, (size_t)kBins1 * kBins2 * sizeof(uint32_t), st));
+        if (e == hipSuccess) step(launch_bin_hist(l2, st));
+        if (e == hipSuccess) step(launch_bin_scan(l2, st));
+        if (e == hipSuccess) step(launch_bin_partition(l2, st));
+        if (e == hipSuccess) step(launch_seed_gather16((const uint4 *)rec16.p, ra, S, sites16 + (size_t)s * S, st));
+        std::vector<uint32_t> h2((size_t)kBins1 * kBins2);
+        step(hipMemcpyAsync(h2.data(), l2.hist, h2.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        step(hipStreamSynchronize(st));  // (the host tables of this table's levels go out of use here)
+        if (e != hipSuccess) break;
+        uint64_t run = (uint64_t)s * S;  // key = level-1 bin << 7 | level-2 bin: the groups lie in key order
+        for (size_t k = 0; k < h2.size(); ++k) {
+            bs[(size_t)s * 2 * kBucketsPerSeg + k] = (uint32_t)run;
+            run += h2[k];
+        }
+        if (run != (uint64_t)(s + 1) * S) {
+            *why = "index build: the ordered table lost or gained sites";
+            e = hipErrorUnknown;
+        }
     }
-    if (e == hipSuccess) step(hipStreamSynchronize(st));
-    for (DeviceBuf *b : {&k1, &k2, &i1, &i2, &tmp, &rec16}) b->release();
+    bs[kKeys] = (uint32_t)(3 * S);
+    rec16.release();
+    ht.lap("index: three tables ordered");
     step(hipMalloc((void **)&g->d_ix_sites, std::max<uint64_t>(3 * S, 1) * sizeof(uint2)));
     step(hipMalloc((void **)&g->d_ix_edge, edge_words * sizeof(uint32_t)));
     if (e == hipSuccess) step(hipMemsetAsync(g->d_ix_edge, 0, edge_words * sizeof(uint32_t), st));
-    std::vector<uint32_t> bs(kKeys + 1, 0);  // bs[2 b + strand] = first site of bucket b on that strand
     if (e == hipSuccess) {
         step(launch_seed_compact(sites16, std::max<uint64_t>(S, 1), 3 * S, g->d_ix_sites, g->d_ix_edge, st));
-        step(hipMemcpyAsync(bs.data(), starts.p, bs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         step(hipStreamSynchronize(st));
     }
     if (e != hipSuccess) {
@@ -526,6 +611,7 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         free_index(g);
         return e;
     }
+    ht.lap("index: site records");
     // chunks: at most kSlicedChunk sites of one bucket each; the sites of a chunk also exist bit-sliced, in
     // blocks of 32, from block `vfirst` on.  Word z: bucket | rank in the chunk of its first '-' site << 16
     // (| edge flag << 28, set on the device below)
@@ -556,6 +642,7 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
     if (e == hipSuccess) step(launch_seed_chunk_flags(g->d_ix_chunk_tab, g->ix_chunks, g->d_ix_edge, st));
     step(hipEventRecord(ctx->ev[6], st));
     step(hipStreamSynchronize(st));
+    ht.lap("index: chunk table, bit-sliced blocks");
     release();
     if (e != hipSuccess) {
         free_index(g);

@@ -301,17 +301,12 @@ hipError_t launch_merge_packed(const uint64_t *seg_src, const uint64_t *seg_dst,
 // *out += fingerprint of words [0, n_words) of the three planes (zero *out first)
 hipError_t launch_plane_hash(const uint32_t *hi, const uint32_t *lo, const uint32_t *nm, uint64_t n_words, unsigned long long *out,
                              hipStream_t stream);
-hipError_t sort32_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes);
-hipError_t launch_sort32(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
-                         const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream);
 // vsc_seed.hip
-hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint32_t *keys, uint32_t *idx, hipStream_t stream);
-hipError_t launch_lower_bound(const uint32_t *sorted_keys, uint64_t n, uint32_t n_buckets, uint32_t key_offset,
-                              uint32_t base, uint32_t *out, hipStream_t stream);
+hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint64_t *sort_records, hipStream_t stream);
 hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t max_mm, uint32_t pam21, uint32_t *count,
                              uint32_t *poff, uint4 *list_rest, hipStream_t stream);
 hipError_t launch_seed_pack16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, uint64_t n, uint4 *rec, hipStream_t stream);
-hipError_t launch_seed_gather16(const uint4 *rec, const uint32_t *idx, uint64_t n, uint4 *out, hipStream_t stream);
+hipError_t launch_seed_gather16(const uint4 *rec, const uint64_t *sorted, uint64_t n, uint4 *out, hipStream_t stream);
 hipError_t launch_seed_compact(const uint4 *sites16, uint64_t n_per_table, uint64_t n, uint2 *sites8, uint32_t *edge_bits,
                                hipStream_t stream);
 hipError_t launch_seed_chunk_flags(uint4 *chunk_tab, uint32_t n_chunks, const uint32_t *edge_bits, hipStream_t stream);

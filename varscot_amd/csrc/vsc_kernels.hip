@@ -14,7 +14,6 @@
 
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace vsc {
 
@@ -504,22 +503,6 @@ hipError_t launch_plane_hash(const uint32_t *hi, const uint32_t *lo, const uint3
     const unsigned blocks = (unsigned)std::min<uint64_t>((n_words + 255) / 256, 4096);
     hipLaunchKernelGGL(plane_hash_kernel, dim3(blocks), dim3(256), 0, stream, hi, lo, nm, n_words, out);
     return hipGetLastError();
-}
-
-// 32-bit (key, value) sorts of the one-off index build and of the per-search read lists (a few million pairs): rocPRIM
-hipError_t sort32_temp_bytes(uint64_t n, unsigned end_bit, size_t *bytes)
-{
-    *bytes = 0;
-    return rocprim::radix_sort_pairs((void *)nullptr, *bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                     (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, end_bit);
-}
-
-hipError_t launch_sort32(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
-                         const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit, hipStream_t stream)
-{
-    if (n == 0) return hipSuccess;
-    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit,
-                                     stream);
 }
 
 // ------------------------------------------------------------------------------------------------

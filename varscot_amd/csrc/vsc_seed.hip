@@ -31,15 +31,17 @@ __device__ __forceinline__ uint32_t segment_key(uint32_t x, uint32_t l, int s)
 // ------------------------------------------------------------------------------------------------
 // index build
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void seed_key_kernel(const uint4 *rec, uint64_t n, int seg, uint32_t *keys, uint32_t *idx)
+// One 8-byte sort record per site and table: (bucket << 1 | strand) << 32 | index of the site.  The bin sort's partition
+// kernels (vsc_sort.hip) order them by the 15 key bits in two levels (8 + 7 bits); the index then fetches the site.
+__global__ __launch_bounds__(256) void seed_key_kernel(const uint4 *rec, uint64_t n, int seg, uint64_t *out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4 r = rec[i];  // {hi plane | strand | edge, lo plane, position, 0}
     // bucket, then strand: inside a bucket the '+' sites precede the '-' sites, so that a chunk needs one number
     // (where its '-' sites begin) instead of a strand bit per site record
-    keys[i] = (segment_key(r.x, r.y, seg) << 1) | ((r.x >> kSiteStrandBit) & 1u);
-    idx[i] = (uint32_t)i;
+    const uint32_t key = (segment_key(r.x, r.y, seg) << 1) | ((r.x >> kSiteStrandBit) & 1u);
+    out[i] = ((uint64_t)key << 32) | (uint32_t)i;
 }
 
 // The extracted sites as 16-byte records {hi plane | strand | edge, lo plane, position, 0}: ordering a table by bucket
@@ -53,32 +55,17 @@ __global__ __launch_bounds__(256) void seed_pack16_kernel(const uint32_t *x, con
 }
 
 // the sites in bucket order: out[i] = rec[idx[i]] (what the bit-slicing pass and the compaction read)
-__global__ __launch_bounds__(256) void seed_gather16_kernel(const uint4 *rec, const uint32_t *idx, uint64_t n, uint4 *out)
+__global__ __launch_bounds__(256) void seed_gather16_kernel(const uint4 *rec, const uint64_t *sorted, uint64_t n, uint4 *out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = rec[idx[i]];
+    out[i] = rec[(uint32_t)sorted[i]];  // the low word of a sort record is the site's index
 }
 
-// out[b] = base + (first index i with sorted_keys[i] >= b), b = 0 .. n_buckets (inclusive)
-__global__ __launch_bounds__(256) void lower_bound_kernel(const uint32_t *sorted_keys, uint64_t n, uint32_t n_buckets,
-                                                          uint32_t key_offset, uint32_t base, uint32_t *out)
-{
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > n_buckets) return;
-    const uint32_t want = b + key_offset;
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (sorted_keys[mid] < want) lo = mid + 1; else hi = mid;
-    }
-    out[b] = base + (uint32_t)lo;
-}
-
-hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint32_t *keys, uint32_t *idx, hipStream_t stream)
+hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint64_t *out, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(seed_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, n, seg, keys, idx);
+    hipLaunchKernelGGL(seed_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, n, seg, out);
     return hipGetLastError();
 }
 
@@ -89,10 +76,10 @@ hipError_t launch_seed_pack16(const uint32_t *x, const uint32_t *l, const uint32
     return hipGetLastError();
 }
 
-hipError_t launch_seed_gather16(const uint4 *rec, const uint32_t *idx, uint64_t n, uint4 *out, hipStream_t stream)
+hipError_t launch_seed_gather16(const uint4 *rec, const uint64_t *sorted, uint64_t n, uint4 *out, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(seed_gather16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, idx, n, out);
+    hipLaunchKernelGGL(seed_gather16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, sorted, n, out);
     return hipGetLastError();
 }
 
@@ -144,14 +131,6 @@ hipError_t launch_seed_chunk_flags(uint4 *chunk_tab, uint32_t n_chunks, const ui
 {
     if (n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(seed_chunk_flags_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, chunk_tab, n_chunks, edge_bits);
-    return hipGetLastError();
-}
-
-hipError_t launch_lower_bound(const uint32_t *sorted_keys, uint64_t n, uint32_t n_buckets, uint32_t key_offset,
-                              uint32_t base, uint32_t *out, hipStream_t stream)
-{
-    hipLaunchKernelGGL(lower_bound_kernel, dim3((n_buckets + 1 + 255) / 256), dim3(256), 0, stream, sorted_keys, n,
-                       n_buckets, key_offset, base, out);
     return hipGetLastError();
 }
 
