@@ -100,6 +100,10 @@ def parse():
     ap.add_argument("--classify", action="store_true",
                     help="workload c5: score -> classify fused (vsc_score_classify_hits: the reference's forest walked per hit, "
                          "2 bytes of votes per hit out) instead of writing the 64-byte packed feature rows")
+    ap.add_argument("--rows", default="fused", choices=["fused", "two-pass"],
+                    help="workload c5 on one GPU: fused = vsc_search_stream_rows (the search keeps the sites' bases beside the records, "
+                         "the record assembly writes the feature rows); two-pass = vsc_search_stream + vsc_score_hits_packed from the "
+                         "callback (re-reads the records, gathers the windows from the planes)")
     ap.add_argument("--hook", action="append", default=[], metavar="NAME=VALUE",
                     help="experiment hook of include/varscot_hip_debug.h (e.g. seed_groups_per_cu=2); the defaults are what "
                          "every reported number uses")
@@ -454,6 +458,7 @@ def main():
         torch.cuda.synchronize()
 
     streamed = args.workload == "c5"
+    rows_fused = streamed and args.rows == "fused" and not args.classify and world == 1 and not args.force_dist and algorithm == "seed"
     forest, guide_activity = None, None
     if args.classify:
         from varscot_amd.classifier import Forest
@@ -531,7 +536,10 @@ def main():
         (vsc_search_stream, scoring from the batch callback)."""
         acc = new_acc()
         if not use_dist:
-            genome.search_streamed(codes, max_mm, score_batch, batch=args.batch, algorithm=algorithm)
+            if rows_fused:
+                genome.search_streamed_rows(codes, max_mm, lambda h, first, count, rows_dev: None, batch=args.batch, algorithm=algorithm)
+            else:
+                genome.search_streamed(codes, max_mm, score_batch, batch=args.batch, algorithm=algorithm)
             add_timing(acc, ctx.timing(), score=True)
             return [], acc["hits"], acc
         # several ranks: every batch is scored on the rank that found the hits, then records (+ votes with the classifier)
@@ -697,13 +705,15 @@ def main():
             return d
 
         sort_ms, fin_ms, score_ms = sums["sort_ms"] / args.steps, sums["finalize_ms"] / args.steps, sums["score_ms"] / args.steps
-        fin_bytes = 24.0 * hits_local
-        part_bytes = max(0.0, sums["sort_bytes"] / args.steps - fin_bytes)
+        fin_bytes = (24.0 + (4.0 + 64.0 if rows_fused else 0.0)) * hits_local
+        part_bytes = max(0.0, sums["sort_bytes"] / args.steps - (24.0 + (80.0 if rows_fused else 0.0)) * hits_local)
         kernels = [kernel_entry(kernel, scan_avg_ms, structure_bytes, structure_model, valu=valu, hbm_traffic_measured=traffic),
                    kernel_entry("bin_partition_kernel (+ bin_hist / bin_scan where a level needs them)", sort_ms, part_bytes,
                                 "8 B read + 8 B written per record and partition level (+ 8 B per record for a histogram pass)"),
-                   kernel_entry("bin_finalize_kernel", fin_ms, fin_bytes, "8 B record read + 16 B vsc_hit written per hit")]
-        if streamed:
+                   kernel_entry("bin_finalize_kernel" + ("<rows>" if rows_fused else ""), fin_ms, fin_bytes,
+                                "8 B record + 4 B side word read, 16 B vsc_hit + 64 B packed feature row written per hit (record and side word "
+                                "a second time from L2)" if rows_fused else "8 B record read + 16 B vsc_hit written per hit")]
+        if streamed and not rows_fused:
             kernels.append(kernel_entry("rf_predict_kernel<fused>" if forest is not None else "score_packed_kernel", score_ms,
                                         (18.0 if forest is not None else 80.0) * hits_local,
                                         "16 B vsc_hit read + 2 B of votes written per hit (the forest walk is LDS-bound, DESIGN.md 4.6)"
@@ -727,7 +737,9 @@ def main():
                        "batch": args.batch if streamed else n_guides, "variant_genome": snp_info,
                        "per_hit_scoring": (None if not streamed else
                                            "score -> classify fused: rfClassifier (1000 trees) walked per hit, 2 B of votes per hit"
-                                           if forest is not None else "64-byte packed feature rows (442 features) per hit")},
+                                           if forest is not None else "64-byte packed feature rows (442 features) per hit, written by the record "
+                                           "assembly (vsc_search_stream_rows)" if rows_fused else "64-byte packed feature rows (442 features) per hit, "
+                                           "second pass (vsc_score_hits_packed)")},
             "roofline": {"bound": "hbm", "achieved": whole, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": whole / HBM_PEAK_GBS,
                          "scope": "whole step: SURVEY.md 8(d) bytes of the step / ms_per_step / 8 TB/s",
                          "algorithmic_bytes": survey_bytes,

@@ -210,6 +210,19 @@ int vsc_search(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, u
 typedef int (*vsc_batch_fn)(void *user, vsc_hits *batch, uint32_t first_guide, uint32_t n_guides);
 int vsc_search_stream(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
                       const vsc_search_params *params, uint32_t batch_reads, vsc_batch_fn on_batch, void *user);
+/*
+ * vsc_search_stream with the per-hit feature rows made ON THE WAY (BASELINE configuration 5: "streamed ... + per-hit
+ * classification feature scoring"): every batch arrives with its 64-byte packed rows - rows_dev: device memory,
+ * vsc_hits_count(batch) * 64 bytes, row i belongs to record i, valid inside the callback; the same rows as
+ * vsc_score_hits_packed writes.  The search keeps each site's bases beside its hit record (4 bytes per hit through the
+ * sort) and the kernel that assembles the vsc_hit records writes the row in the same pass - instead of a second kernel
+ * that re-reads the records and gathers 23 bases per hit from the planes (a 64-byte sector for 46 bits).
+ * Replaces, per batch: read_mapping/bidir_mapping.cpp:285-295 + variant_processing/merge_output_bam.h:696-708
+ * (featureMatrixRecord of every record, feature_matrix.h:25-126).
+ */
+typedef int (*vsc_rows_batch_fn)(void *user, vsc_hits *batch, uint32_t first_guide, uint32_t n_guides, const void *rows_dev);
+int vsc_search_stream_rows(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
+                           const vsc_search_params *params, uint32_t batch_reads, vsc_rows_batch_fn on_batch, void *user);
 uint64_t vsc_hits_count(const vsc_hits *hits);
 /* Device pointer to vsc_hits_count() records of type vsc_hit (valid until vsc_hits_free). */
 const void *vsc_hits_data_dev(const vsc_hits *hits);

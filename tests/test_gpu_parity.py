@@ -1040,6 +1040,62 @@ def test_multi_device_search_on_a_genome_smaller_than_the_device_list(oracle):
         m.close()
 
 
+@pytest.mark.parametrize("hook", [{}, {"sort_cap": 256, "sort_max_bits": 3}, {"sort_cap": 512, "sort_slot_cap": 40}, {"sort_cap": 64, "sort_max_bits": 2, "sort_optimistic": 1, "sort_slot_cap": 60000},
+                                  {"seed_shared": 1, "seed_group_out": 1}, {"seed_shared": 0}])
+def test_streamed_search_writes_the_feature_rows_on_the_way(ctx, oracle, hooks, hook):
+    """vsc_search_stream_rows: the search keeps every site's bases beside its hit record (a 4-byte side word that travels through
+    the partition levels of the sort), the record assembly recomputes the mismatch mask from them and writes the hit's packed
+    feature row in the same pass.  Records = the oracle's; rows = vsc_score_hits_packed's on the same hits (which gathers the
+    windows from the planes), row for row - with regions that fit the last stage as they are, several partition levels, the slot
+    partition with and without its fallback, bins that go on to a second level from their slots, both chunk-sharing modes; thousands
+    of hits per read, both strands, N runs, contig ends, reads without hits."""
+    import torch
+    from varscot_amd.dist import DeviceAlias
+    if hook:
+        hooks(**hook)
+    rng = np.random.default_rng(31337)
+    guides = random_guides(rng, 90)
+    pieces = []
+    for _ in range(5000):  # a contig of mutated read copies: thousands of hits for some reads
+        g = guides[int(rng.integers(0, 70))]
+        pieces.append(mutate(rng, g, int(rng.integers(0, 7)), 0, 20) + random_seq(rng, int(rng.integers(0, 3))))
+    contigs = make_genome(31337, [60000, 20000, 33, 9000], guides[:70], 8, n_plant=300, n_runs=3) + ["".join(pieces)]
+    want = oracle.search_fast(contigs, guides, 8)
+    assert len(want) > 5000
+    gen = ctx.load_genome(va.PackedGenome.from_sequences(contigs))
+    seen, recs, rows = [], [], []
+
+    def on_batch(h, first, count, rows_dev):
+        seen.append((first, count))
+        a = h.to_numpy().copy()
+        recs.append(a)
+        if len(a):
+            got = torch.as_tensor(DeviceAlias(rows_dev, 64 * len(a)), device="cuda:0").view(torch.int32).view(-1, 16).cpu().numpy().view(np.uint32).copy()
+            ref, _ = h.packed_features(to_host=True)  # the gathering kernel, on the same records (afterwards: it reuses the scratch)
+            assert np.array_equal(got, ref), np.flatnonzero((got != ref).any(axis=1))[:5]
+            rows.append(got)
+        else:
+            assert not rows_dev
+
+    gen.search_streamed_rows(guides, 8, on_batch, batch=32, algorithm="seed")
+    assert seen == [(0, 32), (32, 32), (64, 26)]
+    assert np.concatenate(recs).tobytes() == want.tobytes()
+    # the rows against the oracle's feature rows, on a sample
+    allrec, allrows = np.concatenate(recs), va.unpack_features(np.concatenate(rows))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    for i in range(0, len(allrec), max(1, len(allrec) // 200)):
+        r = allrec[i]
+        off = contigs[r["contig"]][r["pos"]:r["pos"] + 23]
+        if r["info"] >> 31:
+            off = "".join(comp[c] for c in reversed(off))
+        assert np.array_equal(allrows[i].astype(np.uint32), oracle.feature_row(guides[r["guide"]], off))
+    # the streaming scan (no seed index involved) takes the two-step route behind the same entry point
+    small = []
+    gen.search_streamed_rows(guides[:8], 4, lambda h, f, c, p: small.append((len(h), bool(p))), batch=8, algorithm="scan")
+    assert small and small[0][0] == len(oracle.search_fast(contigs, guides[:8], 4)) and small[0][1] == (small[0][0] > 0)
+    gen.close()
+
+
 @pytest.mark.parametrize("devices,batch,score", [([0] * 8, 16, None), ([0] * 3, 7, "rows"), ([0, 0], 25, "votes"), ([0] * 5, 64, "votes")])
 def test_multi_device_streamed_search_scored_on_the_owning_shard(ctx, oracle, devices, batch, score):
     """vsc_multi_search_stream (BASELINE configuration 5 behind the C ABI): the reads go through all shards batch by batch, every

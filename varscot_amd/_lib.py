@@ -86,6 +86,7 @@ class MultiDebugParams(C.Structure):
 
 
 BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32)  # vsc_batch_fn
+ROWS_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)  # vsc_rows_batch_fn
 MULTI_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)  # vsc_multi_batch_fn
 
 # every symbol include/varscot_hip.h declares: (name, restype, argtypes)
@@ -114,6 +115,7 @@ SYMBOLS = [
     ("vsc_genome_device_bytes", C.c_uint64, [_vp]),
     ("vsc_search", C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(SearchParams), C.POINTER(_vp)]),
     ("vsc_search_stream", C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(SearchParams), C.c_uint32, BATCH_FN, _vp]),
+    ("vsc_search_stream_rows", C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(SearchParams), C.c_uint32, ROWS_BATCH_FN, _vp]),
     ("vsc_hits_count", C.c_uint64, [_vp]),
     ("vsc_hits_data_dev", _vp, [_vp]),
     ("vsc_hits_data", C.c_int, [_vp, C.POINTER(_vp)]),

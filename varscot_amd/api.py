@@ -277,6 +277,35 @@ class Genome:
         check(rc, self.ctx._h)
 
 
+    def search_streamed_rows(self, guides, max_mismatches, on_batch, batch=0, extra_pam=None, algorithm="auto"):
+        """vsc_search_stream_rows: as search_streamed, and every batch arrives with its 64-byte packed feature rows -
+        on_batch(hits, first_guide, n_guides, rows_dev) with rows_dev = device address of len(hits) * 64 bytes (row i belongs
+        to record i; valid inside the call; None for an empty batch).  The rows are written by the kernel that assembles the
+        records - no second pass over the hits, no gather from the planes."""
+        codes = guides if isinstance(guides, np.ndarray) else pack_guides(guides)
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        p = self._params(max_mismatches, extra_pam, algorithm)
+        failure = []
+
+        def trampoline(_user, handle, first, count, rows_dev):
+            try:
+                h = Hits(self, C.c_void_p(handle), codes, owned=False)
+                try:
+                    on_batch(h, int(first), int(count), rows_dev)
+                finally:
+                    h.close()
+                return 0
+            except BaseException as e:  # no exception may cross the C boundary
+                failure.append(e)
+                return -5
+
+        cb = _lib.ROWS_BATCH_FN(trampoline)
+        rc = lib().vsc_search_stream_rows(self.ctx._h, self._h, ptr(codes), len(codes), C.byref(p), int(batch), cb, None)
+        if failure:
+            raise failure[0]
+        check(rc, self.ctx._h)
+
+
 class Hits:
     """Result of one search (vsc_hits): records sorted by (guide, strand, contig, pos)."""
 

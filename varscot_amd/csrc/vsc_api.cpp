@@ -205,7 +205,7 @@ int vsc_ctx_release_scratch(vsc_ctx *ctx)
     if (!ctx) return VSC_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->score_guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a,
+    for (DeviceBuf *b : {&ctx->counters, &ctx->guides, &ctx->score_guides, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->vals_b,
                          &ctx->score_mit, &ctx->score_flags, &ctx->score_feat, &ctx->score_sched, &ctx->sort_segs, &ctx->sort_tabs,
                          &ctx->sort_over, &ctx->seed_off,
                          &ctx->seed_poff, &ctx->seed_lrest})
@@ -918,6 +918,17 @@ unsigned ceil_log2(uint64_t x)
 }
 
 // what one bin sort did (goes into vsc_timing)
+// A search that keeps the sites' bases (vsc_search_stream_rows): every record travels with a 32-bit side word (the site's lo
+// plane; parallel arrays beside the two record buffers) and the finalize kernel writes the hits' packed feature rows.
+struct SortRows {
+    uint32_t *side_src = nullptr;     // side words beside `src`
+    DeviceBuf *side_other = nullptr;  // grows to the size of `other` (in records) x 4 bytes
+    const uint2 *guides = nullptr;    // planes of the pass's reads
+    uint32_t guide_first = 0;         // read index of guides[0]
+    uint4 *rows = nullptr;            // row of result record i at rows + (i - rows_first)
+    uint64_t rows_first = 0;
+};
+
 struct SortInfo {
     unsigned levels = 0;     // partition levels run (0: every region fitted the finalize kernel as it was)
     unsigned bin_bits = 0;   // key bits of the first partition level
@@ -937,8 +948,9 @@ struct SortInfo {
 // with the histogram and clears *slots, so that later searches of this genome and budget go the exact way at once.
 hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg> segs, uint64_t *src, uint64_t *other,
                     unsigned key_bits, unsigned pos_pad, uint32_t pos_base, vsc_hit *out, hipEvent_t ev_sorted, SortInfo *info,
-                    DeviceBuf *other_buf = nullptr, bool *slots = nullptr)
+                    DeviceBuf *other_buf = nullptr, bool *slots = nullptr, const SortRows *rows = nullptr)
 {
+    uint32_t *side_src = rows ? rows->side_src : nullptr, *side_other = nullptr;
     // (key_bits counts the meaningful bits: the pos_pad zero bits at the bottom of every position field are not among them)
     hipStream_t st = ctx->stream;
     unsigned rem = key_bits;  // key bits no partition level has used yet
@@ -982,7 +994,9 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
                 size_t free_b = 0, total_b = 0;
                 if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
                 const uint64_t room = (uint64_t)free_b + other_buf->cap;  // (the buffer's present allocation is given back first)
-                if (slot_records > 4 * n_all + (1ull << 20) || slot_records * sizeof(uint64_t) + (1ull << 30) > room) {
+                // (a search that keeps the sites' bases has a side word beside every slot)
+                const uint64_t slot_bytes = slot_records * (sizeof(uint64_t) + (rows ? sizeof(uint32_t) : 0));
+                if (slot_records > 4 * n_all + (1ull << 20) || slot_bytes + (1ull << 30) > room + (rows ? rows->side_other->cap : 0)) {
                     use_slots = false;
                     *slots = false;  // remembered per genome and budget: later searches do not ask again
                 }
@@ -997,6 +1011,10 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             }
             if (ge != hipSuccess) return ge;
             other = (uint64_t *)other_buf->p;
+            if (rows) {  // the side words' second buffer: as many words as `other` has records
+                VSC_TRY(rows->side_other->ensure(other_buf->cap / sizeof(uint64_t) * sizeof(uint32_t)));
+                side_other = (uint32_t *)rows->side_other->p;
+            }
         }
         std::vector<uint32_t> &tile0 = ctx->host_tile0;
         tile0.assign(n_segs + 1, 0);
@@ -1028,6 +1046,13 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
             f.segs = d_segs;
             f.n_segs = (uint32_t)n_segs;
             f.src = src;
+            f.side_src = side_src;
+            if (rows) {
+                f.guides = rows->guides;
+                f.guide_first = rows->guide_first;
+                f.rows = rows->rows;
+                f.rows_first = rows->rows_first;
+            }
             if (bits) {
                 SortArgs a{};
                 a.segs = d_segs;
@@ -1036,6 +1061,8 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
                 a.n_tiles = (uint32_t)tiles;
                 a.in = src;
                 a.out = other;
+                a.side_in = rows ? side_src : nullptr;
+                a.side_out = rows ? side_other : nullptr;
                 a.hist = (uint32_t *)ctx->sort_tabs.p;
                 a.cursor = a.hist + n_bins;
                 a.bin_start = a.cursor + n_bins;
@@ -1076,6 +1103,7 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
                     VSC_TRY(launch_bin_partition(a, st));
                 }
                 f.src = other;
+                f.side_src = side_other;
                 f.hist = a.hist;
                 f.bin_start = a.bin_start;
                 f.bin_bits = bits;
@@ -1087,7 +1115,7 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
                 sorted_marked = true;
             }
             const unsigned rem_after = rem - bits;
-            f.sub_bits = std::min<unsigned>(kSortSubBits, rem_after);
+            f.sub_bits = std::min<unsigned>(rows ? kSortSubBitsRows : kSortSubBits, rem_after);
             f.sub_shift = kRecPosShift + pos_pad + rem_after - f.sub_bits;
             f.pos_pad = pos_pad;
             f.pos_base = pos_base;
@@ -1122,6 +1150,7 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
                 info->bytes += (use_slots ? 16 : 24) * n_all;  // (histogram read,) partition read + write
             }
             if (info) info->bytes += 24 * n_all;  // finalize: 8-byte read, 16-byte write
+            if (info && rows) info->bytes += (bits ? 8 : 0) * n_all + (4 + 12 + 64) * n_all;  // side words moved, read (twice: + the records again), rows written
             break;
         }
         if (!bits) break;
@@ -1132,6 +1161,13 @@ hipError_t bin_sort(vsc_ctx *ctx, const vsc_genome *genome, std::vector<SortSeg>
         VSC_TRY(hipMemcpyAsync(segs.data(), (char *)ctx->sort_over.p + 256, (size_t)n_over * sizeof(SortSeg), hipMemcpyDeviceToHost, st));
         VSC_TRY(hipStreamSynchronize(st));
         std::swap(src, other);  // the listed bins are spans of the buffer this level wrote
+        std::swap(side_src, side_other);
+        if (rows && !side_other) {  // (level 1 did not partition: the first buffer's sibling has no twin yet)
+            uint64_t span = 1;
+            for (const SortSeg &sg : segs) span = std::max<uint64_t>(span, sg.out_off + sg.n_in);
+            VSC_TRY(rows->side_other->ensure(span * sizeof(uint32_t)));
+            side_other = (uint32_t *)rows->side_other->p;
+        }
     }
     return hipSuccess;
 }
@@ -1170,9 +1206,11 @@ struct PassResult {
 
 // One search pass: reads guides[0 .. n_guides) (n_guides <= kMaxPassReads), reported as read indices
 // guide_base + i, appended to `hits` behind the `used` records it already holds.  Timings are ADDED to t.
+// want_rows (SEED only): the search keeps the sites' bases beside the records and the sort's last stage writes every hit's
+// packed feature row into ctx->score_feat (row i of the pass at byte 64 i).
 int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides, uint32_t guide_base,
                 const vsc_search_params *params, int algo, vsc_hits *hits, uint64_t used, uint64_t projected, vsc_timing &t,
-                PassResult *res)
+                PassResult *res, bool want_rows = false)
 {
 #define VSC_HIP_H(call)                                                                                  \
     do {                                                                                                 \
@@ -1301,6 +1339,11 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
             VSC_HIP_H(launch_scan(a, n_groups, false, ctx->stream));
         } else {
             sa.hit_recs = (uint64_t *)ctx->keys_a.p;
+            sa.hit_side = nullptr;
+            if (want_rows) {
+                VSC_HIP_H(ctx->vals_a.ensure(cap * sizeof(uint32_t)));
+                sa.hit_side = (uint32_t *)ctx->vals_a.p;
+            }
             sa.part_cap = part_cap;
             VSC_HIP_H(launch_seed_sliced(sa, n_groups, seed_shared, ctx->stream));
         }
@@ -1404,8 +1447,26 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         // the seed search's regions go through the slot partition (no histogram pass) unless this genome has shown
         // bins that outgrow their slots at this budget
         bool *slots = algo == VSC_ALGO_SEED ? &const_cast<vsc_genome *>(genome)->sort_slots_ok[params->max_mismatches] : nullptr;
+        SortRows rows;
+        if (want_rows) {
+            // the batch's rows, all at once (the caller reads them in its callback): 64 bytes per hit - 104 GB for 10 000 reads at
+            // 8 mismatches on 3 Gbp.  If that does not fit beside the pooled buffers, those go back first.
+            if (ctx->score_feat.ensure(n * VSC_PACKED_FEATURE_BYTES) != hipSuccess) {
+                (void)hipGetLastError();
+                for (auto &b : ctx->spare_records) b.release();
+                ctx->spare_records.clear();
+                for (DeviceBuf *b : {&ctx->score_mit, &ctx->score_flags, &ctx->score_sched, &ctx->keys_b, &ctx->vals_b}) b->release();
+                VSC_HIP_H(ctx->score_feat.ensure(n * VSC_PACKED_FEATURE_BYTES));
+            }
+            rows.side_src = (uint32_t *)ctx->vals_a.p;
+            rows.side_other = &ctx->vals_b;
+            rows.guides = (const uint2 *)ctx->guides.p;
+            rows.guide_first = guide_base;
+            rows.rows = (uint4 *)ctx->score_feat.p;
+            rows.rows_first = used;
+        }
         VSC_HIP_H(bin_sort(ctx, genome, std::move(segs), src, other, key_bits, pos_pad, pos_base, hits->d_records, ctx->ev[3], &info,
-                           algo == VSC_ALGO_SEED ? &ctx->keys_b : nullptr, slots));
+                           algo == VSC_ALGO_SEED ? &ctx->keys_b : nullptr, slots, want_rows ? &rows : nullptr));
     } else {
         VSC_HIP_H(hipEventRecord(ctx->ev[3], ctx->stream));
     }
@@ -1532,6 +1593,52 @@ int vsc_search_stream(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *gu
             prc = on_batch(user, hits, first, count);
             t.score_ms += ctx->timing.score_ms;  // what the callback's scoring calls measured
             if (prc != VSC_OK && ctx->err.empty()) ctx->err = "vsc_search_stream: the batch callback failed";
+        }
+        vsc_hits_free(hits);
+        if (prc != VSC_OK) return prc;
+    }
+    ctx->timing = t;
+    return VSC_OK;
+    });
+}
+
+int vsc_search_stream_rows(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, uint32_t n_guides,
+                           const vsc_search_params *params, uint32_t batch_reads, vsc_rows_batch_fn on_batch, void *user)
+{
+    return guarded(ctx, [&]() -> int {
+    if (!ctx) return VSC_ERR_INVALID;
+    vsc_timing t{};
+    int algo = 0;
+    const int rc = search_setup(ctx, genome, guides, n_guides, params, "vsc_search_stream_rows", &algo, &t);
+    if (rc != VSC_OK) return rc;
+    if (!on_batch) return fail(ctx, VSC_ERR_INVALID, "vsc_search_stream_rows: null callback");
+    if (batch_reads == 0 || batch_reads > (uint32_t)kMaxPassReads) batch_reads = kMaxPassReads;
+    for (uint32_t first = 0; first < n_guides; first += batch_reads) {
+        const uint32_t count = std::min<uint32_t>(batch_reads, n_guides - first);
+        vsc_hits *hits = new (std::nothrow) vsc_hits();
+        if (!hits) return fail(ctx, VSC_ERR_NOMEM, "vsc_search_stream_rows: out of host memory");
+        hits->ctx = ctx;
+        PassResult r;
+        // the seed search hands the sites' bases to the record assembly, which writes the rows; the streaming scan's hits
+        // (small searches on a genome without an index) are scored the usual way afterwards
+        int prc = search_pass(ctx, genome, guides + first, count, first, params, algo, hits, 0, 0, t, &r, algo == VSC_ALGO_SEED);
+        if (prc == VSC_OK) {
+            hits->n = r.n;
+            if (r.n == 0) hits->host_valid = true;
+            ctx->timing = t;
+            ctx->timing.score_ms = 0;
+            const void *rows = nullptr;
+            if (r.n && algo != VSC_ALGO_SEED) {
+                prc = vsc_score_hits_packed(ctx, genome, hits, guides, n_guides, 0, r.n, nullptr, nullptr, nullptr);
+                if (prc == VSC_OK && ctx->score_feat.cap < r.n * VSC_PACKED_FEATURE_BYTES)
+                    prc = fail(ctx, VSC_ERR_NOMEM, "vsc_search_stream_rows: the batch's rows do not fit the device at once (smaller batches)");
+                t.score_ms += ctx->timing.score_ms;
+            }
+            if (prc == VSC_OK) {
+                if (r.n) rows = ctx->score_feat.p;
+                prc = on_batch(user, hits, first, count, rows);
+                if (prc != VSC_OK && ctx->err.empty()) ctx->err = "vsc_search_stream_rows: the batch callback failed";
+            }
         }
         vsc_hits_free(hits);
         if (prc != VSC_OK) return prc;

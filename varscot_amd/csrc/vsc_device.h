@@ -59,4 +59,42 @@ __device__ __forceinline__ bool is_contig_end(const uint32_t *contig_end, uint32
     return lo < n_contigs && contig_end[lo] == p;
 }
 
+// ------------------------------------------------------------------------------------------------
+// packed feature rows: the 442 features of feature_matrix.h:25-126 in 64 bytes per hit (layout: include/varscot_hip.h,
+// vsc_score_hits_packed); on / off = 23-base plane pairs of the on-target (the read) and the off-target in read orientation.
+// Used by score_packed_kernel / rf_predict_kernel (vsc_kernels.hip) and by the rows-writing finalize (vsc_sort.hip).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void feature_row_packed(uint32_t on_h, uint32_t on_l, uint32_t off_h, uint32_t off_l, uint32_t (&w)[16])
+{
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = 0;
+    const uint32_t m21 = 0x1FFFFFu;
+    const uint32_t mm = ((on_h ^ off_h) | (on_l ^ off_l)) & m21;  // positions 0..20 (:53)
+    const uint32_t total = __popc(mm);
+    const uint32_t adjacent = __popc(mm & (mm >> 1));             // :100-105
+    const uint32_t seed = __popc(mm & 0xFFF00u);                  // 8 <= i <= 19, :94-98
+    // transitions = mismatches whose codes differ in the hi bit only (AG, CT, GA, TC; :47)
+    const uint32_t ts = __popc(mm & (on_h ^ off_h) & ~(on_l ^ off_l));
+    uint32_t types = 0;
+    for (uint32_t r = mm; r; r &= r - 1) {
+        const int i = __ffs(r) - 1;
+        const int o = (int)(((on_h >> i) & 1u) << 1 | ((on_l >> i) & 1u));
+        const int b = (int)(((off_h >> i) & 1u) << 1 | ((off_l >> i) & 1u));
+        types |= 1u << (o * 3 + (b > o ? b - 1 : b));             // :45-46,119
+    }
+    w[0] = mm | (total << 21) | (adjacent << 26);
+    w[1] = types | (ts << 12) | ((total - ts) << 17) | (seed << 22);
+    // (unrolled: bit 4 i + base lies in word 2 + i / 8, bit 16 i + pair in word 5 + i / 2 whatever the base is, so every word
+    // index is a compile-time constant - no dynamically indexed register array)
+#pragma unroll
+    for (int i = 0; i < 21; ++i) {
+        const uint32_t b = ((off_h >> i) & 1u) << 1 | ((off_l >> i) & 1u);
+        w[2 + (i >> 3)] |= 1u << ((4 * (i & 7)) + b);             // :64-83
+        if (i < 19) {                                             // :56-60
+            const uint32_t b2 = ((off_h >> (i + 1)) & 1u) << 1 | ((off_l >> (i + 1)) & 1u);
+            w[5 + (i >> 1)] |= 1u << (16 * (i & 1) + b * 4u + b2);
+        }
+    }
+}
+
 }  // namespace vsc

@@ -96,6 +96,8 @@ constexpr int kSortCap = kFinThreads * kFinItems - 128;  // the largest bin it o
                                                       // waits for memory)
 constexpr int kSortMaxBinBits = 11;                   // <= 2048 bins per partition level
 constexpr int kSortSubBits = 13;                      // <= 8 192 sub-bins inside the finalize kernel
+constexpr int kSortSubBitsRows = 12;                  // ... 4 096 when it also writes the feature rows: the other half of the table's LDS
+                                                      // stages the rows on their way out
 constexpr int kHistTiles = 8;                         // tiles a block of the histogram kernel walks through
 
 // Required plane bits of the two PAM letters, expanded to all-ones / all-zero words.
@@ -143,6 +145,8 @@ struct SortArgs {
     const uint64_t *pair_keys;     // level 0 only (streaming scan): guide << 33 | strand << 32 | position ...
     const uint32_t *pair_vals;     //                                ... and NM << 23 | mask; `in` is then unused
     uint64_t *out;
+    const uint32_t *side_in;       // null, or one 32-bit side word per record of `in` (the site's lo plane) ...
+    uint32_t *side_out;            // ... moved to the same places of this array as the records in `out`
     uint32_t *hist;                // [n_segs << bin_bits] records per bin
     uint32_t *cursor;              // [n_segs << bin_bits] next free record of every bin (relative to the segment)
     uint32_t *bin_start;           // [n_segs << bin_bits] first record of every bin (relative to the segment)
@@ -178,6 +182,13 @@ struct FinArgs {
     vsc_hit *out;
     uint32_t slot_cap;             // slot mode: bin i's records are src[i * slot_cap ...) (hist = the partition's cursors)
     const uint32_t *overflow;      // slot mode: non-zero = the partition gave up, nothing to do
+    // a search that keeps the sites' bases (SeedArgs.hit_side): the side words beside `src`, the reads' planes, and where the
+    // 64-byte packed feature row of result record i goes: rows + (i - rows_first) * 64 bytes
+    const uint32_t *side_src;
+    const uint2 *guides;           // (hi plane, lo plane) of read guide_first + j
+    uint32_t guide_first;
+    uint4 *rows;                   // null: plain records (low 23 bits = mismatch mask)
+    uint64_t rows_first;
 };
 
 struct ScoreArgs {
@@ -212,6 +223,8 @@ struct SeedArgs {
     const uint32_t *contig_end;
     uint32_t n_contigs;
     uint64_t *hit_recs;            // out: packed records (layout above), region p = [p * part_cap, (p + 1) * part_cap)
+    uint32_t *hit_side;            // null, or (per-hit feature rows wanted): one word beside every record = the site's lo plane in read
+                                   // orientation; its hi plane then sits in the record's low 23 bits in place of the mismatch mask
     uint32_t group_out;            // 1: the four waves of a workgroup share their open blocks (chunk-sharing kernel only)
     uint32_t pam21;                // base code every site has at read position 21 (first PAM letter), or >= 4: not all the same
     uint32_t reserve;              // records a wave reserves per atomic on its region's cursor: a power of two, 64 .. 1024

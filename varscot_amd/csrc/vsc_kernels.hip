@@ -641,37 +641,7 @@ __global__ __launch_bounds__(256) void score_kernel(const ScoreArgs a)
 //   w15     0
 // vsc_unpack_features (vsc_pack.cpp) expands a row to the 442 dense values.
 // ------------------------------------------------------------------------------------------------
-__device__ void feature_row_packed(uint32_t on_h, uint32_t on_l, uint32_t off_h, uint32_t off_l, uint32_t (&w)[16])
-{
-#pragma unroll
-    for (int k = 0; k < 16; ++k) w[k] = 0;
-    const uint32_t m21 = 0x1FFFFFu;
-    const uint32_t mm = ((on_h ^ off_h) | (on_l ^ off_l)) & m21;  // positions 0..20 (:53)
-    const uint32_t total = __popc(mm);
-    const uint32_t adjacent = __popc(mm & (mm >> 1));             // :100-105
-    const uint32_t seed = __popc(mm & 0xFFF00u);                  // 8 <= i <= 19, :94-98
-    // transitions = mismatches whose codes differ in the hi bit only (AG, CT, GA, TC; :47)
-    const uint32_t ts = __popc(mm & (on_h ^ off_h) & ~(on_l ^ off_l));
-    uint32_t types = 0;
-    for (uint32_t r = mm; r; r &= r - 1) {
-        const int i = __ffs(r) - 1;
-        const int o = (int)(((on_h >> i) & 1u) << 1 | ((on_l >> i) & 1u));
-        const int b = (int)(((off_h >> i) & 1u) << 1 | ((off_l >> i) & 1u));
-        types |= 1u << (o * 3 + (b > o ? b - 1 : b));             // :45-46,119
-    }
-    w[0] = mm | (total << 21) | (adjacent << 26);
-    w[1] = types | (ts << 12) | ((total - ts) << 17) | (seed << 22);
-    for (int i = 0; i < 21; ++i) {
-        const uint32_t b = ((off_h >> i) & 1u) << 1 | ((off_l >> i) & 1u);
-        const uint32_t bit = 4u * i + b;                          // :64-83
-        w[2 + (bit >> 5)] |= 1u << (bit & 31u);
-        if (i < 19) {                                             // :56-60
-            const uint32_t b2 = ((off_h >> (i + 1)) & 1u) << 1 | ((off_l >> (i + 1)) & 1u);
-            const uint32_t pbit = 16u * i + b * 4u + b2;
-            w[5 + (pbit >> 5)] |= 1u << (pbit & 31u);
-        }
-    }
-}
+// (feature_row_packed lives in vsc_device.h: the sort's last stage writes the same rows for searches that keep the sites' bases)
 
 // ---- processing order of the packed scoring ------------------------------------------------------------------
 // The rows are a 64-byte-per-hit stream, but every hit also gathers its 23-base window from the planes: 16 bytes

@@ -21,7 +21,7 @@ struct DeviceBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        size_t want = bytes + bytes / 8;
+        size_t want = bytes + (bytes < ((size_t)32 << 30) ? bytes / 8 : bytes / 32);  // (3 % on buffers of tens of GB: batch sizes wobble by 1 %)
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess && want != bytes) {
             (void)hipGetLastError();
@@ -67,6 +67,7 @@ struct vsc_ctx {
     vsc_debug_params dbg = vsc::default_debug_params();  // test / experiment hooks (include/varscot_hip_debug.h)
     // keys_a / keys_b: the two record buffers the bin sort alternates between (keys_a + vals_a: the scan's (key, value) pairs)
     vsc::DeviceBuf counters, guides, keys_a, keys_b, vals_a, score_mit, score_flags, score_feat;
+    vsc::DeviceBuf vals_b;  // side words beside keys_b (searches that keep the sites' bases; vals_a then holds those beside keys_a)
     // the read planes of the scoring calls (their own buffer: `guides` is the search passes'), kept while the read set stays the same
     vsc::DeviceBuf score_guides;
     uint64_t score_guides_hash = 0;

@@ -473,13 +473,21 @@ __device__ __forceinline__ bool sliced_reserve(const SeedArgs &a, const SeedWave
     return true;
 }
 
+// record slot `at` of the output regions (+ the parallel side word: a search that keeps the sites' bases - SeedArgs.hit_side -
+// writes the site's lo plane there, its hi plane sits in the record where the mismatch mask is otherwise)
+__device__ __forceinline__ void put_record(const SeedArgs &a, unsigned long long at, uint64_t rec, uint32_t side)
+{
+    a.hit_recs[at] = rec;
+    if (a.hit_side) a.hit_side[at] = side;
+}
+
 // Group-shared open blocks (SeedArgs.group_out; with chunk sharing only): the four waves of a workgroup fill ONE open
 // block per region - a quarter of the partly written lines in flight and of the sentinels at the end, blocks four times
 // as large for the same padding (fewer reservations).  The slow path serialises per region on the BUSY bit: the wave
 // that finds the block full and not busy sets BUSY (LDS compare-and-swap), reserves the next block (global atomic) and
 // installs it with a plain LDS store that clears BUSY; a wave that finds BUSY waits (s_sleep, bounded) and then claims
 // again.  A wave holds BUSY only across its own reservation, so nobody waits on a waiter.
-__device__ __forceinline__ void sliced_store_group_slow(const SeedArgs &a, SeedWave &w, uint32_t p, bool mine, uint64_t rec)
+__device__ __forceinline__ void sliced_store_group_slow(const SeedArgs &a, SeedWave &w, uint32_t p, bool mine, uint64_t rec, uint32_t side)
 {
     volatile uint32_t *const word = &w.parts[p];
     for (uint32_t spins = 0;;) {
@@ -501,7 +509,7 @@ __device__ __forceinline__ void sliced_store_group_slow(const SeedArgs &a, SeedW
             uint32_t st = kPartUsedMask;
             if (mine) st = atomicAdd(&w.parts[p], 1u);
             const bool ok = mine && (st & kPartUsedMask) < a.reserve;
-            if (ok) a.hit_recs[(unsigned long long)p * (uint32_t)a.part_cap + (((st >> kPartBlockShift) << a.reserve_log2) + (st & kPartUsedMask))] = rec;
+            if (ok) put_record(a, (unsigned long long)p * (uint32_t)a.part_cap + (((st >> kPartBlockShift) << a.reserve_log2) + (st & kPartUsedMask)), rec, side);
             mine = mine && !ok;
             if (__ballot(mine) == 0) return;
             continue;
@@ -526,33 +534,33 @@ __device__ __forceinline__ void sliced_store_group_slow(const SeedArgs &a, SeedW
         const uint32_t n = (uint32_t)__popcll(b);
         uint32_t next = 0;
         const bool ok = sliced_reserve(a, w, p, n, next);
-        if (mine && ok) a.hit_recs[(unsigned long long)p * a.part_cap + next + lanes_below(b)] = rec;
+        if (mine && ok) put_record(a, (unsigned long long)p * a.part_cap + next + lanes_below(b), rec, side);
         if (w.lane == 0) *word = ok ? ((next >> a.reserve_log2) << kPartBlockShift) | n : (kPartDeadBlock << kPartBlockShift) | a.reserve;
         return;
     }
 }
 
-// lanes with `hit` store their record in the region of their read
-__device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, bool hit, uint32_t region, uint64_t rec)
+// lanes with `hit` store their record (+ its side word, when the search keeps the sites' bases) in the region of their read
+__device__ __forceinline__ void sliced_store(const SeedArgs &a, SeedWave &w, bool hit, uint32_t region, uint64_t rec, uint32_t side)
 {
     uint32_t state = kPartUsedMask;
     if (hit) state = atomicAdd(&w.parts[region], 1u);  // LDS; the count may run past `reserve`: those lanes take the path below
     const uint32_t slot = state & kPartUsedMask;
     const bool placed = hit && slot < a.reserve;
     // (part_cap < 2^32 - the host checks - so the slot index is one 32 x 32 -> 64-bit multiply-add)
-    if (placed) a.hit_recs[(unsigned long long)region * (uint32_t)a.part_cap + (((state >> kPartBlockShift) << a.reserve_log2) + slot)] = rec;
+    if (placed) put_record(a, (unsigned long long)region * (uint32_t)a.part_cap + (((state >> kPartBlockShift) << a.reserve_log2) + slot), rec, side);
     uint64_t todo = __ballot(hit && !placed);
     while (todo != 0) {
         const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)region, (int)__builtin_ctzll(todo));
         const bool mine = hit && !placed && region == p;
         const uint64_t b = __ballot(mine);
         if (a.group_out) {
-            sliced_store_group_slow(a, w, p, mine, rec);
+            sliced_store_group_slow(a, w, p, mine, rec, side);
         } else {
             const uint32_t n = (uint32_t)__popcll(b);
             uint32_t next = 0;
             const bool ok = sliced_reserve(a, w, p, n, next);
-            if (mine && ok) a.hit_recs[(unsigned long long)p * a.part_cap + next + lanes_below(b)] = rec;
+            if (mine && ok) put_record(a, (unsigned long long)p * a.part_cap + next + lanes_below(b), rec, side);
             // (a region that is full keeps a "used up" block: later hits come here again and are counted as lost)
             if (w.lane == 0) w.parts[p] = ok ? ((next >> a.reserve_log2) << kPartBlockShift) | n : a.reserve;
         }
@@ -649,9 +657,12 @@ __device__ __forceinline__ void sliced_consume(const SeedArgs &a, SeedWave &w, c
             if (((a.edge_bits[site >> 5] >> (site & 31u)) & 1u) && is_contig_end(a.contig_end, a.n_contigs, pos + VSC_READ_LEN)) hit = false;
         }
     }
+    // (a search that keeps the sites' bases for the per-hit feature rows: the site's planes in READ orientation - hi in the
+    // record's low 23 bits, lo in the side word - instead of the mask, which the record assembly recomputes from them)
+    const uint32_t low23 = a.hit_side ? (site_hi & kMask23) : mask;
     const uint64_t rec = ((uint64_t)(gid_of & (uint32_t)(kRegionReads - 1)) << kRecReadShift) | ((uint64_t)strand << kRecStrandShift) |
-                         ((uint64_t)((pos - a.pos_base) << a.pos_pad) << kRecPosShift) | mask;
-    sliced_store(a, w, hit, gid_of >> kRegionBits, rec);
+                         ((uint64_t)((pos - a.pos_base) << a.pos_pad) << kRecPosShift) | low23;
+    sliced_store(a, w, hit, gid_of >> kRegionBits, rec, site_lo & kMask23);
 }
 
 // Resolves tokens in passes of 64.  kDrain = false: full passes only - what is left (< 64 tokens) waits

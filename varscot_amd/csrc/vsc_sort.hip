@@ -197,7 +197,9 @@ hipError_t launch_bin_scan(const SortArgs &args, hipStream_t stream)
 // ------------------------------------------------------------------------------------------------
 // partition: one tile of kSortTile records per workgroup
 // ------------------------------------------------------------------------------------------------
-template <bool kPairs>
+// kSide: every record has a 32-bit side word in a parallel array (the site's lo plane of a search that keeps the sites'
+// bases): it is moved with its record - through the same LDS buffer, in a second pass over the tile's slots.
+template <bool kPairs, bool kSide = false>
 __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortArgs a)
 {
     __shared__ uint64_t s_rec[kSortTile];
@@ -225,11 +227,13 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
     // as 16-wide vectors, copies them at every branch and spills.
     uint64_t r[kSortItems];
     uint32_t bin[kSortItems];  // bin | rank inside (tile, bin) << 16
+    uint32_t side[kSide ? kSortItems : 1];
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         const uint32_t i = tile_record(k, t);
         const bool in_tile = i < n;
         const uint64_t at = sg.in_off + first + (in_tile ? i : 0u);
+        if (kSide) side[k] = a.side_in[at];
         if (kPairs) {
             const uint64_t key = a.pair_keys[at];
             r[k] = in_tile ? pack_pair(key, a.pair_vals[at], a.pos_pad, a.pos_base) : kRecSentinel;
@@ -267,6 +271,11 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
         if (!(r[k] >> 63)) s_rec[s_cnt[bin[k] & 0xFFFFu] + (bin[k] >> 16)] = r[k];
     block_sync();
     // the tile, grouped by bin: neighbouring lanes write neighbouring records of a bin
+    uint32_t slot_bin[kSide ? kSortItems / 2 : 1];  // kSide: the bin of every slot this thread writes, two to a word
+    if (kSide) {
+#pragma unroll
+        for (int j = 0; j < kSortItems / 2; ++j) slot_bin[j] = 0;
+    }
     for (uint32_t i = t; i < total; i += kSortThreads) {
         const uint64_t x = s_rec[i];
         // level 0 dropped the region from the record: find the bin of slot i in the scanned counters instead
@@ -286,6 +295,33 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
         } else {
             a.out[sg.out_off + s_gbase[b] + (i - s_cnt[b])] = x;
         }
+        if (kSide) {
+            const uint32_t j = i / kSortThreads;  // this thread's j-th slot
+#pragma unroll
+            for (int q = 0; q < kSortItems / 2; ++q)
+                if ((uint32_t)q == (j >> 1)) slot_bin[q] |= b << ((j & 1u) * 16u);
+        }
+    }
+    if (kSide) {
+        // the side words follow: into the LDS slots of their records (which have left), then out to the same places
+        block_sync();
+        uint32_t *const s_side = (uint32_t *)s_rec;
+#pragma unroll
+        for (int k = 0; k < kSortItems; ++k)
+            if (!(r[k] >> 63)) s_side[s_cnt[bin[k] & 0xFFFFu] + (bin[k] >> 16)] = side[k];
+        block_sync();
+#pragma unroll
+        for (int j = 0; j < kSortItems; ++j) {
+            const uint32_t i = t + (uint32_t)j * kSortThreads;
+            if (i < total) {
+                const uint32_t b = (slot_bin[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                if (a.slot_cap) {
+                    if (s_gbase[b] != 0xFFFFFFFFu) a.side_out[(((uint64_t)seg << a.bin_bits) + b) * a.slot_cap + s_gbase[b] + (i - s_cnt[b])] = s_side[i];
+                } else {
+                    a.side_out[sg.out_off + s_gbase[b] + (i - s_cnt[b])] = s_side[i];
+                }
+            }
+        }
     }
 }
 
@@ -295,6 +331,8 @@ hipError_t launch_bin_partition(const SortArgs &args, hipStream_t stream)
     const unsigned blocks = args.xcd_tiles ? 8u * args.xcd_tiles : args.n_tiles;
     if (args.pair_keys)
         hipLaunchKernelGGL(bin_partition_kernel<true>, dim3(blocks), dim3(kSortThreads), 0, stream, args);
+    else if (args.side_in)
+        hipLaunchKernelGGL((bin_partition_kernel<false, true>), dim3(blocks), dim3(kSortThreads), 0, stream, args);
     else
         hipLaunchKernelGGL(bin_partition_kernel<false>, dim3(blocks), dim3(kSortThreads), 0, stream, args);
     return hipGetLastError();
@@ -316,11 +354,19 @@ constexpr int kFinalizeAhead = 4;  // records of a sub-bin the ranking reads at 
 constexpr int kFinalizeNear = 4;    // contigs a bin's position range may touch for the straight-line contig lookup
 constexpr int kFinalizeRange = 64;  // ... for a binary search in LDS (more: in global memory - variant genomes)
 
-// one bin (index `which` over all segments' bins), by the whole workgroup
+// one bin (index `which` over all segments' bins), by the whole workgroup.
+// kRows (a search that keeps the sites' bases, FinArgs.side_src / .rows): the record's low 23 bits and its side word are the
+// site's hi / lo planes in read orientation; the mismatch mask is recomputed from them and the read, and the hit's 64-byte
+// packed feature row (vsc_score_hits_packed's) is written beside its vsc_hit.  In LDS the record's plane bits give way to its
+// load slot: the thread that ranks a record fetches the record and its side word again by that slot (from L2), so that no
+// side word ever has to sit in LDS and hits and rows still leave in rank order, coalesced.
+template <bool kRows>
 __device__ __forceinline__ void finalize_bin(const FinArgs &a, const uint32_t which)
 {
     __shared__ uint64_t s_rec[kSortCap];
-    __shared__ uint32_t s_sub[(1 << kSortSubBits) / 2 + 1 + kWave];  // packed pairs of 16-bit counters, then first slots (+ spares)
+    __shared__ uint32_t s_sub[(1 << (kRows ? kSortSubBitsRows : kSortSubBits)) / 2 + 1 + kWave];  // packed pairs of 16-bit counters, then first slots (+ spares)
+    // kRows: 16 rows of 64 bytes per wave on their way out (see the end of the walk)
+    __shared__ uint4 s_stage[kRows ? (kFinThreads / kWave) * 64 : 1];
     __shared__ uint32_t s_wave[kFinThreads / kWave];
     __shared__ uint32_t s_range[2 + kFinalizeRange];  // first contig of the bin's position range, contigs in it, their starts
     __shared__ uint32_t s_edge[4];                    // the bin's position range [0], [1]; contigs starting at or below either end [2], [3]
@@ -485,92 +531,223 @@ __device__ __forceinline__ void finalize_bin(const FinArgs &a, const uint32_t wh
     }
 #pragma unroll
     for (int k = 0; k < kFinItems; ++k)
-        if (!(r[k] >> 63)) s_rec[sub_slot(s_sub, (uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u)) + rk[k]] = r[k];
+        if (!(r[k] >> 63))
+            s_rec[sub_slot(s_sub, (uint32_t)(r[k] >> a.sub_shift) & (nsub - 1u)) + rk[k]] =
+                kRows ? (r[k] & ~(uint64_t)kMask23) | (uint32_t)(k * kFinThreads + t) : r[k];  // kRows: the plane bits make room for the load slot
     block_sync();
     const uint32_t c_lo = s_range[0], c_n = s_range[1];
     const uint32_t st0 = s_range[2], st1 = s_range[3], st2 = s_range[4], st3 = s_range[5];
-    // Two records per thread and round, every LDS read unconditional (clamped) so that independent reads leave
-    // together: the phase is bound by LDS round trips (record -> sub-bin bounds -> the sub-bin's records), not by
-    // bandwidth or issue.
-    for (uint32_t base = 0; base < n; base += 2 * kFinThreads) {
-        uint32_t s[2], e[2], smaller[2] = {0u, 0u};
-        uint64_t x[2];
-        bool live[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t idx = base + u * kFinThreads + t;
-            live[u] = idx < n;
-            const uint64_t v = s_rec[live[u] ? idx : 0u];
-            x[u] = live[u] ? v : 0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t sb = (uint32_t)(x[u] >> a.sub_shift) & (nsub - 1u);
-            const uint32_t first = sub_slot(s_sub, sb), next = sub_slot(s_sub, sb + 1u);
-            s[u] = first;
-            e[u] = live[u] ? next : first;
-        }
-        // rank among the records of the sub-bin (keys are unique): its first kFinalizeAhead records in one go, the
-        // few longer sub-bins in a loop with a wave-uniform trip count (per-lane loops cost more in execution-mask
-        // bookkeeping than they save)
-        if (a.low_bits) {
-            uint64_t y[2][kFinalizeAhead];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int j = 0; j < kFinalizeAhead; ++j) y[u][j] = s_rec[min(s[u] + (uint32_t)j, (uint32_t)kSortCap - 1u)];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int j = 0; j < kFinalizeAhead; ++j) smaller[u] += (uint32_t)(s[u] + (uint32_t)j < e[u] && y[u][j] < x[u]);
-            for (uint32_t d = kFinalizeAhead;; ++d) {
-                const bool act0 = s[0] + d < e[0], act1 = s[1] + d < e[1];
-                if (__ballot(act0 || act1) == 0) break;
-                const uint64_t y0 = s_rec[act0 ? s[0] + d : 0u], y1 = s_rec[act1 ? s[1] + d : 0u];
-                smaller[0] += (uint32_t)(act0 && y0 < x[0]);
-                smaller[1] += (uint32_t)(act1 && y1 < x[1]);
+    if (!kRows) {
+        // Two records per thread and round, every LDS read unconditional (clamped) so that independent reads leave
+        // together: the phase is bound by LDS round trips (record -> sub-bin bounds -> the sub-bin's records), not by
+        // bandwidth or issue.
+        for (uint32_t base = 0; base < n; base += 2 * kFinThreads) {
+            uint32_t s[2], e[2], smaller[2] = {0u, 0u};
+            uint64_t x[2];
+            bool live[2];
+    #pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t idx = base + u * kFinThreads + t;
+                live[u] = idx < n;
+                const uint64_t v = s_rec[live[u] ? idx : 0u];
+                x[u] = live[u] ? v : 0ull;
+            }
+    #pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t sb = (uint32_t)(x[u] >> a.sub_shift) & (nsub - 1u);
+                const uint32_t first = sub_slot(s_sub, sb), next = sub_slot(s_sub, sb + 1u);
+                s[u] = first;
+                e[u] = live[u] ? next : first;
+            }
+            // rank among the records of the sub-bin (keys are unique): its first kFinalizeAhead records in one go, the
+            // few longer sub-bins in a loop with a wave-uniform trip count (per-lane loops cost more in execution-mask
+            // bookkeeping than they save)
+            if (a.low_bits) {
+                uint64_t y[2][kFinalizeAhead];
+    #pragma unroll
+                for (int u = 0; u < 2; ++u)
+    #pragma unroll
+                    for (int j = 0; j < kFinalizeAhead; ++j) y[u][j] = s_rec[min(s[u] + (uint32_t)j, (uint32_t)kSortCap - 1u)];
+    #pragma unroll
+                for (int u = 0; u < 2; ++u)
+    #pragma unroll
+                    for (int j = 0; j < kFinalizeAhead; ++j) smaller[u] += (uint32_t)(s[u] + (uint32_t)j < e[u] && y[u][j] < x[u]);
+                for (uint32_t d = kFinalizeAhead;; ++d) {
+                    const bool act0 = s[0] + d < e[0], act1 = s[1] + d < e[1];
+                    if (__ballot(act0 || act1) == 0) break;
+                    const uint64_t y0 = s_rec[act0 ? s[0] + d : 0u], y1 = s_rec[act1 ? s[1] + d : 0u];
+                    smaller[0] += (uint32_t)(act0 && y0 < x[0]);
+                    smaller[1] += (uint32_t)(act1 && y1 < x[1]);
+                }
+            }
+    #pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!live[u]) continue;
+                const uint32_t pos = ((uint32_t)(x[u] >> kRecPosShift) >> a.pos_pad) + a.pos_base;
+                uint32_t c, start;
+                if (c_n <= (uint32_t)kFinalizeNear) {
+                    // the usual case: the bin's positions lie in at most four contigs - three comparisons
+                    const uint32_t k = (uint32_t)(pos >= st1) + (uint32_t)(pos >= st2) + (uint32_t)(pos >= st3);
+                    c = c_lo + k;
+                    start = k == 0 ? st0 : (k == 1 ? st1 : (k == 2 ? st2 : st3));
+                } else if (c_n <= (uint32_t)kFinalizeRange) {
+                    uint32_t lo = 0, hi = c_n;  // last contig of the staged range whose start is <= pos
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_range[2 + mid] <= pos) lo = mid; else hi = mid;
+                    }
+                    c = c_lo + lo;
+                    start = s_range[2 + lo];
+                } else {
+                    uint32_t lo = c_lo, hi = c_lo + c_n;
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (a.contig_off[mid] <= pos) lo = mid; else hi = mid;
+                    }
+                    c = lo;
+                    start = a.contig_off[c];
+                }
+                const uint32_t mask = (uint32_t)x[u] & kMask23;
+                uint4 h;
+                h.x = sg.guide_base + ((uint32_t)(x[u] >> kRecReadShift) & (uint32_t)(kRegionReads - 1));  // vsc_hit.guide
+                h.y = c;                                                                              // .contig
+                h.z = pos - start;                                                                    // .pos
+                h.w = ((uint32_t)(x[u] >> kRecStrandShift) & 1u) << 31 | (uint32_t)__popc(mask) << 23 | mask;  // .info
+                // (written once, read by a later kernel at the earliest: past the caches - finalize 8.30 -> 8.15 ms)
+                v4u hv;
+                hv.x = h.x;
+                hv.y = h.y;
+                hv.z = h.z;
+                hv.w = h.w;
+                __builtin_nontemporal_store(hv, (v4u *)a.out + (dst + s[u] + smaller[u]));
             }
         }
+    } else {
+        // ---- the walk again, for records whose low 23 bits in LDS are their LOAD SLOT (the scatter above put it there): the
+        // walker fetches the record and its side word again by that slot - from L2, the bin was loaded a moment ago - and has the
+        // site's planes, from which the mismatch mask and the feature row follow; hit and row leave at bin start + rank,
+        // neighbouring lanes writing neighbouring records and rows.
+        const uint32_t *const side_in = a.side_src + src;
+        const uint64_t kmask = ~(uint64_t)kMask23;
+        for (uint32_t base = 0; base < n; base += 2 * kFinThreads) {
+            uint32_t s[2], e[2], smaller[2] = {0u, 0u};
+            uint64_t x[2], full[2];
+            uint32_t lo_plane[2];
+            bool live[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (!live[u]) continue;
-            const uint32_t pos = ((uint32_t)(x[u] >> kRecPosShift) >> a.pos_pad) + a.pos_base;
-            uint32_t c, start;
-            if (c_n <= (uint32_t)kFinalizeNear) {
-                // the usual case: the bin's positions lie in at most four contigs - three comparisons
-                const uint32_t k = (uint32_t)(pos >= st1) + (uint32_t)(pos >= st2) + (uint32_t)(pos >= st3);
-                c = c_lo + k;
-                start = k == 0 ? st0 : (k == 1 ? st1 : (k == 2 ? st2 : st3));
-            } else if (c_n <= (uint32_t)kFinalizeRange) {
-                uint32_t lo = 0, hi = c_n;  // last contig of the staged range whose start is <= pos
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (s_range[2 + mid] <= pos) lo = mid; else hi = mid;
-                }
-                c = c_lo + lo;
-                start = s_range[2 + lo];
-            } else {
-                uint32_t lo = c_lo, hi = c_lo + c_n;
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (a.contig_off[mid] <= pos) lo = mid; else hi = mid;
-                }
-                c = lo;
-                start = a.contig_off[c];
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t idx = base + u * kFinThreads + t;
+                live[u] = idx < n;
+                const uint64_t v = s_rec[live[u] ? idx : 0u];
+                x[u] = live[u] ? v : 0ull;
             }
-            const uint32_t mask = (uint32_t)x[u] & kMask23;
-            uint4 h;
-            h.x = sg.guide_base + ((uint32_t)(x[u] >> kRecReadShift) & (uint32_t)(kRegionReads - 1));  // vsc_hit.guide
-            h.y = c;                                                                              // .contig
-            h.z = pos - start;                                                                    // .pos
-            h.w = ((uint32_t)(x[u] >> kRecStrandShift) & 1u) << 31 | (uint32_t)__popc(mask) << 23 | mask;  // .info
-            // (written once, read by a later kernel at the earliest: past the caches - finalize 8.30 -> 8.15 ms)
-            v4u hv;
-            hv.x = h.x;
-            hv.y = h.y;
-            hv.z = h.z;
-            hv.w = h.w;
-            __builtin_nontemporal_store(hv, (v4u *)a.out + (dst + s[u] + smaller[u]));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {  // the gathers leave first, the ranking covers them
+                const uint32_t slot = (uint32_t)x[u] & 0x1FFFu;
+                full[u] = in[slot];
+                lo_plane[u] = side_in[slot];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t sb = (uint32_t)(x[u] >> a.sub_shift) & (nsub - 1u);
+                const uint32_t first = sub_slot(s_sub, sb), next = sub_slot(s_sub, sb + 1u);
+                s[u] = first;
+                e[u] = live[u] ? next : first;
+            }
+            if (a.low_bits) {
+                uint64_t y[2][kFinalizeAhead];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < kFinalizeAhead; ++j) y[u][j] = s_rec[min(s[u] + (uint32_t)j, (uint32_t)kSortCap - 1u)];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < kFinalizeAhead; ++j) smaller[u] += (uint32_t)(s[u] + (uint32_t)j < e[u] && (y[u][j] & kmask) < (x[u] & kmask));
+                for (uint32_t d = kFinalizeAhead;; ++d) {
+                    const bool act0 = s[0] + d < e[0], act1 = s[1] + d < e[1];
+                    if (__ballot(act0 || act1) == 0) break;
+                    const uint64_t y0 = s_rec[act0 ? s[0] + d : 0u], y1 = s_rec[act1 ? s[1] + d : 0u];
+                    smaller[0] += (uint32_t)(act0 && (y0 & kmask) < (x[0] & kmask));
+                    smaller[1] += (uint32_t)(act1 && (y1 & kmask) < (x[1] & kmask));
+                }
+            }
+            uint32_t w[2][16];
+            uint64_t row_at[2] = {~0ull, ~0ull};  // where the row goes (rows of 64 bytes); ~0: no record
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!live[u]) continue;
+                const uint32_t pos = ((uint32_t)(x[u] >> kRecPosShift) >> a.pos_pad) + a.pos_base;
+                uint32_t c, start;
+                if (c_n <= (uint32_t)kFinalizeNear) {
+                    const uint32_t k = (uint32_t)(pos >= st1) + (uint32_t)(pos >= st2) + (uint32_t)(pos >= st3);
+                    c = c_lo + k;
+                    start = k == 0 ? st0 : (k == 1 ? st1 : (k == 2 ? st2 : st3));
+                } else if (c_n <= (uint32_t)kFinalizeRange) {
+                    uint32_t lo = 0, hi = c_n;  // last contig of the staged range whose start is <= pos
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_range[2 + mid] <= pos) lo = mid; else hi = mid;
+                    }
+                    c = c_lo + lo;
+                    start = s_range[2 + lo];
+                } else {
+                    uint32_t lo = c_lo, hi = c_lo + c_n;
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (a.contig_off[mid] <= pos) lo = mid; else hi = mid;
+                    }
+                    c = lo;
+                    start = a.contig_off[c];
+                }
+                const uint32_t strand = (uint32_t)(x[u] >> kRecStrandShift) & 1u;
+                const uint32_t guide = sg.guide_base + ((uint32_t)(x[u] >> kRecReadShift) & (uint32_t)(kRegionReads - 1));
+                const uint2 gp = a.guides[guide - a.guide_first];  // the read's planes: what the site was compared with
+                const uint32_t hi_pl = (uint32_t)full[u] & kMask23, lo_pl = lo_plane[u] & kMask23;
+                const uint32_t tm = ((hi_pl ^ gp.x) | (lo_pl ^ gp.y)) & kMask23;  // mismatches in read orientation ...
+                const uint32_t mask = strand ? reverse23(tm) : tm;               // ... in forward-genome window coordinates
+                v4u hv;
+                hv.x = guide;
+                hv.y = c;
+                hv.z = pos - start;
+                hv.w = strand << 31 | (uint32_t)__popc(mask) << 23 | mask;
+                const uint64_t at = dst + s[u] + smaller[u];
+                __builtin_nontemporal_store(hv, (v4u *)a.out + at);
+                row_at[u] = at - a.rows_first;
+                feature_row_packed(gp.x, gp.y, hi_pl, lo_pl, w[u]);
+            }
+            // The rows leave through the wave's kilobyte of LDS, sixteen at a time: sixteen lanes put their 64-byte rows
+            // down, then every lane takes one 16-byte piece - four neighbouring lanes one whole row - so that a store
+            // instruction writes sixteen complete 64-byte lines (streaming stores; a lane storing its own row, 16 bytes
+            // per instruction 64 bytes apart, sends the lines out in quarters: 29 instead of 18 ms per c5 batch).
+            uint4 *const stage = s_stage + (t / kWave) * 64;
+            const uint32_t lane = t % kWave;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (__ballot(row_at[u] != ~0ull) == 0) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if ((lane >> 4) == (uint32_t)j) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)  // (piece q of row r in slot 4 r + (q ^ (r & 3)): the pieces of a row in different banks)
+                            stage[4 * (lane & 15u) + ((uint32_t)q ^ (lane & 3u))] = make_uint4(w[u][4 * q], w[u][4 * q + 1], w[u][4 * q + 2], w[u][4 * q + 3]);
+                    }
+                    wave_sync();
+                    const uint32_t r = lane >> 2, q = lane & 3u;  // this lane's piece: row r of the sixteen, quarter q
+                    const uint32_t owner = 16u * (uint32_t)j + r;
+                    const uint32_t at_lo = __shfl((uint32_t)row_at[u], (int)owner, kWave), at_hi = __shfl((uint32_t)(row_at[u] >> 32), (int)owner, kWave);
+                    const uint4 piece = stage[4 * r + (q ^ (r & 3u))];
+                    if ((at_lo & at_hi) != 0xFFFFFFFFu) {
+                        v4u rv;
+                        rv.x = piece.x;
+                        rv.y = piece.y;
+                        rv.z = piece.z;
+                        rv.w = piece.w;
+                        __builtin_nontemporal_store(rv, (v4u *)a.rows + ((((uint64_t)at_hi << 32) | at_lo) * 4 + q));
+                    }
+                    wave_sync();
+                }
+            }
         }
     }
 }
@@ -581,6 +758,7 @@ __device__ __forceinline__ void finalize_bin(const FinArgs &a, const uint32_t wh
 // XCDs, and in-order dispatch makes the others wait for the busy ones (3 Gbp: 12.1 ms; 3.9 Gbp with 30 % more
 // records: 11.2 ms; bins rotated by their group number: 11.1 ms).
 // (amdgpu_waves_per_eu: two workgroups of 8 waves per CU = 4 waves per SIMD = at most 128 VGPRs; the loop makes the allocator ask for 166)
+template <bool kRows>
 __global__ __launch_bounds__(kFinThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bin_finalize_kernel(const FinArgs a)
 {
     __shared__ uint32_t s_next[2];
@@ -590,7 +768,7 @@ __global__ __launch_bounds__(kFinThreads) __attribute__((amdgpu_waves_per_eu(4, 
     while (which < total) {
         // the next bin's number is asked for now and looked at after this bin
         if (threadIdx.x == 0) s_next[parity] = atomicAdd(a.cursor, 1u) + gridDim.x;
-        finalize_bin(a, which);
+        finalize_bin<kRows>(a, which);
         block_sync();  // the LDS tables are free again, s_next is written
         which = s_next[parity];
         parity ^= 1u;
@@ -601,10 +779,14 @@ hipError_t launch_bin_finalize(const FinArgs &args, int max_groups, hipStream_t 
 {
     if (args.n_segs == 0) return hipSuccess;
     const uint64_t bins = (uint64_t)args.n_segs << args.bin_bits;
-    if (bins >= (1ull << 31) || args.sub_bits > (uint32_t)kSortSubBits || args.bin_bits > (uint32_t)kSortMaxBinBits ||
+    if (bins >= (1ull << 31) || args.sub_bits > (uint32_t)(args.rows ? kSortSubBitsRows : kSortSubBits) || args.bin_bits > (uint32_t)kSortMaxBinBits ||
         args.cap > (uint32_t)kSortCap || max_groups < 1)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bin_finalize_kernel, dim3((unsigned)std::min<uint64_t>(bins, (uint64_t)max_groups)), dim3(kFinThreads), 0, stream, args);
+    const dim3 grid((unsigned)std::min<uint64_t>(bins, (uint64_t)max_groups));
+    if (args.rows)
+        hipLaunchKernelGGL(bin_finalize_kernel<true>, grid, dim3(kFinThreads), 0, stream, args);
+    else
+        hipLaunchKernelGGL(bin_finalize_kernel<false>, grid, dim3(kFinThreads), 0, stream, args);
     return hipGetLastError();
 }
 
