@@ -101,6 +101,43 @@ def one(ctx, seed):
                 seed, algo, world, max_mm, len(guides), lens, extra,
                 hooks, len(got), len(want))
         n_rec = len(got)
+    # the streamed search that writes the feature rows on the way (side words through the sort), under the last hooks: records =
+    # the oracle's, rows = the gathering kernel's on the same hits; sometimes through the multi-device stream as well
+    if rng.integers(0, 2):
+        import torch
+        from varscot_amd.dist import DeviceAlias
+        g = ctx.load_genome(packed)
+        recs, bad_rows = [], []
+
+        def on_batch(h, first, count, rows_dev):
+            a = h.to_numpy().copy()
+            recs.append(a)
+            if len(a):
+                got_rows = torch.as_tensor(DeviceAlias(rows_dev, 64 * len(a)), device="cuda:0").view(torch.int32).view(-1, 16).cpu().numpy().view(np.uint32).copy()
+                ref, _ = h.packed_features(to_host=True)
+                if not np.array_equal(got_rows, ref):
+                    bad_rows.append(first)
+
+        batch = int(rng.choice([1, 7, 64, 100, 4096]))
+        g.search_streamed_rows(guides, max_mm, on_batch, batch=batch, extra_pam=extra, algorithm="seed")
+        g.close()
+        got = np.concatenate(recs) if recs else np.zeros(0, dtype=va.HIT_DTYPE)
+        if hits_as_tuples(got) != hits_as_tuples(want) or bad_rows:
+            return "seed %d: streamed rows differ (m=%d, %d reads, batch %d, contigs %s, extra %s, hooks %s): %d vs %d records, rows of batches %s" % (
+                seed, max_mm, len(guides), batch, lens, extra, hooks, len(got), len(want), bad_rows[:4])
+    if rng.integers(0, 3) == 0:
+        world = int(rng.integers(2, 6))
+        m = va.MultiContext([0] * world)
+        g = m.load_genome(packed)
+        recs = []
+        g.search_streamed(guides, max_mm, lambda h, first, count, votes: recs.append(h.to_numpy().copy()), batch=int(rng.choice([5, 64, 1000])),
+                          extra_pam=extra, algorithm=str(rng.choice(["scan", "seed"])), score=str(rng.choice(["rows", "rows", ""])) or None)
+        g.close()
+        m.close()
+        got = np.concatenate(recs) if recs else np.zeros(0, dtype=va.HIT_DTYPE)
+        if hits_as_tuples(got) != hits_as_tuples(want):
+            return "seed %d: multi stream x%d differs (m=%d, %d reads, contigs %s, extra %s): %d vs %d records" % (
+                seed, world, max_mm, len(guides), lens, extra, len(got), len(want))
     return n_rec
 
 

@@ -73,7 +73,8 @@ def test_one_process_over_several_devices_behind_the_abi(extra):
     r, line5 = _bench("--multi", "abi", "--gpus", "2", "--abi-devices", "0,0", "--workload", "c5", "--guides", "40", "--bases", "2000000",
                       "--batch", "16", "--steps", "1", "--warmup", "1", *extra)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert line5["config"]["batches"] == 3 and line5["config"]["hits_per_step"] > 0 and line5["vsc_multi_timing"]["score_ms_max"] > 0
+    assert line5["config"]["batches"] == 3 and line5["config"]["hits_per_step"] > 0
+    assert (line5["vsc_multi_timing"]["score_ms_max"] > 0) == bool(extra)  # (feature rows: written by the record assembly, no kernel of their own)
     assert ("classify" in line5["config"]["per_hit_scoring"]) == bool(extra)
 
 

@@ -242,6 +242,33 @@ def test_c5_streamed_batches_with_packed_scoring(big):
     assert t["read_passes"] == 2 and t["hits"] == want[0] and t["score_ms"] > 0
 
 
+def test_c5_rows_written_on_the_way_equal_the_gathered_rows(big, oracle_big):
+    """vsc_search_stream_rows at c5 batch size on the 3 Gbp genome: two batches of 5 000 reads at <= 8 mismatches, 8e8 hits each.
+    Every batch's records are strictly ascending and - for the oracle's read subset - the oracle's; every one of its 64-byte rows
+    (written by the record assembly from the bases the search kept beside the records) equals the row vsc_score_hits_packed makes
+    of the same record by gathering the window from the planes, compared in HBM."""
+    ctx, packed, genome, guides, planted = big
+    ctx.release_scratch()
+    seen = []
+
+    def on_batch(h, first, count, rows_dev):
+        n, ascending, max_nm, sums = _digest(h)
+        reads = [r for r in ORACLE_READS_C3 if first <= r < first + count]
+        _assert_equals_oracle(_records_of_reads(_device_records(h), reads), oracle_big["c3"], reads)
+        got = torch.as_tensor(_DeviceAlias(rows_dev, n * 64), device="cuda:0").view(torch.int32).view(-1, 16)
+        ref = torch.empty((n, 16), dtype=torch.int32, device="cuda:0")
+        h.packed_features(to_host=False, dev_ptr=ref.data_ptr())  # (into `ref`: the library's row buffer is not touched)
+        same = all(bool((got[b:b + (1 << 26)] == ref[b:b + (1 << 26)]).all()) for b in range(0, n, 1 << 26))
+        seen.append((first, count, n, ascending, max_nm, same))
+        del ref
+        torch.cuda.empty_cache()
+
+    genome.search_streamed_rows(guides, 8, on_batch, batch=5000, algorithm="seed")
+    assert [(f, c) for f, c, *_ in seen] == [(0, 5000), (5000, 5000)]
+    assert all(n > 700_000_000 and asc and nm <= 8 and same for _, _, n, asc, nm, same in seen), seen
+    ctx.release_scratch()
+
+
 def test_c5_all_100000_reads_streamed(big):
     """BASELINE.json configs[4] at its stated size on one GPU: all 100 000 reads streamed in 10 batches of 10 000 at
     <= 8 mismatches (1.6e10 records in total), every batch scored from the callback (packed feature rows, dropped).

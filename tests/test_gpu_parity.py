@@ -1154,7 +1154,7 @@ def test_multi_device_streamed_search_scored_on_the_owning_shard(ctx, oracle, de
     assert seen == [(b, min(batch, len(guides) - b)) for b in range(0, len(guides), batch)]
     assert np.concatenate(recs).tobytes() == want.tobytes()
     assert t["batches"] == len(seen) and t["hits"] == len(want) and t["n_devices"] == len(devices)
-    assert (t["score_ms_max"] > 0) == (score is not None)
+    assert (t["score_ms_max"] > 0) == (score == "votes")  # (the rows are written by the record assembly: no scoring kernel of their own)
     if score == "votes":
         assert np.array_equal(np.concatenate(votes), want_votes)
 

@@ -408,17 +408,17 @@ int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides,
             std::fill(s.key_counts.begin() + r * (size_t)K, s.key_counts.begin() + (r + 1) * (size_t)K, 0u);
             if (g->shard[r]) {
                 vsc_ctx *ctx = m->ctx[r];
-                vsc_hits *part = nullptr;
-                int rc = vsc_search(ctx, g->shard[r], guides + first, cnt, params, &part);
-                if (rc == VSC_OK) {
+                // what happens to one batch's result on its shard: the caller's per-hit scores where the hits were found, then
+                // the records (+ votes) packed for the exchange
+                auto pack = [&](vsc_hits *part, bool rows_done) -> int {
+                    int rc = VSC_OK;
                     vsc_timing t{};
                     (void)vsc_ctx_timing(ctx, &t);
                     search_ms[r] += t.total_ms;
                     shard_hits[r] += t.hits;
                     const uint64_t c = vsc_hits_count(part);
                     s.count[r] = c;
-                    // what the caller wants of every hit is computed here, on the device that found it
-                    if (rc == VSC_OK && c && mode == VSC_MULTI_SCORE_ROWS)
+                    if (c && mode == VSC_MULTI_SCORE_ROWS && !rows_done)
                         rc = vsc_score_hits_packed(ctx, g->shard[r], part, guides + first, cnt, 0, c, nullptr, nullptr, nullptr);
                     // (an exchange buffer that does not fit beside the context's pooled scratch: the scratch goes back first)
                     auto ensure = [&](DeviceBuf &buf, size_t bytes) {
@@ -436,7 +436,7 @@ int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides,
                                                          0, c, m->vbuf[b & 1][r].p, nullptr, nullptr);
                         }
                     }
-                    if (rc == VSC_OK && mode != VSC_MULTI_SCORE_NONE && c) {
+                    if (rc == VSC_OK && mode != VSC_MULTI_SCORE_NONE && c && !rows_done) {
                         (void)vsc_ctx_timing(ctx, &t);
                         score_ms[r] += t.score_ms;
                     }
@@ -448,7 +448,27 @@ int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides,
                             rc = vsc_hits_pack_exchange(ctx, g->shard[r], part, cnt, m->xbuf[b & 1][r].p, 1, s.key_counts.data() + r * (size_t)K);
                         }
                     }
-                    vsc_hits_free(part);  // the 8-byte records carry everything the merge needs
+                    return rc;
+                };
+                int rc;
+                if (mode == VSC_MULTI_SCORE_ROWS) {
+                    // the feature rows are written on the way (vsc_search_stream_rows: one batch = the whole read range of this
+                    // step), a consumer on the shard would read them inside the callback
+                    struct Ctx {
+                        decltype(pack) *fn;
+                    } cb{&pack};
+                    rc = vsc_search_stream_rows(ctx, g->shard[r], guides + first, cnt, params, cnt,
+                                                [](void *u, vsc_hits *part, uint32_t, uint32_t, const void *) { return (*((Ctx *)u)->fn)(part, true); }, &cb);
+                    if (rc == VSC_OK && cnt == 0) {  // (no reads: no batch, no callback)
+                        s.count[r] = 0;
+                    }
+                } else {
+                    vsc_hits *part = nullptr;
+                    rc = vsc_search(ctx, g->shard[r], guides + first, cnt, params, &part);
+                    if (rc == VSC_OK) {
+                        rc = pack(part, false);
+                        vsc_hits_free(part);  // the 8-byte records carry everything the merge needs
+                    }
                 }
                 if (rc != VSC_OK) return fail_all(rc, "shard " + std::to_string(r) + ": " + vsc_last_error(ctx));
             }
