@@ -10,6 +10,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_sources_sha  # noqa: E402  (what the counters are keyed by: bench.py prints null for other kernels)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
@@ -74,6 +76,8 @@ for w in ("c2", "c3"):
         "pairs": bench["config"].get("hits_per_step") and bench["roofline"]["valu"]["pair_compares_per_s"] * launch_ms * 1e-3,
     }
     traffic["%s/seed/1" % w] = hbm
+    traffic["%s/seed/1:counters" % w] = {"SQ_INSTS_VALU": c.get("SQ_INSTS_VALU"), "SQ_INSTS_SALU": c.get("SQ_INSTS_SALU"),
+                                         "simd_cycles": simd_cycles, "fetch_bytes_raw": fetch_raw, "write_bytes": write}
     # the sort kernels of the same runs (round 2 on: vsc_sort.hip)
     sort = {}
     for kname in ("bin_hist_kernel", "bin_partition_kernel", "bin_finalize_kernel"):
@@ -84,7 +88,32 @@ for w in ("c2", "c3"):
             sort[kname] = {"counters": ck, "fetch_bytes_x2": 2048.0 * ck.get("FETCH_SIZE", 0.0), "write_bytes": 1024.0 * ck.get("WRITE_SIZE", 0.0),
                            "rocprof_avg_ms": kernel_avg_ms(stats[0], kname) if stats else None}
     summary[w]["sort_kernels"] = sort
+# the kernels that write the per-hit feature rows of c5 (two batches of 10 000 reads), both routes
+rows = {}
+for route in ("fused", "two-pass"):
+    per = {}
+    for kname in ("seed_sliced_kernel", "bin_partition_kernel", "bin_finalize_kernel", "score_packed_kernel"):
+        ck = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            ck.update(counters(os.path.join(src, "pmc_c5_%s_%s" % (route, ctr), "**", "*counter_collection.csv"), kname))
+        stats = glob.glob(os.path.join(src, "stats_c5_%s" % route, "**", "*kernel_stats.csv"), recursive=True)
+        if ck:
+            per[kname] = {"fetch_bytes_raw_per_launch": 1024.0 * ck.get("FETCH_SIZE", 0.0), "write_bytes_per_launch": 1024.0 * ck.get("WRITE_SIZE", 0.0),
+                          "rocprof_avg_ms": kernel_avg_ms(stats[0], kname) if stats else None}
+    if per:
+        rows[route] = per
+    stats = glob.glob(os.path.join(src, "stats_c5_%s" % route, "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, "%s_c5_%s_kernel_stats.csv" % (tag, route.replace("-", "_"))))
+summary["c5_rows"] = dict(rows, note="bench.py --workload c5 --guides 20000 --rows fused | two-pass: per launch = per batch of 10 000 reads (8.2e8 ... "
+                                     "1.63e9 hits); FETCH_SIZE raw (the guide's x2 not applied), averages over the launches of the run incl. warm-up")
+summary["kernel_sources_sha"] = kernel_sources_sha()
 json.dump(summary, open(os.path.join(dst, "%s_seed_pmc.json" % tag), "w"), indent=1)
+for name in ("bench_c4", "bench_c5", "bench_c5_two_pass", "bench_c5_classify", "bench_abi_c3_x1", "bench_abi_c3_x4_one_gpu", "bench_abi_c5_x2_one_gpu", "bench_default"):
+    path = os.path.join(src, name + ".json")
+    if os.path.exists(path) and os.path.getsize(path):
+        shutil.copy(path, os.path.join(dst, "%s_%s.json" % (tag, name)))
+traffic["_kernel_sources_sha"] = kernel_sources_sha()
 traffic["_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh, digested into profiles/%s_seed_pmc.json (FETCH_SIZE x 2 + WRITE_SIZE per launch of the search kernel)" % tag
 json.dump(traffic, open(traffic_path, "w"))
 print(json.dumps({w: summary[w]["derived"] for w in ("c2", "c3")}, indent=1))
