@@ -1209,6 +1209,47 @@ def test_multi_device_exchange_over_rccl_with_one_rank(oracle):
     assert len(want) > 200 and got.tobytes() == want.tobytes()
 
 
+def test_multi_device_stream_over_rccl_with_one_rank(ctx, oracle):
+    """vsc_multi_search_stream with the RCCL leg on the one GPU of this box (hook rccl=1: a one-rank communicator that sends to
+    itself): records AND votes go through grouped ncclSend / ncclRecv, batch after batch; result = the oracle's records, votes = one
+    context's."""
+    import torch
+    from varscot_amd.classifier import Forest
+    from varscot_amd.dist import DeviceAlias
+    rng = np.random.default_rng(909)
+    guides = random_guides(rng, 30)
+    contigs = make_genome(909, [70000, 30000], guides, 5, n_plant=300, n_runs=2)
+    packed = va.PackedGenome.from_sequences(contigs)
+    want = oracle.search_fast(contigs, guides, 5)
+    forest = Forest()
+    act = np.random.default_rng(7).uniform(0.2, 1.8, size=len(guides))
+    gen = ctx.load_genome(packed)
+    h = gen.search(guides, 5, algorithm="seed")
+    want_votes, _ = forest.classify_hits(h, act)
+    h.close()
+    gen.close()
+    recs, votes = [], []
+
+    def on_batch(h, first, count, votes_dev):
+        a = h.to_numpy()
+        recs.append(a)
+        if len(a):
+            votes.append(torch.as_tensor(DeviceAlias(votes_dev, 2 * len(a)), device="cuda:0").view(torch.int16).cpu().numpy().view(np.uint16).copy())
+
+    m = va.MultiContext([0], rccl=True)
+    try:
+        assert m.uses_rccl
+        g = m.load_genome(packed)
+        g.search_streamed(guides, 5, on_batch, batch=8, algorithm="seed", score="votes", forest=forest, guide_activity=act)
+        t = m.timing()
+        g.close()
+    finally:
+        m.close()
+    assert t["used_rccl"] == 1 and t["batches"] == 4
+    assert len(want) > 200 and np.concatenate(recs).tobytes() == want.tobytes()
+    assert np.array_equal(np.concatenate(votes), want_votes)
+
+
 def test_multi_device_falls_back_to_copies_when_rccl_cannot_be_loaded(oracle):
     """librccl missing from the loader path (here: a library name that does not exist): vsc_multi_create used to
     build its error text from a second dlerror() call - NULL - and crashed; now the context reports why and the

@@ -46,7 +46,7 @@ summary = {"round": tag, "kernel": "vsc::seed_sliced_kernel",
                    "--no-cpu-baseline` (tools/collect_profiles.sh); FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE counts "
                    "64 B per 128 B request on gfx950 (MI355X_MICROARCH.md, HBM) and is doubled; averages per launch"}
 traffic_path = os.path.join(dst, "scan_traffic.json")
-traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
+traffic = {}  # only what THIS collection measured: the file is keyed by the hash of the kernel sources it was taken with
 for w in ("c2", "c3"):
     bench = json.loads(open(os.path.join(src, "bench_%s.json" % w)).read().strip().splitlines()[-1])
     json.dump(bench, open(os.path.join(dst, "%s_bench_%s_seed.json" % (tag, w)), "w"))
@@ -59,7 +59,8 @@ for w in ("c2", "c3"):
     fetch_raw = c.get("FETCH_SIZE", 0.0) * 1024.0
     write = c.get("WRITE_SIZE", 0.0) * 1024.0
     hbm = 2.0 * fetch_raw + write
-    launch_ms = bench["roofline"]["launch_ms"]
+    search_entry = bench["roofline"]["kernels"][0]  # the search kernel: first of the per-kernel entries
+    launch_ms = search_entry["ms"]
     # GRBM_GUI_ACTIVE is reported once per XCD (8 rows per dispatch, summed above): busy cycles = sum / 8
     busy = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
     simd_cycles = busy * 256 * 4
@@ -73,7 +74,7 @@ for w in ("c2", "c3"):
                     "wait_any_share_of_wave_cycles": c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0)},
         "algorithmic_bytes": bench["roofline"]["algorithmic_bytes"], "launch_ms": launch_ms,
         "rocprof_avg_ms": kernel_avg_ms(stats[0], "seed_sliced_kernel") if stats else None,
-        "pairs": bench["config"].get("hits_per_step") and bench["roofline"]["valu"]["pair_compares_per_s"] * launch_ms * 1e-3,
+        "pairs": bench["config"].get("hits_per_step") and search_entry["valu"]["pair_compares_per_s"] * launch_ms * 1e-3,
     }
     traffic["%s/seed/1" % w] = hbm
     traffic["%s/seed/1:counters" % w] = {"SQ_INSTS_VALU": c.get("SQ_INSTS_VALU"), "SQ_INSTS_SALU": c.get("SQ_INSTS_SALU"),
