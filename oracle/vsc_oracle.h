@@ -6,10 +6,15 @@
  * it, and only as the checker / the timed CPU baseline - never as the thing shipped.
  *
  * Parity status (see DESIGN.md "Oracle"):
- *   - search (rows R1-R4): PARITY UNPINNED.  The search primitive of the reference lives in SeqAn
- *     2.4.0rc2 (VARSCOT_pipeline/Dockerfile:41), which is not under /root/reference and cannot be
- *     fetched; the reference's own SAM/TSV outputs are absent git-LFS blobs.  The restatement is
- *     derived from the source of read_mapping/bidir_mapping.cpp alone (cited per function).
+ *   - search (rows R1-R4): the search primitive of the reference lives in SeqAn 2.4.0rc2
+ *     (VARSCOT_pipeline/Dockerfile:41), which is not under /root/reference and cannot be fetched; the
+ *     reference's own SAM/TSV outputs are absent git-LFS blobs.  The restatement is derived from the
+ *     source of read_mapping/bidir_mapping.cpp (cited per function) and PINNED where the reference
+ *     still holds anything: acceptance, strand and NM on the 2 779 (guide, site, NM) triples of
+ *     VARSCOT's own SAM output kept in workflow/data-objects/datasetsSampling.RData, the write order
+ *     on the 348 SAM row numbers of indexGuideSeq.RData (tests/test_oracle.py).  UNPINNED (nothing in
+ *     the reference can pin them): completeness of the hit set, the right-edge rule, N handling, the
+ *     MD text.
  *   - feature matrix (row R6): pinned by tests/golden/features_golden.npz (6960 x 442 values from
  *     workflow/data-objects/featureMatrix.RData).
  *   - MIT score (row R5): pinned by the known answers SURVEY.md section 8 R5 lists and, where the
