@@ -243,7 +243,7 @@ def run_abi_child(args):
                                                              "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
-        child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
     except Exception as e:  # noqa: BLE001
         return {"error": "child not run: %r" % (e,)}
     lines = [l for l in child.stdout.decode(errors="replace").splitlines() if l.startswith("{")]

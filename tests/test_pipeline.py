@@ -194,13 +194,15 @@ def test_driver_in_one_process_equals_the_staged_tools(scenario, tmp_path, evalu
     vcf2.write_text("\n".join(lines) + "\n")
     for case, extra in (("ref", []), ("one", ["-f", str(d / "in.vcf"), "-s", "0"]), ("two", ["-f", str(vcf2), "-s", "all"]), ("pam", ["-p", "AG"])):
         got = {}
-        for route in ("inproc", "staged"):
+        for route in ("inproc", "staged") + (("shards",) if case == "one" else ()):
             out = tmp_path / ("%s_%s.txt" % (case, route))
             cmd = ["bash", driver, "-b", str(d / "targets.bed"), "-o", str(out), "-g", str(d / "genome.fa"), "-i", str(tmp_path / "idx"),
                    "-m", "5", "-t", "2", "-T", str(tmp_path / ("tmp_" + route)), "-a", str(d / "activity.txt"), "-e", evaluation] + extra
             env = dict(os.environ)
             if route == "staged":
                 env["VARSCOT_STAGED"] = "1"
+            if route == "shards":  # the reference search over three contexts on the one GPU (vsc_multi_search), same files
+                env["VARSCOT_DEVICES"] = "0,0,0"
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
             assert r.returncode == 0, r.stdout + r.stderr
             stems = ["%s_sample%d" % (str(out)[:-4], k) for k in (0, 1)] if case == "two" else [str(out)[:-4]]
@@ -213,6 +215,7 @@ def test_driver_in_one_process_equals_the_staged_tools(scenario, tmp_path, evalu
                     assert not os.path.exists(stem + "_feature_matrix.txt")
             got[route] = files
         assert got["inproc"] == got["staged"], case
+        assert got.get("shards", got["inproc"]) == got["inproc"], case
         first = next(iter(got["inproc"].values())).decode().splitlines()
         assert len(first) > 20 and first[0].split("\t")[3] == ("Targetsite" if evaluation == "mit" else "Name")
         if case != "ref" and case != "pam":

@@ -113,7 +113,8 @@ int main(int argc, char **argv)
         {'s', "samples", "VCF sample columns, comma-separated (default 0)", false},
         {'e', "evaluation", "mit (default) | class | prob", false},
         {'S', "md-style", "0 = SAM-spec MD strings (default), 1 = no zeros between adjacent mismatches", false},
-        {'D', "device", "HIP device (default 0)", false},
+        {'D', "device", "HIP device (default 0), or a comma-separated list (0,1,2,...): the reference genome is sharded over those devices for its "
+                        "search (vsc_multi_search: one gather to the first), everything else runs on the first", false},
         {'t', "threads", "Host threads for VCF parsing and text", false},
         {'V', "verbose", "Stage times on stderr", false, false},
     };
@@ -130,6 +131,7 @@ int main(int argc, char **argv)
     lap.on = val('V').set;
     vsc_ctx *ctx = nullptr;
     vsc_genome *genome = nullptr;
+    vsc_multi *multi = nullptr;
     int rc = 1;
     try {
         char *end = nullptr;
@@ -139,7 +141,9 @@ int main(int argc, char **argv)
         if (evaluation != "mit" && evaluation != "class" && evaluation != "prob") throw std::runtime_error("Error: -e must be mit, class or prob.");
         const bool features = evaluation != "mit";
         const int md_style = val('S').set ? std::atoi(val('S').value.c_str()) : 0;
-        const int device = val('D').set ? std::atoi(val('D').value.c_str()) : 0;
+        std::vector<int> devices;
+        for (unsigned d : parse_list(val('D').set ? val('D').value : "0")) devices.push_back((int)d);
+        const int device = devices[0];
         const unsigned threads = val('t').set ? (unsigned)std::atoi(val('t').value.c_str()) : 0;
         const std::string stem = val('o').value, prefix = val('i').value, fasta = val('g').value;
         const std::string pam = val('p').set ? val('p').value : "";
@@ -217,15 +221,32 @@ int main(int argc, char **argv)
             sp.extra_pam[1] = pam[1];
         }
         vsc_hits *hits = nullptr;
-        st = vsc_search(ctx, genome, codes.data(), (uint32_t)codes.size(), &sp, &hits);
-        if (st != VSC_OK) throw std::runtime_error(vsc_last_error(ctx));
+        if (devices.size() > 1) {
+            // the reference genome over several devices (what `bidir_mapping -D 0,1,...` does): shards, one gather, merge
+            vsc_genome_free(genome);
+            genome = nullptr;
+            vsc_multi_genome *mg = nullptr;
+            st = vsc_multi_create(devices.data(), (int)devices.size(), &multi);
+            if (st != VSC_OK) throw std::runtime_error("could not create the device contexts");
+            st = vsc_multi_genome_load(multi, planes->hi, planes->lo, planes->nm, planes->n_words, planes->contigs.data(),
+                                       (uint32_t)planes->contigs.size(), &mg);
+            if (st == VSC_OK) st = vsc_multi_search(multi, mg, codes.data(), (uint32_t)codes.size(), &sp, &hits);
+            const std::string why = st == VSC_OK ? "" : vsc_multi_last_error(multi);
+            vsc_multi_genome_free(mg);
+            if (st != VSC_OK) throw std::runtime_error(why);
+        } else {
+            st = vsc_search(ctx, genome, codes.data(), (uint32_t)codes.size(), &sp, &hits);
+            if (st != VSC_OK) throw std::runtime_error(vsc_last_error(ctx));
+        }
         lap("reference search");
         const std::vector<OffTarget> ref_hits = rows_of_hits(
             hits, ctx, read_names, md_style, [&](uint32_t c) -> const std::string & { return planes->names[c]; },
             [&](uint32_t c, uint32_t pos) { return planes->bases(c, pos, VSC_READ_LEN); });
         vsc_hits_free(hits);
-        vsc_genome_free(genome);
+        if (genome) vsc_genome_free(genome);
         genome = nullptr;
+        if (multi) vsc_multi_destroy(multi);
+        multi = nullptr;
         lap("reference records -> off-targets");
 
         OutputOptions oo;
@@ -319,6 +340,7 @@ int main(int argc, char **argv)
         rc = 1;
     }
     if (genome) vsc_genome_free(genome);
+    if (multi) vsc_multi_destroy(multi);
     if (ctx) vsc_ctx_destroy(ctx);
     return rc;
 }

@@ -536,13 +536,16 @@ int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides,
             };
             in_group(m->rccl.GroupStart());
             if (bad == ncclSuccess) {
+                // (one thread drives both ends: the current device is set to the communicator's before each call, as
+                // RCCL's single-process examples do)
+                (void)hipSetDevice(m->device[0]);
                 in_group(m->rccl.Recv(m->gbuf[r].p, rec_bytes, ncclUint8, (int)r, m->comm[0], m->xstream[0]));
+                if (votes) in_group(m->rccl.Recv(m->gvotes[r].p, vote_bytes, ncclUint8, (int)r, m->comm[0], m->xstream[0]));
+                (void)hipSetDevice(m->device[r]);
                 in_group(m->rccl.Send(src, rec_bytes, ncclUint8, 0, m->comm[r], m->xstream[r]));
-                if (votes) {
-                    in_group(m->rccl.Recv(m->gvotes[r].p, vote_bytes, ncclUint8, (int)r, m->comm[0], m->xstream[0]));
-                    in_group(m->rccl.Send(vsrc, vote_bytes, ncclUint8, 0, m->comm[r], m->xstream[r]));
-                }
+                if (votes) in_group(m->rccl.Send(vsrc, vote_bytes, ncclUint8, 0, m->comm[r], m->xstream[r]));
                 in_group(m->rccl.GroupEnd());
+                (void)hipSetDevice(m->device[0]);
             }
             if (bad != ncclSuccess) return give_up_rccl("send / receive of the hit records", bad);
             if (r != 0) mt.exchanged_bytes += rec_bytes + vote_bytes;
