@@ -178,7 +178,7 @@ int vsc_genome_build_index(vsc_ctx *ctx, vsc_genome *genome, const vsc_search_pa
  * The file names the library version, the PAM set, a fingerprint of the genome and the sizes of its arrays; _load
  * refuses a file that does not match or whose length is not what its header announces (VSC_ERR_INVALID,
  * vsc_last_error says why; the genome's index stays as it was - only a read error half-way leaves it without one).  36 bytes per window:
- * at 3 Gbp the file is 27 GB and rebuilding on the device (0.3 s) is faster than reading it - the tools only use the
+ * at 3 Gbp the file is 27 GB and rebuilding on the device (0.19 s) is faster than reading it - the tools only use the
  * file when asked to (bidir_index -S). */
 int vsc_genome_index_save(vsc_ctx *ctx, const vsc_genome *genome, const char *path);
 int vsc_genome_index_load(vsc_ctx *ctx, vsc_genome *genome, const char *path);
