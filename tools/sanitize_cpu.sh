@@ -48,3 +48,4 @@ tsan|all)
     run tsan libclang_rt.tsan-x86_64.so "TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0" tests/test_variants.py tests/test_tools.py ;;
 esac
 grep -cE "ERROR: (Address|Thread)Sanitizer|runtime error:|WARNING: ThreadSanitizer" "$LOG" | sed 's/^/sanitizer reports: /' | tee -a "$LOG"
+rm -rf "$ROOT/build/sanitize"  # (50 MB that would travel to the GPU box with every gpurun call)
