@@ -179,6 +179,47 @@ def test_c3_scan_and_seed_agree_on_the_device(big, oracle_big):
     torch.cuda.empty_cache()
 
 
+def test_full_size_genome_sharded_behind_the_abi(big, oracle_big):
+    """The product's multi-device driver (vsc_multi_search, here three / two contexts on the one GPU) on the 3 Gbp genome: shards
+    whose positions start at 1.0e9 and 2.0e9 (records hold shard-relative positions, bins of the upper shards, contig lookup
+    with a position base), one exchange of 8-byte records, the segment merge.  c2: byte-equal to the single-context result and,
+    for the oracle's read subset, to the oracle.  c3: the same digest (count, order, NM bound, three checksums) as one context,
+    the oracle's subset again."""
+    ctx, packed, genome, guides, planted = big
+    ctx.release_scratch()
+    h = genome.search(guides[:1000], 6, algorithm="seed")
+    one = h.to_numpy().copy()
+    h.close()
+    h = genome.search(guides, 8, algorithm="seed")
+    want_c3 = _digest(h)
+    h.close()
+    ctx.release_scratch()
+    m = va.MultiContext([0, 0, 0])
+    try:
+        g = m.load_genome(packed)
+        g.build_index()
+        h = g.search(guides[:1000], 6, algorithm="seed")
+        got = h.to_numpy().copy()
+        h.close()
+        assert got.tobytes() == one.tobytes()
+        _assert_equals_oracle(got[np.isin(got["guide"], np.asarray(ORACLE_READS_C2, dtype=np.uint32))], oracle_big["c2"], ORACLE_READS_C2)
+        g.close()
+    finally:
+        m.close()
+    m = va.MultiContext([0, 0])
+    try:
+        g = m.load_genome(packed)
+        g.build_index()
+        h = g.search(guides, 8, algorithm="seed")
+        assert _digest(h) == want_c3
+        _assert_equals_oracle(_records_of_reads(_device_records(h), ORACLE_READS_C3), oracle_big["c3"], ORACLE_READS_C3)
+        h.close()
+        g.close()
+    finally:
+        m.close()
+    torch.cuda.empty_cache()
+
+
 def test_c5_streamed_batches_equal_the_oracle_on_the_read_subset(big, oracle_big):
     """Two streamed batches of 10 000 reads (the first 20 000 of the c5 read set, <= 8 mismatches): the records of
     the oracle's reads inside each batch - first / last read of a batch, region edges - equal the oracle's."""
