@@ -77,8 +77,8 @@ def parse():
     ap.add_argument("--snps", type=int, default=5_000_000, help="records of the synthetic VCF (workload c4)")
     ap.add_argument("--batch", type=int, default=10_000, help="reads per search call for the streamed workload c5")
     ap.add_argument("--sub-batches", type=int, default=None,
-                    help="multi-rank runs with --exchange reads: cut the reads into this many pieces and overlap the "
-                         "exchange of one piece with the search of the next (default: 4 at 2 ranks, 2 at 3-4, 1 otherwise)")
+                    help="multi-rank runs: cut the reads into this many pieces and overlap the exchange of one piece with the "
+                         "search of the next (default: --exchange root 4; --exchange reads 4 at 2 ranks, 2 at 3-4, 1 otherwise)")
     ap.add_argument("--rehearse", action="store_true",
                     help="rehearsal of the multi-rank control flow on a box with ONE GPU: all ranks use cuda:0, the "
                          "process group is gloo and the records travel through host memory (use a small workload)")
@@ -477,8 +477,13 @@ def main():
 
     # more pieces = more of the exchange hidden, but every piece visits all site chunks again (c3 on one GPU:
     # 102 ms in one piece, 116 ms in four): 4 pieces at 2 ranks (13 GB over one link), 2 at 4, 1 at 8
-    sub_batches = args.sub_batches if args.sub_batches is not None else {2: 4, 3: 2, 4: 2}.get(world, 1)
-    pipelined = use_dist and args.exchange == "reads" and sub_batches > 1 and args.workload in ("c2", "c3")
+    # (--exchange root: the gather to rank 0 is the long leg at every N - 13 GB into one GPU's links - so always 4 pieces:
+    # piece i travels while piece i + 1 is searched and piece i - 1 is merged, varscot_amd.dist.sharded_search_stream)
+    if args.sub_batches is not None:
+        sub_batches = args.sub_batches
+    else:
+        sub_batches = {2: 4, 3: 2, 4: 2}.get(world, 1) if args.exchange == "reads" else 4
+    pipelined = use_dist and sub_batches > 1 and args.workload in ("c1", "c2", "c3")
     # (the headline is --exchange root unless asked otherwise: the north star's single gather; "reads" is reported beside it)
 
     # per-step sums of the library's device timings (vsc_timing): every step function returns
@@ -515,6 +520,20 @@ def main():
 
     def step_pipelined():
         timings, acc = [], new_acc()
+        if mode["exchange"] == "root":
+            total = [0]
+
+            def on_piece(mh, first, count, votes):
+                if mh is not None:
+                    total[0] += len(mh)
+
+            def note(h, first, count):          # (called after every piece's search on the rank that ran it)
+                add_timing(acc, ctx.timing())
+                return None
+
+            vdist.sharded_search_stream(ctx, genome, codes, max_mm, on_piece, -(-n_guides // sub_batches), device=xdev,
+                                        algorithm=algorithm, score=note)
+            return [], total[0], acc
         parts = vdist.sharded_search_pipelined(ctx, genome, codes, max_mm, device=xdev, algorithm=algorithm,
                                                sub_batches=sub_batches, timings=timings)
         for t in timings:
@@ -625,7 +644,7 @@ def main():
             keep = (dt_x, sums_x, hits_x)
         mode.update(exchange=args.exchange, pipelined=True)
         if pipelined:
-            dt, sums, total_hits, _ = timed_run()   # the headline: --exchange reads with the exchange of one piece
+            dt, sums, total_hits, _ = timed_run()   # the headline: --exchange's gather with the exchange of one piece
         else:                                       # hidden behind the search of the next
             dt, sums, total_hits = keep             # (the last plain run was --exchange's)
     else:

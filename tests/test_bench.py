@@ -50,7 +50,8 @@ def test_two_ranks_on_one_gpu_report_both_exchanges():
     assert line["config"]["hits_per_step"] > 0
     # the headline is the north star's single gather; the product's own multi-device driver (one process over the devices
     # behind the C ABI) ran the same workload first, as a child of rank 0, and its line is embedded
-    assert line["config"]["exchange"] == "root" and line["value"] == ex["root"]["value"]
+    # (in four pieces, a piece travelling while the next is searched; the plain one-piece runs are the `exchanges` entries)
+    assert line["config"]["exchange"] == "root" and line["config"]["sub_batches"] == 4 and line["value"] > 0
     abi = line["multi_abi"]
     assert "error" not in abi, abi
     assert abi["n_gpus"] == 2 and abi["config"]["devices"] == [0, 0] and abi["value"] > 0

@@ -231,10 +231,13 @@ def sharded_search_stream(ctx, genome_shard, codes, max_mismatches, on_batch, ba
     merge = merge or gpu_merge
     pending = None
 
-    def finish(p):
+    def wait(p):
         first, count, keep, recv, rreqs, vrecv, vreqs, all_counts = p
         _wait(rreqs, recv)
         _wait(vreqs, vrecv)
+
+    def deliver(p):
+        first, count, keep, recv, rreqs, vrecv, vreqs, all_counts = p
         if rank == 0:
             merged, votes = merge(recv, vrecv, all_counts, first)
             try:
@@ -245,17 +248,26 @@ def sharded_search_stream(ctx, genome_shard, codes, max_mismatches, on_batch, ba
         else:
             on_batch(None, first, count, None)
 
-    n = len(codes)
-    for first in range(0, max(n, 1), max(batch, 1)):
-        part = codes[first:first + batch]
-        local, counts, votes = produce(first, part)  # (overlaps the pending gather of the batch before)
-        if pending is not None:
-            finish(pending)
+    def start(first, part, local, counts, votes):
         all_counts = all_gather_key_counts(counts, device if on_device else None, group)
         recv, rreqs = start_gather_to_root(local, all_counts, group)
         vrecv, vreqs = (None, [])
         if votes is not None:
             vrecv, vreqs = start_gather_to_root(votes, all_counts, group, item_bytes=2)
-        pending = (first, len(part), (local, votes), recv, rreqs, vrecv, vreqs, all_counts)
+        return (first, len(part), (local, votes), recv, rreqs, vrecv, vreqs, all_counts)
+
+    # Per batch: search (+ score + pack) while the batch before travels; then that one has arrived, THIS batch's gather is
+    # started, and only then the arrived one is merged and handed over - the links are busy while rank 0 merges.
+    n = len(codes)
+    for first in range(0, max(n, 1), max(batch, 1)):
+        part = codes[first:first + batch]
+        local, counts, votes = produce(first, part)
+        if pending is not None:
+            wait(pending)
+        nxt = start(first, part, local, counts, votes)
+        if pending is not None:
+            deliver(pending)
+        pending = nxt
     if pending is not None:
-        finish(pending)
+        wait(pending)
+        deliver(pending)
