@@ -35,6 +35,12 @@ def test_rf_predict_matches_restatement_and_training_labels(golden_dir):
     feats = x[:, :442].astype(np.uint8)
     act = x[:, 442].astype(np.float64)
     prob, cls, tie = Forest(MODEL).predict(ctx, feats, act)
+    # the three node forms of the kernel (pair nodes - the default for this forest -, compact nodes, plain nodes) vote alike
+    for form in (1, 0):
+        ctx.set_debug(rf_form=form)
+        other = Forest(MODEL).predict(ctx, feats, act)
+        assert all(np.array_equal(a, b) for a, b in zip((prob, cls, tie), other)), form
+    ctx.set_debug()
     of = OracleForest(MODEL)
     for i in range(0, len(x), 5):  # every 5th row through the Python restatement: identical votes
         p, c, ti = of.predict(dict(zip(names, x[i])))
@@ -158,10 +164,11 @@ def _synthetic_forest(path, rng, n_trees, n_nodes, names, depth_first=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_nodes", [31, 511, 512, 700])
-def test_rf_predict_on_synthetic_forests(tmp_path, golden_dir, n_nodes):
-    """Both node forms of the forest kernel - compact nodes walked through per-lane tree queues (<= 512 nodes per tree)
-    and the self-looping form with wave-uniform step counts (more) - against the Python restatement of
+@pytest.mark.parametrize("n_nodes,form", [(31, -1), (511, -1), (512, -1), (512, 1), (512, 0), (31, 1), (700, -1)])
+def test_rf_predict_on_synthetic_forests(tmp_path, golden_dir, n_nodes, form):
+    """The node forms of the forest kernel - pair nodes (two levels per 8-byte node) and compact nodes, both walked through
+    per-lane tree queues (<= 512 nodes per tree; `form` = the rf_form hook: 1 stops at the compact form, 0 at the plain one),
+    and the self-looping form with wave-uniform step counts (more nodes) - against the Python restatement of
     randomForest's predict, on random forests: unbalanced trees, trees that are one terminal node, count predictors
     split at integers and at x.5, splits below zero and above every value, the activity split at a handful of
     thresholds with rows exactly on them; dense rows, packed rows and few / many rows."""
@@ -175,6 +182,7 @@ def test_rf_predict_on_synthetic_forests(tmp_path, golden_dir, n_nodes):
     feats = g["feat"][::9].astype(np.uint8)
     act = rng.choice([0.2, 0.31, 0.5, 0.77, 0.9, 1.02, 1.4, 1.7], size=len(feats))
     ctx = va.Context(0)
+    ctx.set_debug(rf_form=form)
     forest = Forest(path)
     prob, cls, tie = forest.predict(ctx, feats, act)
     of = OracleForest(path)

@@ -2256,6 +2256,8 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
     h = hash_words(model->split, nn * 8, h);
     h = hash_words(model->node_class, nn, h);
     vsc_ctx::Forest &f = ctx->forest;
+    const int want_form = ctx->dbg.rf_form;  // (test hook: -1 = the best form the forest allows)
+    h ^= (uint64_t)(uint32_t)(want_form + 2) * 0x9E3779B97F4A7C15ull;
     if (f.nodes.p && f.fingerprint == h && f.n_trees == model->n_trees && f.n_nodes == model->n_nodes) return VSC_OK;
     f.fingerprint = 0;
     // distinct activity thresholds, ascending: `activity <= T_j` <=> `rank(activity) <= j`
@@ -2315,7 +2317,7 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
     for (size_t i = 0; i < keys.size(); ++i) index_of[i] = test_index((uint16_t)(keys[i] >> 8), (uint8_t)keys[i]);
     // nodes: test | left << 10 | right << 20 (0-based) | terminal << 30 | votes class "1" << 31; or the compact form
     // (trees of <= 512 nodes): test | (nodes to skip | vote << 10) << 10 (right) / << 21 (left)
-    const bool compact = model->n_nodes <= 512;
+    const bool compact = model->n_nodes <= 512 && want_form != 0;
     std::vector<uint32_t> nodes(nn);
     std::vector<uint8_t> depth(model->n_trees, 0);
     std::vector<uint16_t> level(model->n_nodes);
@@ -2352,12 +2354,83 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
             nodes[(size_t)tr * model->n_nodes] = leaf << 10 | leaf << 21;
         }
     }
+    // PAIR form (vsc_internal.h): a node of 8 bytes holds a split node AND its two daughters - two levels per LDS read.
+    // Pair nodes are rooted at the split nodes on even levels; a tree's pair nodes lie in breadth-first order (every exit
+    // leads forward), the trees back to back at a stride of `pair_stride` nodes.  For forests of at most 256 tests and 127
+    // pair nodes per tree (rfClassifier: 217 and 70).
+    std::vector<uint64_t> pairs;
+    uint32_t pair_stride = 0;
+    if (compact && want_form != 1 && tests.size() <= 256) {
+        auto split = [&](uint32_t tr, uint32_t k) { return model->node_status[(size_t)tr * model->n_nodes + k] == 1; };
+        std::vector<std::vector<uint32_t>> roots(model->n_trees);  // per tree: the split nodes that root a pair node, in order
+        std::vector<uint32_t> index_in(model->n_nodes);
+        // (first pass: the roots of every tree; second pass below fills the words once the stride is known)
+        auto daughters = [&](uint32_t tr, uint32_t k, uint32_t &l, uint32_t &r, uint32_t &test) {
+            const size_t i = (size_t)tr * model->n_nodes + k;
+            const Split sp = split_of(i);
+            l = model->left[i] - 1u, r = model->right[i] - 1u, test = 0;
+            if (sp.never) l = r;
+            else test = index_of[std::lower_bound(keys.begin(), keys.end(), (uint32_t)sp.col << 8 | sp.thr) - keys.begin()];
+        };
+        for (uint32_t tr = 0; tr < model->n_trees; ++tr) {
+            auto &q = roots[tr];
+            q.push_back(0);  // (a tree that is one terminal node: a pair node whose four exits carry the root's vote)
+            for (size_t at = 0; at < q.size() && split(tr, q[at]); ++at) {
+                uint32_t l, r, test;
+                daughters(tr, q[at], l, r, test);
+                for (uint32_t c : {l, r}) {
+                    if (!split(tr, c)) continue;
+                    uint32_t cl, cr, ct;
+                    daughters(tr, c, cl, cr, ct);
+                    for (uint32_t g : {cl, cr})
+                        if (split(tr, g) && std::find(q.begin(), q.end(), g) == q.end()) q.push_back(g);
+                }
+            }
+            pair_stride = std::max<uint32_t>(pair_stride, (uint32_t)q.size());
+        }
+        if (pair_stride <= 127) {
+            pairs.assign((size_t)model->n_trees * pair_stride, 0);
+            for (uint32_t tr = 0; tr < model->n_trees; ++tr) {
+                const auto &q = roots[tr];
+                for (uint32_t j = 0; j < q.size(); ++j) index_in[q[j]] = j;
+                auto vote_of = [&](uint32_t k) { return model->node_class[(size_t)tr * model->n_nodes + k] == 2 ? 1u : 0u; };
+                for (uint32_t j = 0; j < q.size(); ++j) {
+                    // an exit (one byte): vote | pair nodes to skip << 1 - to the pair node rooted at a split granddaughter, or -
+                    // terminal - to the next tree's root with the vote
+                    auto exit_to = [&](uint32_t g) { return split(tr, g) ? (index_in[g] - j) << 1 : ((pair_stride - j) << 1 | vote_of(g)); };
+                    uint32_t ex[4], t_root = 0, t_left = 0, t_right = 0;  // ex[2 * (root bit) + (daughter bit)]; bit set = x <= thr = LEFT
+                    if (!split(tr, q[j])) {
+                        ex[0] = ex[1] = ex[2] = ex[3] = exit_to(q[j]);
+                    } else {
+                        uint32_t l, r;
+                        daughters(tr, q[j], l, r, t_root);
+                        auto half = [&](uint32_t c, uint32_t &t, uint32_t &on_left, uint32_t &on_right) {
+                            if (!split(tr, c)) { t = 0; on_left = on_right = exit_to(c); return; }
+                            uint32_t cl, cr;
+                            daughters(tr, c, cl, cr, t);
+                            on_left = exit_to(cl), on_right = exit_to(cr);
+                        };
+                        half(l, t_left, ex[3], ex[2]);
+                        half(r, t_right, ex[1], ex[0]);
+                    }
+                    // a test in the upper word: its bit in the row's test word at bits s .. s + 4, the word's number at s + 10 ..
+                    // s + 12 (s = 0 root, 5 right daughter, 18 left daughter: rf_predict_kernel masks the word number in place)
+                    auto field = [](uint32_t test, uint32_t s) { return (uint64_t)((test & 31u) | (test >> 5) << 10) << s; };
+                    uint64_t w = 0;
+                    for (int e = 0; e < 4; ++e) w |= (uint64_t)ex[e] << (8 * e);
+                    w |= (field(t_root, 0) | field(t_right, 5) | field(t_left, 18)) << 32;
+                    pairs[(size_t)tr * pair_stride + j] = w;
+                }
+            }
+        }
+    }
     VSC_HIP(ctx, hipSetDevice(ctx->device));
     auto pad = [](size_t n) { return (n + 255) / 256 * 256; };
-    const size_t nodes_b = pad(nn * sizeof(uint32_t)), depth_b = pad(depth.size()), tests_b = pad(tests.size() * sizeof(RfTest));
+    const size_t node_bytes = pairs.empty() ? nn * sizeof(uint32_t) : pairs.size() * sizeof(uint64_t);
+    const size_t nodes_b = pad(node_bytes), depth_b = pad(depth.size()), tests_b = pad(tests.size() * sizeof(RfTest));
     VSC_HIP(ctx, f.nodes.ensure(nodes_b + depth_b + tests_b + pad(test_begin.size() * sizeof(uint32_t))));
     char *base = (char *)f.nodes.p;
-    VSC_HIP(ctx, hipMemcpyAsync(base, nodes.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    VSC_HIP(ctx, hipMemcpyAsync(base, pairs.empty() ? (const void *)nodes.data() : (const void *)pairs.data(), node_bytes, hipMemcpyHostToDevice, ctx->stream));
     VSC_HIP(ctx, hipMemcpyAsync(base + nodes_b, depth.data(), depth.size(), hipMemcpyHostToDevice, ctx->stream));
     VSC_HIP(ctx, hipMemcpyAsync(base + nodes_b + depth_b, tests.data(), tests.size() * sizeof(RfTest), hipMemcpyHostToDevice, ctx->stream));
     VSC_HIP(ctx, hipMemcpyAsync(base + nodes_b + depth_b + tests_b, test_begin.data(), test_begin.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -2366,7 +2439,8 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
     f.tests_at = nodes_b + depth_b;
     f.begin_at = nodes_b + depth_b + tests_b;
     f.n_tests = (uint32_t)tests.size();
-    f.compact = compact;
+    f.form = !pairs.empty() ? 2u : compact ? 1u : 0u;
+    f.node_stride = !pairs.empty() ? pair_stride : model->n_nodes;
     f.n_trees = model->n_trees;
     f.n_nodes = model->n_nodes;
     f.thresholds = thr;
@@ -2383,9 +2457,9 @@ void fill_forest(RfArgs &a, const vsc_ctx *ctx)
     a.tests = (const RfTest *)(base + f.tests_at);
     a.test_begin = (const uint32_t *)(base + f.begin_at);
     a.n_tests = f.n_tests;
-    a.compact = f.compact ? 1u : 0u;
+    a.compact = f.form;
     a.n_trees = f.n_trees;
-    a.n_nodes = f.n_nodes;
+    a.n_nodes = f.node_stride;
 }
 
 uint8_t activity_rank(const std::vector<double> &thr, double activity)

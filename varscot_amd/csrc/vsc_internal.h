@@ -255,6 +255,8 @@ constexpr int kRfRows = 512;             // feature rows per workgroup (one thre
 constexpr int kRfMaxTests = 1024;        // distinct (predictor, threshold) pairs a forest may use
 constexpr int kRfMaxNodes = 1024;        // nodes of one tree (rfClassifier: 275)
 constexpr int kRfTileBytes = 26624;      // whole trees staged in LDS per step (with 14 KB of test bits: 4 workgroups = 32 waves per CU)
+constexpr int kRfPairBitsBytes = 16384;  // pair form: the test bits as two planes of 256 rows x 8 words
+constexpr int kRfPairTileBytes = 24512;  // ... and its tree tile (16 + 24 KB: four workgroups per CU)
 constexpr int kRfChains = 2;             // trees a thread walks at the same time (compact form)
 constexpr int kRfRowWords = 20;          // a row as the test extraction sees it: 16 packed words, 3 words of dinucleotide
                                          // counts (5 bits each, 6 / 6 / 4), 1 word activity rank
@@ -269,7 +271,8 @@ struct RfArgs {
     const uint32_t *nodes;      // [n_trees * n_nodes], tree-major
     const uint8_t *depth;       // [n_trees] steps from the root to the deepest terminal node
     uint32_t n_trees, n_nodes;
-    uint32_t compact;           // 1: compact nodes (<= 512 per tree), walked through per-lane tree queues; 0: the form above
+    uint32_t compact;           // 2: pair nodes (8 bytes, two levels each), 1: compact nodes (<= 512 per tree), both walked through
+                                // per-lane tree queues; 0: the form above
     const RfTest *tests;        // [n_tests], sorted by the row word they read
     const uint32_t *test_begin; // [kRfRowWords + 1] first test of every row word
     uint32_t n_tests;

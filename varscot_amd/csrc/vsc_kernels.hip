@@ -874,9 +874,13 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
     extern __shared__ uint32_t s_dyn[];
     // s_bits[word][thread]: the row's test results, one bit per test; then the tree tile
     const uint32_t n_words = (a.n_tests + 31u) / 32u;
-    uint32_t *const s_bits = s_dyn;
-    uint32_t *const s_tile = s_dyn + (size_t)n_words * kRfRows;
     const uint32_t t = threadIdx.x;
+    // pair form: two planes of 256 threads, eight words of 1 KB each (the walk masks a word's number into the address in place:
+    // the words must lie a power of two apart that the node has room for); else words of kRfRows threads
+    const bool pairs = a.compact == 2u;
+    const uint32_t bits_stride = pairs ? 256u : (uint32_t)kRfRows, bits_base = pairs ? (t >> 8) * 2048u + (t & 255u) : t;
+    uint32_t *const s_bits = s_dyn;
+    uint32_t *const s_tile = s_dyn + (pairs ? (size_t)kRfPairBitsBytes / sizeof(uint32_t) : (size_t)n_words * kRfRows);
     const uint64_t row = (uint64_t)blockIdx.x * kRfRows + t;
     const bool live = row < a.n;
     if (kMode == 0) {
@@ -889,7 +893,7 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
                 const uint32_t x = !live ? 0u : (ts.dense_col == VSC_N_FEATURES ? rank : a.dense[row * VSC_N_FEATURES + ts.dense_col]);
                 bits |= (x <= ts.thr ? 1u : 0u) << (i & 31u);
             }
-            s_bits[wd * kRfRows + t] = bits;
+            s_bits[wd * bits_stride + bits_base] = bits;
         }
     } else {
         uint32_t w[16] = {};
@@ -931,24 +935,35 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
                 const uint32_t x = (rk >> ts.shift) & ((1u << ts.width) - 1u);
                 bits |= (x <= ts.thr ? 1u : 0u) << (i & 31u);
                 if ((i & 31u) == 31u) {
-                    s_bits[(i >> 5) * kRfRows + t] = bits;
+                    s_bits[(i >> 5) * bits_stride + bits_base] = bits;
                     bits = 0;
                 }
             }
         }
-        if (a.n_tests & 31u) s_bits[(a.n_tests >> 5) * kRfRows + t] = bits;
+        if (a.n_tests & 31u) s_bits[(a.n_tests >> 5) * bits_stride + bits_base] = bits;
     }
     // this workgroup's share of the trees
     const uint32_t per_split = (a.n_trees + a.tree_splits - 1) / a.tree_splits;
     const uint32_t tree_begin = blockIdx.y * per_split, tree_end = min(tree_begin + per_split, a.n_trees);
-    const uint32_t tile_trees = max(1u, (uint32_t)(kRfTileBytes / sizeof(uint32_t)) / a.n_nodes);
-    const uint32_t *const bt = s_bits + t;
+    const uint32_t tile_trees = max(1u, (pairs ? (uint32_t)(kRfPairTileBytes / sizeof(uint2)) : (uint32_t)(kRfTileBytes / sizeof(uint32_t))) / a.n_nodes);
+    const uint32_t *const bt = s_bits + bits_base;
     uint32_t ones = 0;
     for (uint32_t t0 = tree_begin; t0 < tree_end; t0 += tile_trees) {
         const uint32_t nt = min(tile_trees, tree_end - t0);
         block_sync();  // the previous tile (first round: the rows' words) is done with
         const uint32_t *src = a.nodes + (size_t)t0 * a.n_nodes;
-        if (a.compact) {  // [trees of chain 0][sink][trees of chain 1][sink] - see below
+        if (a.compact == 2u) {  // pair nodes (8 bytes): the same layout as the compact form, [trees of chain 0][sink][trees of chain 1][sink]
+            const uint2 *const src2 = (const uint2 *)a.nodes + (size_t)t0 * a.n_nodes;
+            uint2 *const tile2 = (uint2 *)s_tile;
+            const uint32_t per_nodes = ((nt + kRfChains - 1) / kRfChains) * a.n_nodes, total = nt * a.n_nodes;
+            for (uint32_t i = t; i < total; i += kRfRows) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int k = 1; k < kRfChains; ++k) c += i >= (uint32_t)k * per_nodes ? 1u : 0u;
+                tile2[i + c] = src2[i];
+            }
+            if (t < (uint32_t)kRfChains) tile2[min((t + 1u) * per_nodes, total) + t] = make_uint2(0u, 0u);
+        } else if (a.compact) {  // [trees of chain 0][sink][trees of chain 1][sink] - see below
             // chain c's trees lie c words further on: a sink word follows every chain
             const uint32_t per_nodes = ((nt + kRfChains - 1) / kRfChains) * a.n_nodes, total = nt * a.n_nodes;
             for (uint32_t i = t; i < total; i += kRfRows) {
@@ -965,6 +980,58 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
             for (uint32_t i = t; i < nt * a.n_nodes; i += kRfRows) s_tile[i] = src[i];
         }
         block_sync();
+        if (a.compact == 2u) {
+            // PAIR nodes: the per-lane tree queues of the compact form below, two levels per step.  A node of 8 bytes holds a
+            // split node's test, both daughters' tests and the four exits (granddaughters): one 8-byte LDS read - a random
+            // ds_read_b64 of a wave costs what a random ds_read_b32 costs, 64 banks of pairs against 32 - and two reads of the
+            // row's test words (conflict-free) per TWO levels, instead of two and two: 11 LDS cycles instead of 18.  That leaves
+            // the vector unit as the bound (tools/micro/valu_kinds.hip: 2.4 cycles per SIMD for the two-operand shifts / and / add,
+            // 2.7 for v_bitop3, 4.2 for every other three-operand form), so the node is laid out for few and cheap instructions:
+            //   lower word: exit[2 * root bit + daughter bit], a byte each: vote | pair nodes to skip << 1
+            //   upper word: three tests, each as (bit in the row's test word: 5 bits at s, number of the word: 3 bits at s + 10),
+            //   s = 0 root, 5 right daughter, 18 left daughter (bit set = x <= thr = left).  A test word's address is the upper
+            //   word (shifted by s) masked IN PLACE, OR-ed into the lane's base - one v_bitop3; the bit comes out as a mask
+            //   (v_bfe_i32, which takes its offset from the low five bits of the same register) that selects the daughter's test
+            //   and the exit byte's shift.  A terminal daughter: both its exits carry its vote to the next tree's root.
+            //   All zero = the sink (a real node has no zero exit).
+            typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
+            typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+            typedef const __attribute__((address_space(3))) v2u *lds_u64;
+            const uint32_t per = (nt + kRfChains - 1) / kRfChains;
+            const uint32_t tile_at = (uint32_t)(uintptr_t)(lds_u32)s_tile, bits_at = (uint32_t)(uintptr_t)(lds_u32)bt;
+            uint32_t k_word = 0x1C00u, k_16 = 16u;  // (in vector registers: a scalar or literal operand makes v_bitop3 a 4.2-cycle instruction)
+            asm volatile("" : "+v"(k_word), "+v"(k_16));
+            uint32_t at[kRfChains];
+            v2u n[kRfChains];
+            uint32_t any = 0;
+#pragma unroll
+            for (int c = 0; c < kRfChains; ++c) {
+                const uint32_t first = min((uint32_t)c * per, nt);
+                at[c] = tile_at + (first * a.n_nodes + (uint32_t)c) * 8u;
+                n[c] = *(lds_u64)(uintptr_t)at[c];
+                any |= n[c].x;
+            }
+            while (__ballot(any != 0u)) {
+                any = 0;
+#pragma unroll
+                for (int c = 0; c < kRfChains; ++c) {
+                    const uint32_t hi = n[c].y;
+                    const uint32_t w_root = *(lds_u32)(uintptr_t)__builtin_amdgcn_bitop3_b32(hi, k_word, bits_at, 0xEA);  // (hi & k) | base
+                    const uint32_t m_root = (uint32_t)__builtin_amdgcn_sbfe((int)w_root, hi, 1u);                          // all ones: left
+                    const uint32_t next = __builtin_amdgcn_bitop3_b32(m_root, hi >> 18, hi >> 5, 0xCA);                    // m ? left : right
+                    const uint32_t w_next = *(lds_u32)(uintptr_t)__builtin_amdgcn_bitop3_b32(next, k_word, bits_at, 0xEA);
+                    const uint32_t m_next = (uint32_t)__builtin_amdgcn_sbfe((int)w_next, next, 1u);
+                    const uint32_t d = n[c].x >> __builtin_amdgcn_bitop3_b32(m_root, k_16, m_next & 8u, 0xEA);            // exit byte 2 r + d
+                    ones += d & 1u;
+                    uint32_t skip;
+                    asm("v_and_b32 %0, 0xfe, %1" : "=v"(skip) : "v"(d));
+                    at[c] += skip << 2;
+                    n[c] = *(lds_u64)(uintptr_t)at[c];
+                    any |= n[c].x;
+                }
+            }
+            continue;
+        }
         if (a.compact) {
             // Per-lane tree queues: a lane that reaches a terminal node goes straight on to its next tree instead of
             // idling until the deepest tree of the wave is through (the trees are 11 - 21 levels deep, a row's path 9
@@ -1042,12 +1109,15 @@ hipError_t launch_rf_predict(const RfArgs &args, hipStream_t stream)
 {
     if (args.n == 0) return hipSuccess;
     if (args.n_tests > (uint32_t)kRfMaxTests || args.n_tests == 0 || args.n_nodes > (uint32_t)kRfMaxNodes || args.n_nodes == 0 ||
-        (size_t)args.n_nodes * sizeof(uint32_t) > (size_t)kRfTileBytes)
+        (args.compact == 2u ? (size_t)args.n_nodes * sizeof(uint2) > (size_t)kRfPairTileBytes || args.n_tests > 256u || args.n_nodes > 127u
+                            : (size_t)args.n_nodes * sizeof(uint32_t) > (size_t)kRfTileBytes))
         return hipErrorInvalidValue;
     const uint64_t tiles = (args.n + kRfRows - 1) / kRfRows;
     if (tiles >= (1ull << 31)) return hipErrorInvalidValue;
     const size_t n_words = (args.n_tests + 31) / 32;
-    const size_t lds = n_words * kRfRows * sizeof(uint32_t) + (size_t)kRfTileBytes + 4 * kRfChains;  // test bits + the tree tile (+ a sink word per chain)
+    // test bits + the tree tile (+ a sink node per chain)
+    const size_t lds = args.compact == 2u ? (size_t)kRfPairBitsBytes + kRfPairTileBytes + 8 * kRfChains
+                                          : n_words * kRfRows * sizeof(uint32_t) + (size_t)kRfTileBytes + 4 * kRfChains;
     const int mode = args.dense ? 0 : (args.packed ? 1 : 2);
     if (mode == 2 && args.tree_splits != 1) return hipErrorInvalidValue;
     auto go = [&](auto kernel) {

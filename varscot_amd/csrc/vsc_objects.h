@@ -48,6 +48,7 @@ inline vsc_debug_params default_debug_params()
     d.seed_shared = -1;
     d.seed_group_out = -1;
     d.seed_pam21 = -1;
+    d.rf_form = -1;
     return d;
 }
 
@@ -82,7 +83,8 @@ struct vsc_ctx {
         vsc::DeviceBuf nodes, ranks;   // nodes + tree depths + test table; activity ranks of the reads of a fused call
         size_t depth_at = 0, tests_at = 0, begin_at = 0;
         uint32_t n_tests = 0, n_trees = 0, n_nodes = 0;
-        bool compact = false;           // node form (vsc_internal.h)
+        uint32_t form = 0;              // node form (vsc_internal.h): 0 plain, 1 compact, 2 pairs
+        uint32_t node_stride = 0;       // nodes from one tree's root to the next (n_nodes; pair form: the largest tree's pair nodes)
         std::vector<double> thresholds;  // distinct activity splits, ascending
         uint64_t fingerprint = 0;
         uint64_t ranks_key = 0;  // activities + forest the resident ranks were made from
