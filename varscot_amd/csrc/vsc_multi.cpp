@@ -126,12 +126,24 @@ void shard_range(uint64_t n_words, unsigned r, unsigned n, uint64_t *b, uint64_t
     *e = std::min<uint64_t>(tiles * (r + 1) / n * kTileWords, n_words);
 }
 
+// joins what was started, whatever ends the scope (a thread that cannot be started, an exception in body(0))
+struct JoinAll {
+    std::vector<std::thread> &pool;
+    ~JoinAll()
+    {
+        for (auto &t : pool)
+            if (t.joinable()) t.join();
+    }
+};
+
+// body(i) for every i on a thread of its own (i = 0 on this one).  The bodies call the C ABI, which throws nothing.
 template <class F> void on_all(size_t n, F &&body)
 {
     std::vector<std::thread> pool;
+    pool.reserve(n);
+    JoinAll join{pool};
     for (size_t i = 1; i < n; ++i) pool.emplace_back([&, i] { body(i); });
     if (n) body(0);
-    for (auto &t : pool) t.join();
 }
 
 }  // namespace
@@ -289,7 +301,8 @@ int vsc_multi_genome_load(vsc_multi *m, const uint32_t *hi, const uint32_t *lo, 
     m->err.clear();
     if (!hi || !lo || !nmask || !contigs || n_words == 0 || n_contigs == 0)
         return mfail(m, VSC_ERR_INVALID, "vsc_multi_genome_load: null or empty argument");
-    vsc_multi_genome *g = new (std::nothrow) vsc_multi_genome();
+    std::unique_ptr<vsc_multi_genome, int (*)(vsc_multi_genome *)> holder(new (std::nothrow) vsc_multi_genome(), vsc_multi_genome_free);
+    vsc_multi_genome *g = holder.get();
     if (!g) return mfail(m, VSC_ERR_NOMEM, "vsc_multi_genome_load: out of host memory");
     g->multi = m;
     const unsigned n = (unsigned)m->ctx.size();
@@ -304,17 +317,11 @@ int vsc_multi_genome_load(vsc_multi *m, const uint32_t *hi, const uint32_t *lo, 
     });
     for (unsigned r = 0; r < n; ++r)
         if (rc[r] != VSC_OK) {
-            const std::string why = vsc_last_error(m->ctx[r]);
-            vsc_multi_genome_free(g);
-            return mfail(m, rc[r], "shard " + std::to_string(r) + ": " + why);
+            return mfail(m, rc[r], "shard " + std::to_string(r) + ": " + vsc_last_error(m->ctx[r]));
         }
     const int trc = genome_table_only(m->merge_ctx, contigs, n_contigs, &g->table);
-    if (trc != VSC_OK) {
-        const std::string why = vsc_last_error(m->merge_ctx);
-        vsc_multi_genome_free(g);
-        return mfail(m, trc, "contig table on the first device: " + why);
-    }
-    *out = g;
+    if (trc != VSC_OK) return mfail(m, trc, std::string("contig table on the first device: ") + vsc_last_error(m->merge_ctx));
+    *out = holder.release();
     return VSC_OK;
     });
 }
@@ -394,7 +401,7 @@ int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides,
         cv.notify_all();
     };
 
-    auto shard_loop = [&](size_t r) {
+    auto shard_body = [&](size_t r) {
         if (hipSetDevice(m->device[r]) != hipSuccess) return fail_all(VSC_ERR_DEVICE, "shard " + std::to_string(r) + ": hipSetDevice failed");
         for (uint32_t b = 0; b < n_batches; ++b) {
             {
@@ -480,16 +487,37 @@ int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides,
             cv.notify_all();
         }
     };
+    auto shard_loop = [&](size_t r) {  // (no exception leaves a thread: the host allocations in there are strings and small vectors)
+        try {
+            shard_body(r);
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (failed == VSC_OK) failed = VSC_ERR_NOMEM;
+            cv.notify_all();
+        }
+    };
     std::vector<std::thread> pool;
-    for (size_t r = 0; r < n; ++r) pool.emplace_back(shard_loop, r);
+    pool.reserve(n);
+    // whatever ends this scope - also an exception on this thread, or a shard thread that cannot be started -: the shard
+    // threads are told to stop (they wait on `failed`) before they are joined
     struct Joiner {
         std::vector<std::thread> &p;
+        std::mutex &mu;
+        std::condition_variable &cv;
+        int &failed;
+        bool done = false;
         ~Joiner()
         {
+            if (!done) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (failed == VSC_OK) failed = VSC_ERR_NOMEM;
+            }
+            cv.notify_all();
             for (auto &t : p)
                 if (t.joinable()) t.join();
         }
-    } joiner{pool};
+    } joiner{pool, mu, cv, failed};
+    for (size_t r = 0; r < n; ++r) pool.emplace_back(shard_loop, r);
 
     // ---- the exchange thread: this one ---------------------------------------------------------------------------
     vsc_multi_timing mt{};
@@ -631,6 +659,7 @@ int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides,
         }
         mt.batches++;
     }
+    joiner.done = true;  // (a stream that broke off has set `failed` itself)
     for (auto &t : pool) t.join();
     // (the exchange and landing buffers stay pooled, like every context's scratch: hipMalloc / hipFree of 13 GB cost hundreds
     // of milliseconds per search - vsc_multi_release_scratch gives them back)
