@@ -6,7 +6,7 @@
 # by tools/digest_profiles.py into profiles/.
 set -e -o pipefail
 TAG=${1:-r01}
-PART=${2:-all}   # pmc | c5 | lines | all - gpurun gives a call at most 20 minutes: one part per call
+PART=${2:-all}   # pmc | c5 | forest | lines | all - gpurun gives a call at most 20 minutes: one part per call
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -42,6 +42,22 @@ for R in fused two-pass; do
     echo "pmc c5 $R done"
 done
 for f in "$OUT"/pmc_c5_*/*counter_collection.csv "$OUT"/pmc_c5_*/*/*counter_collection.csv; do
+    [ -f "$f" ] || continue
+    { head -1 "$f"; grep -E 'vsc::' "$f" || true; } > "$f.small" && mv "$f.small" "$f"
+done
+fi
+if [ "$PART" == forest ] || [ "$PART" == all ]; then
+# the forest walk (c5 with the classifier, one batch of 10 000 reads + the warm-up batch): vector and LDS instruction counts,
+# LDS cycles and bank-conflict cycles of rf_predict_kernel, pair nodes and (hook rf_form = 1) the compact nodes of round 3
+for F in pair compact; do
+    HOOK=""; [ "$F" == compact ] && HOOK="--hook rf_form=1"
+    ARGS="$ROOT/bench.py --workload c5 --classify --guides 10000 --steps 1 --warmup 1 --no-cpu-baseline $HOOK"
+    timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS -d "$OUT/pmc_forest_${F}_a" -o run --output-format csv -- python3 $ARGS > /dev/null 2> "$OUT/pmc_forest_${F}_a.err" || true
+    timeout -k 10 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d "$OUT/pmc_forest_${F}_b" -o run --output-format csv -- python3 $ARGS > /dev/null 2> "$OUT/pmc_forest_${F}_b.err" || true
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_forest_$F" -o run --output-format csv -- python3 $ARGS > "$OUT/bench_forest_$F.json" 2> "$OUT/stats_forest_$F.err" || true
+    echo "forest $F done"
+done
+for f in "$OUT"/pmc_forest_*/*counter_collection.csv "$OUT"/pmc_forest_*/*/*counter_collection.csv; do
     [ -f "$f" ] || continue
     { head -1 "$f"; grep -E 'vsc::' "$f" || true; } > "$f.small" && mv "$f.small" "$f"
 done

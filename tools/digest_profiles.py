@@ -108,6 +108,28 @@ for route in ("fused", "two-pass"):
         shutil.copy(stats[0], os.path.join(dst, "%s_c5_%s_kernel_stats.csv" % (tag, route.replace("-", "_"))))
 summary["c5_rows"] = dict(rows, note="bench.py --workload c5 --guides 20000 --rows fused | two-pass: per launch = per batch of 10 000 reads (8.2e8 ... "
                                      "1.63e9 hits); FETCH_SIZE raw (the guide's x2 not applied), averages over the launches of the run incl. warm-up")
+# the forest walk: pair nodes and the compact nodes of round 3 (one c5 batch of 10 000 reads each + a warm-up batch)
+forest = {}
+for form in ("pair", "compact"):
+    ck = {}
+    for grp in ("a", "b"):
+        ck.update(counters(os.path.join(src, "pmc_forest_%s_%s" % (form, grp), "**", "*counter_collection.csv"), "rf_predict_kernel"))
+    stats = glob.glob(os.path.join(src, "stats_forest_%s" % form, "**", "*kernel_stats.csv"), recursive=True)
+    if not ck:
+        continue
+    ms = kernel_avg_ms(stats[0], "rf_predict_kernel") if stats else None
+    busy = ck.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    forest[form] = {"counters": ck, "rocprof_avg_ms": ms,
+                    "derived": {"valu_wave_instr_per_simd_cycle": ck.get("SQ_INSTS_VALU", 0.0) / (busy * 1024) if busy else None,
+                                "lds_wave_instr_per_cu_cycle": ck.get("SQ_INSTS_LDS", 0.0) / (busy * 256) if busy else None,
+                                "lds_array_cycles_per_cu_cycle": ck.get("SQ_LDS_IDX_ACTIVE", 0.0) / (busy * 256) if busy else None,
+                                "bank_conflict_share_of_lds_cycles": ck.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(ck.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0),
+                                "valu_per_lds_instr": ck.get("SQ_INSTS_VALU", 0.0) / max(ck.get("SQ_INSTS_LDS", 1.0), 1.0)}}
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, "%s_forest_%s_kernel_stats.csv" % (tag, form)))
+if forest:
+    summary["forest"] = dict(forest, note="bench.py --workload c5 --classify --guides 10000 [--hook rf_form=1]: rf_predict_kernel<2> per launch = one batch "
+                                          "(1.63e9 rows x 1 000 trees); SQ_* summed over the chip, GRBM_GUI_ACTIVE / 8 = busy cycles")
 summary["kernel_sources_sha"] = kernel_sources_sha()
 json.dump(summary, open(os.path.join(dst, "%s_seed_pmc.json" % tag), "w"), indent=1)
 for name in ("bench_c4", "bench_c5", "bench_c5_two_pass", "bench_c5_classify", "bench_abi_c3_x1", "bench_abi_c3_x4_one_gpu", "bench_abi_c5_x2_one_gpu", "bench_default"):
