@@ -1,6 +1,6 @@
 // valu_rate.hip - measures the issue rate of the integer VALU instructions the scan kernel is made of
 // (v_xor_b32, v_bitop3_b32, v_bcnt_u32_b32, v_min3_u32) on gfx950, at 1/2/4 waves per SIMD.
-// Build: hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o gpurun_out/valu_rate
+// Build: hipcc --offload-arch=gfx950 -O3 tools/micro/valu_rate_scan.hip -o gpurun_out/valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
