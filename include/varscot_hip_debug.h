@@ -40,6 +40,10 @@ typedef struct {
 int vsc_ctx_set_debug_params(vsc_ctx *ctx, const vsc_debug_params *params);
 int vsc_ctx_get_debug_params(const vsc_ctx *ctx, vsc_debug_params *out);
 
+/* A context whose stream may only use the compute units of `cu_mask` (bit i of word i / 32 = CU i, n_words words:
+ * hipExtStreamCreateWithCUMask) - experiments with kernels of two contexts on disjoint parts of the device (tools/cu_mask_probe.py). */
+int vsc_ctx_create_masked(int device_id, const uint32_t *cu_mask, uint32_t n_words, vsc_ctx **out);
+
 /* Host-side lap times of vsc_search and vsc_windows_build on stderr (process-wide; 0 = off). */
 void vsc_debug_set_host_timing(int on);
 

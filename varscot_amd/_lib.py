@@ -163,6 +163,7 @@ DEBUG_SYMBOLS = [
     ("vsc_ctx_set_debug_params", C.c_int, [_vp, C.POINTER(DebugParams)]),
     ("vsc_ctx_get_debug_params", C.c_int, [_vp, C.POINTER(DebugParams)]),
     ("vsc_debug_set_host_timing", None, [C.c_int]),
+    ("vsc_ctx_create_masked", C.c_int, [C.c_int, _vp, C.c_uint32, C.POINTER(_vp)]),
     ("vsc_multi_create_debug", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(MultiDebugParams), C.POINTER(_vp)]),
 ]
 

@@ -106,9 +106,14 @@ class PackedGenome:
 class Context:
     """One device + one stream (vsc_ctx).  Single-threaded."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, cu_mask=None):
+        """cu_mask (experiments, include/varscot_hip_debug.h): uint32 words, bit i of word i // 32 = compute unit i may be used."""
         self._h = C.c_void_p()
-        check(lib().vsc_ctx_create(device, C.byref(self._h)))
+        if cu_mask is None:
+            check(lib().vsc_ctx_create(device, C.byref(self._h)))
+        else:
+            mask = np.ascontiguousarray(cu_mask, dtype=np.uint32)
+            check(lib().vsc_ctx_create_masked(device, mask.ctypes.data, len(mask), C.byref(self._h)))
         self.device = device
         self._children = weakref.WeakSet()  # genomes and results must go before their context
 

@@ -173,7 +173,9 @@ int vsc_device_count(void)
     return n;
 }
 
-int vsc_ctx_create(int device_id, vsc_ctx **out)
+int vsc_ctx_create(int device_id, vsc_ctx **out) { return vsc_ctx_create_masked(device_id, nullptr, 0, out); }
+
+int vsc_ctx_create_masked(int device_id, const uint32_t *cu_mask, uint32_t n_mask_words, vsc_ctx **out)
 {
     if (!out) return VSC_ERR_INVALID;
     *out = nullptr;
@@ -185,7 +187,7 @@ int vsc_ctx_create(int device_id, vsc_ctx **out)
     ctx->device = device_id;
     hipDeviceProp_t prop;
     if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess ||
-        hipStreamCreate(&ctx->stream) != hipSuccess) {
+        (cu_mask && n_mask_words ? hipExtStreamCreateWithCUMask(&ctx->stream, n_mask_words, cu_mask) : hipStreamCreate(&ctx->stream)) != hipSuccess) {
         delete ctx;
         return VSC_ERR_DEVICE;
     }
