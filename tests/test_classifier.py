@@ -124,7 +124,7 @@ def test_fused_score_classify_equals_score_then_predict(golden_dir):
     ctx.close()
 
 
-def _synthetic_forest(path, rng, n_trees, n_nodes, names, depth_first=False):
+def _synthetic_forest(path, rng, n_trees, n_nodes, names, depth_first=False, split_choices=None):
     """A random forest file (the exporter's format): random binary trees grown breadth-first (randomForest's node
     numbering: the daughters of a node are the next two free numbers) over predictors of the feature matrix, with
     splits at x.5, integer splits, a few below zero and above any value, some trees a single terminal node."""
@@ -149,7 +149,7 @@ def _synthetic_forest(path, rng, n_trees, n_nodes, names, depth_first=False):
                 if names[v] == "ontargetActivity":
                     split[t, k] = float(rng.choice([0.31, 0.5, 0.77, 1.02, 1.4]))
                 else:
-                    split[t, k] = float(rng.choice([0.5, 0.5, 0.5, 1.5, 2.5, 1.0, 3.0, -0.5, 300.0]))
+                    split[t, k] = float(rng.choice(split_choices if split_choices is not None else [0.5, 0.5, 0.5, 1.5, 2.5, 1.0, 3.0, -0.5, 300.0]))
             else:
                 status[t, k] = -1
                 cls[t, k] = int(rng.integers(1, 3))
@@ -212,6 +212,44 @@ def test_rf_predict_on_synthetic_forests(tmp_path, golden_dir, n_nodes, form):
     assert np.array_equal(votes / float(forest.n_trees), want[0])
     h.close()
     gen.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_rf_node_forms_agree_on_random_forests(tmp_path, golden_dir, seed):
+    """Random forests of random shapes through every node form the kernel has (rf_form hook: -1 the best the forest allows,
+    1 at most compact nodes, 0 plain nodes): identical votes, and the Python restatement's on a sample.  The shapes cover the
+    limits of the pair form - more than 256 distinct tests (count predictors split at 0 .. 18), more than 127 pair nodes per
+    tree (deep trees of 511 nodes) - where the library has to fall back, single-node trees and one-tree forests."""
+    from oracle.rf_oracle import Forest as OracleForest
+    rng = np.random.default_rng(1000 + seed)
+    counts = ["AA", "AC", "AG", "AT", "CA", "CC", "CG", "CT", "GA", "GC", "GG", "GT", "TA", "TC", "TG", "TT", "totalMismatches",
+              "seedMismatches", "transitionNumber", "transversionNumber", "adjacentMismatches"]
+    flags = ["mismatchPos%d" % i for i in range(1, 22)] + ["A1", "C8", "G16", "T20", "PAMA", "PAMG", "AC4", "GC16", "TT19", "AtoC", "GtoA", "TtoG"]
+    many_tests = seed % 3 == 0   # > 256 (predictor, threshold) pairs: no pair form
+    deep = seed % 3 == 1         # > 127 pair nodes per tree: no pair form
+    names = (counts if many_tests else counts[:6] + flags) + ["ontargetActivity"]
+    n_nodes = 511 if deep else 255 if many_tests else int(rng.choice([3, 9, 41, 121, 255]))
+    n_trees = 150 if many_tests else int(rng.choice([2, 7, 64, 150]))
+    path = str(tmp_path / "forest.vscrf")
+    _synthetic_forest(path, rng, n_trees, n_nodes, names,
+                      split_choices=[float(v) + float(h) for v in range(-1, 19) for h in (0.0, 0.5)] if many_tests else None)
+    g = np.load(os.path.join(golden_dir, "features_golden.npz"))
+    feats = g["feat"][seed::7].astype(np.uint8)
+    act = rng.choice([0.2, 0.31, 0.5, 0.77, 0.9, 1.02, 1.4, 1.7], size=len(feats))
+    ctx = va.Context(0)
+    votes = {}
+    for form in (-1, 1, 0):
+        ctx.set_debug(rf_form=form)
+        votes[form] = Forest(path).predict(ctx, feats, act)
+    for form in (1, 0):
+        assert all(np.array_equal(a, b) for a, b in zip(votes[-1], votes[form])), form
+    of = OracleForest(path)
+    all_names = feature_names()
+    for i in range(0, len(feats), 41):
+        p, c, ti = of.predict(dict(zip(all_names, list(feats[i]) + [act[i]])))
+        assert (votes[-1][0][i], votes[-1][1][i], bool(votes[-1][2][i])) == (p, c, ti), i
     ctx.close()
 
 
