@@ -491,21 +491,39 @@ inline void write_outputs(const std::string &out_path, const std::string *featur
     const size_t block = 16384;
     std::vector<std::string> kept;  // sorted output: the TSV text of every block
     if (opt.sort_by_name) kept.resize((n + block - 1) / block);
-    std::vector<std::string> tsv(n_threads), fm(n_threads);
-    for (size_t base = 0; base < n; base += block * n_threads) {
+    // two sets of buffers: while one round of blocks is written (in order, by one thread), the next is formatted
+    std::vector<std::string> tsv[2], fm[2];
+    for (int k = 0; k < 2; ++k) {
+        tsv[k].resize(n_threads);
+        fm[k].resize(n_threads);
+    }
+    std::thread writer;
+    struct JoinWriter {  // (an exception on the way out must not meet a running thread)
+        std::thread &t;
+        ~JoinWriter()
+        {
+            if (t.joinable()) t.join();
+        }
+    } join_writer{writer};
+    int round = 0;
+    for (size_t base = 0; base < n; base += block * n_threads, round ^= 1) {
         std::vector<std::thread> workers;
         unsigned used = 0;
         for (unsigned t = 0; t < n_threads && base + t * block < n; ++t, ++used) {
             const size_t b = base + t * block, e = std::min(n, b + block);
-            std::string &dst = opt.sort_by_name ? kept[b / block] : tsv[t];
-            workers.emplace_back(format_block, b, e, std::ref(dst), std::ref(fm[t]), (uint32_t)(b / block));
+            std::string &dst = opt.sort_by_name ? kept[b / block] : tsv[round][t];
+            workers.emplace_back(format_block, b, e, std::ref(dst), std::ref(fm[round][t]), (uint32_t)(b / block));
         }
         for (auto &w : workers) w.join();
-        for (unsigned t = 0; t < used; ++t) {
-            if (!opt.sort_by_name) out.write(tsv[t].data(), (std::streamsize)tsv[t].size());
-            if (feature_path) fout.write(fm[t].data(), (std::streamsize)fm[t].size());
-        }
+        if (writer.joinable()) writer.join();  // (the round before has left its buffers)
+        writer = std::thread([&, used, round] {
+            for (unsigned t = 0; t < used; ++t) {
+                if (!opt.sort_by_name) out.write(tsv[round][t].data(), (std::streamsize)tsv[round][t].size());
+                if (feature_path) fout.write(fm[round][t].data(), (std::streamsize)fm[round][t].size());
+            }
+        });
     }
+    if (writer.joinable()) writer.join();
     if (opt.sort_by_name) {
         // `sort -k4,4` under LC_ALL=C: the name field byte-wise, ties (there are none: names are unique) by the whole line
         std::vector<uint32_t> order(n);
