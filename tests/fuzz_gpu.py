@@ -125,6 +125,22 @@ def one(ctx, seed):
         if hits_as_tuples(got) != hits_as_tuples(want) or bad_rows:
             return "seed %d: streamed rows differ (m=%d, %d reads, batch %d, contigs %s, extra %s, hooks %s): %d vs %d records, rows of batches %s" % (
                 seed, max_mm, len(guides), batch, lens, extra, hooks, len(got), len(want), bad_rows[:4])
+    # the classifier on the hits (score -> classify fused), the reference's forest in every node form the kernel has: same votes
+    if n_rec and rng.integers(0, 3) == 0:
+        from varscot_amd.classifier import Forest
+        forest = Forest(os.path.join(ROOT, "varscot_amd", "models", "rfClassifier.vscrf"))
+        g = ctx.load_genome(packed)
+        h = g.search(guides, max_mm, extra, algorithm="seed")
+        act = rng.choice([0.2, 0.45, 0.87, 0.8885, 1.03, 1.31, 1.47, 1.61, 1.99, 2.3], size=len(guides))
+        votes = {}
+        for form in (-1, 1, 0):
+            ctx.set_debug(rf_form=form)
+            votes[form], _ = forest.classify_hits(h, act)
+        ctx.set_debug()
+        h.close()
+        g.close()
+        if not (np.array_equal(votes[-1], votes[1]) and np.array_equal(votes[-1], votes[0])):
+            return "seed %d: the forest's node forms vote differently (m=%d, %d reads, %d hits)" % (seed, max_mm, len(guides), n_rec)
     if rng.integers(0, 3) == 0:
         world = int(rng.integers(2, 6))
         m = va.MultiContext([0] * world)
