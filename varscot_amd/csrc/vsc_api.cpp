@@ -2358,11 +2358,11 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
     }
     // PAIR form (vsc_internal.h): a node of 8 bytes holds a split node AND its two daughters - two levels per LDS read.
     // Pair nodes are rooted at the split nodes on even levels; a tree's pair nodes lie in breadth-first order (every exit
-    // leads forward), the trees back to back at a stride of `pair_stride` nodes.  For forests of at most 256 tests and 127
+    // leads forward), the trees back to back at a stride of `pair_stride` nodes.  For forests of at most 232 tests and 127
     // pair nodes per tree (rfClassifier: 217 and 70).
     std::vector<uint64_t> pairs;
     uint32_t pair_stride = 0;
-    if (compact && want_form != 1 && tests.size() <= 256) {
+    if (compact && want_form != 1 && tests.size() <= (size_t)kRfPairMaxTests) {
         auto split = [&](uint32_t tr, uint32_t k) { return model->node_status[(size_t)tr * model->n_nodes + k] == 1; };
         std::vector<std::vector<uint32_t>> roots(model->n_trees);  // per tree: the split nodes that root a pair node, in order
         std::vector<uint32_t> index_in(model->n_nodes);
@@ -2417,10 +2417,14 @@ int prepare_forest(vsc_ctx *ctx, const vsc_rf_model *model, const char *who)
                     }
                     // a test in the upper word: its bit in the row's test word at bits s .. s + 4, the word's number at s + 10 ..
                     // s + 12 (s = 0 root, 5 right daughter, 18 left daughter: rf_predict_kernel masks the word number in place)
-                    auto field = [](uint32_t test, uint32_t s) { return (uint64_t)((test & 31u) | (test >> 5) << 10) << s; };
+                    // (test i: word i / 29, bit 3 + i % 29; the root's field holds the bit's position, a daughter's the position - 3)
+                    const uint32_t per = 32u - (uint32_t)kRfPairFirstBit;
+                    auto field = [&](uint32_t test, uint32_t s, bool root) {
+                        return (uint64_t)((test % per + (root ? (uint32_t)kRfPairFirstBit : 0u)) | (test / per) << 10) << s;
+                    };
                     uint64_t w = 0;
                     for (int e = 0; e < 4; ++e) w |= (uint64_t)ex[e] << (8 * e);
-                    w |= (field(t_root, 0) | field(t_right, 5) | field(t_left, 18)) << 32;
+                    w |= (field(t_root, 0, true) | field(t_right, 5, false) | field(t_left, 18, false)) << 32;
                     pairs[(size_t)tr * pair_stride + j] = w;
                 }
             }

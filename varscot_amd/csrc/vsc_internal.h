@@ -255,6 +255,8 @@ constexpr int kRfRows = 512;             // feature rows per workgroup (one thre
 constexpr int kRfMaxTests = 1024;        // distinct (predictor, threshold) pairs a forest may use
 constexpr int kRfMaxNodes = 1024;        // nodes of one tree (rfClassifier: 275)
 constexpr int kRfTileBytes = 26624;      // whole trees staged in LDS per step (with 14 KB of test bits: 4 workgroups = 32 waves per CU)
+constexpr int kRfPairFirstBit = 3;       // pair form: test bits lie at positions 3 .. 31 of their words (29 per word) ...
+constexpr int kRfPairMaxTests = 8 * (32 - kRfPairFirstBit);  // ... of which a row has eight: 232 tests
 constexpr int kRfPairBitsBytes = 16384;  // pair form: the test bits as two planes of 256 rows x 8 words
 constexpr int kRfPairTileBytes = 24512;  // ... and its tree tile (16 + 24 KB: four workgroups per CU)
 constexpr int kRfChains = 2;             // trees a thread walks at the same time (compact form)

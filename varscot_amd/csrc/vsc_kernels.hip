@@ -880,6 +880,9 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
     const bool pairs = a.compact == 2u;
     static_assert(kRfRows == 512 && kRfPairBitsBytes == (kRfRows / 256) * 8192, "pair form: two planes of 256 rows, 8 KB each");
     const uint32_t bits_stride = pairs ? 256u : (uint32_t)kRfRows, bits_base = pairs ? (t >> 8) * 2048u + (t & 255u) : t;
+    // test i's bit: word i / 32, bit i % 32 - pair form: word i / 29, bit 3 + i % 29 (the walk takes a daughter's bit with one
+    // shift to bit 3, where it is worth 8, half of the exit byte's shift: kRfPairFirstBit)
+    const uint32_t first_pos = pairs ? (uint32_t)kRfPairFirstBit : 0u;
     uint32_t *const s_bits = s_dyn;
     uint32_t *const s_tile = s_dyn + (pairs ? (size_t)kRfPairBitsBytes / sizeof(uint32_t) : (size_t)n_words * kRfRows);
     const uint64_t row = (uint64_t)blockIdx.x * kRfRows + t;
@@ -887,15 +890,18 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
     if (kMode == 0) {
         // dense rows (the command-line tool's path): one byte load per test
         const uint32_t rank = live ? a.act_rank[row] : 0u;
-        for (uint32_t wd = 0; wd < n_words; ++wd) {
-            uint32_t bits = 0;
-            for (uint32_t i = wd * 32u; i < min(a.n_tests, wd * 32u + 32u); ++i) {
-                const RfTest ts = a.tests[i];
-                const uint32_t x = !live ? 0u : (ts.dense_col == VSC_N_FEATURES ? rank : a.dense[row * VSC_N_FEATURES + ts.dense_col]);
-                bits |= (x <= ts.thr ? 1u : 0u) << (i & 31u);
+        uint32_t bits = 0, wd = 0, pos = first_pos;
+        for (uint32_t i = 0; i < a.n_tests; ++i) {
+            const RfTest ts = a.tests[i];
+            const uint32_t x = !live ? 0u : (ts.dense_col == VSC_N_FEATURES ? rank : a.dense[row * VSC_N_FEATURES + ts.dense_col]);
+            bits |= (x <= ts.thr ? 1u : 0u) << pos;
+            if (++pos == 32u) {
+                s_bits[wd++ * bits_stride + bits_base] = bits;
+                bits = 0;
+                pos = first_pos;
             }
-            s_bits[wd * bits_stride + bits_base] = bits;
         }
+        if (pos != first_pos) s_bits[wd * bits_stride + bits_base] = bits;
     } else {
         uint32_t w[16] = {};
         uint32_t rank = 0;
@@ -926,7 +932,7 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
         rf_row_words(w, rank, r);
         // the tests are sorted by the row word they read: a compile-time loop over the words (registers), a wave-uniform
         // loop over each word's tests (scalar loads), the bits collected in test order
-        uint32_t bits = 0, i = 0;
+        uint32_t bits = 0, i = 0, wd = 0, pos = first_pos;  // (all four wave-uniform: scalar registers)
 #pragma unroll
         for (int k = 0; k < kRfRowWords; ++k) {
             const uint32_t rk = r[k];
@@ -934,14 +940,15 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
             for (; i < end; ++i) {
                 const RfTest ts = a.tests[i];
                 const uint32_t x = (rk >> ts.shift) & ((1u << ts.width) - 1u);
-                bits |= (x <= ts.thr ? 1u : 0u) << (i & 31u);
-                if ((i & 31u) == 31u) {
-                    s_bits[(i >> 5) * bits_stride + bits_base] = bits;
+                bits |= (x <= ts.thr ? 1u : 0u) << pos;
+                if (++pos == 32u) {
+                    s_bits[wd++ * bits_stride + bits_base] = bits;
                     bits = 0;
+                    pos = first_pos;
                 }
             }
         }
-        if (a.n_tests & 31u) s_bits[(a.n_tests >> 5) * bits_stride + bits_base] = bits;
+        if (pos != first_pos) s_bits[wd * bits_stride + bits_base] = bits;
     }
     // this workgroup's share of the trees
     const uint32_t per_split = (a.n_trees + a.tree_splits - 1) / a.tree_splits;
@@ -985,16 +992,19 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
             // PAIR nodes: the per-lane tree queues of the compact form below, two levels per step.  A node of 8 bytes holds a
             // split node's test, both daughters' tests and the four exits (granddaughters): one 8-byte LDS read - a random
             // ds_read_b64 of a wave costs what a random ds_read_b32 costs, 64 banks of pairs against 32 - and two reads of the
-            // row's test words (conflict-free) per TWO levels, instead of two and two: 11 LDS cycles instead of 18.  That leaves
+            // row's test words (conflict-free) per TWO levels, instead of two and two.  That leaves
             // the vector unit as the bound (tools/micro/valu_kinds.hip: 2.4 cycles per SIMD for the two-operand shifts / and / add,
             // 2.7 for v_bitop3, 4.2 for every other three-operand form), so the node is laid out for few and cheap instructions:
             //   lower word: exit[2 * root bit + daughter bit], a byte each: vote | pair nodes to skip << 1
             //   upper word: three tests, each as (bit in the row's test word: 5 bits at s, number of the word: 3 bits at s + 10),
             //   s = 0 root, 5 right daughter, 18 left daughter (bit set = x <= thr = left).  A test word's address is the upper
-            //   word (shifted by s) masked IN PLACE, OR-ed into the lane's base - one v_bitop3; the bit comes out as a mask
+            //   word (shifted by s) masked IN PLACE, OR-ed into the lane's base - one v_bitop3; the root's bit comes out as a mask
             //   (v_bfe_i32, which takes its offset from the low five bits of the same register) that selects the daughter's test
-            //   and the exit byte's shift.  A terminal daughter: both its exits carry its vote to the next tree's root.
-            //   All zero = the sink (a real node has no zero exit).
+            //   and half of the exit byte's shift; the daughter's bit is shifted to bit 3, where it is the other half (its field
+            //   holds the position - 3: test bits lie at positions 3 .. 31 of their words).  (Taking the root's bit by a shift as
+            //   well needs the daughters' fields 16 bits apart and a third beside them: no arrangement of three (5 + 3)-bit fields
+            //   with the word number a fixed distance above the shift fits 32 bits.)  A terminal daughter: both its exits carry
+            //   its vote to the next tree's root.  All zero = the sink (a real node has no zero exit).
             typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
             typedef uint32_t v2u __attribute__((ext_vector_type(2)));
             typedef const __attribute__((address_space(3))) v2u *lds_u64;
@@ -1014,24 +1024,25 @@ template <int kMode> __global__ __launch_bounds__(kRfRows) void rf_predict_kerne
                 n[c] = *(lds_u64)(uintptr_t)at[c];
                 any |= n[c].x;
             }
-            while (__ballot(any != 0u)) {
+            while (__ballot(any != 0u)) {  // (two steps per chain between the exit tests: a finished chain spins on its sink)
                 any = 0;
 #pragma unroll
-                for (int c = 0; c < kRfChains; ++c) {
+                for (int c2 = 0; c2 < 2 * kRfChains; ++c2) {
+                    const int c = c2 % kRfChains;
                     const uint32_t hi = n[c].y;
                     const uint32_t w_root = *(lds_u32)(uintptr_t)__builtin_amdgcn_bitop3_b32(hi, k_word, bits_at, 0xEA);  // (hi & k) | base
                     const uint32_t m_root = (uint32_t)__builtin_amdgcn_sbfe((int)w_root, hi, 1u);                          // all ones: left
                     const uint32_t next = __builtin_amdgcn_bitop3_b32(m_root, hi >> 18, hi >> 5, 0xCA);                    // m ? left : right
                     const uint32_t w_next = *(lds_u32)(uintptr_t)__builtin_amdgcn_bitop3_b32(next, k_word, bits_at, 0xEA);
-                    const uint32_t m_next = (uint32_t)__builtin_amdgcn_sbfe((int)w_next, next, 1u);
-                    const uint32_t d = n[c].x >> __builtin_amdgcn_bitop3_b32(m_root, k_16, m_next & 8u, 0xEA);            // exit byte 2 r + d
+                    // (a daughter's field holds its bit's position - 3: one shift puts the bit where it is worth 8)
+                    const uint32_t d = n[c].x >> __builtin_amdgcn_bitop3_b32(m_root, k_16, (w_next >> (next & 31u)) & 8u, 0xEA);  // exit byte 2 r + d
                     uint32_t vote, skip;  // (opaque: the compiler would extract the vote from the node word with a v_bfe_u32, 4.2 cycles against 2.4)
                     asm("v_and_b32 %0, 1, %1" : "=v"(vote) : "v"(d));
                     asm("v_and_b32 %0, 0xfe, %1" : "=v"(skip) : "v"(d));
                     ones += vote;
                     at[c] += skip << 2;
                     n[c] = *(lds_u64)(uintptr_t)at[c];
-                    any |= n[c].x;
+                    if (c2 >= kRfChains) any |= n[c].x;
                 }
             }
             continue;
@@ -1113,7 +1124,7 @@ hipError_t launch_rf_predict(const RfArgs &args, hipStream_t stream)
 {
     if (args.n == 0) return hipSuccess;
     if (args.n_tests > (uint32_t)kRfMaxTests || args.n_tests == 0 || args.n_nodes > (uint32_t)kRfMaxNodes || args.n_nodes == 0 ||
-        (args.compact == 2u ? (size_t)args.n_nodes * sizeof(uint2) > (size_t)kRfPairTileBytes || args.n_tests > 256u || args.n_nodes > 127u
+        (args.compact == 2u ? (size_t)args.n_nodes * sizeof(uint2) > (size_t)kRfPairTileBytes || args.n_tests > (uint32_t)kRfPairMaxTests || args.n_nodes > 127u
                             : (size_t)args.n_nodes * sizeof(uint32_t) > (size_t)kRfTileBytes))
         return hipErrorInvalidValue;
     const uint64_t tiles = (args.n + kRfRows - 1) / kRfRows;
