@@ -52,6 +52,10 @@ VALU_ISSUE_CYCLES = {"vector_operands": 2.6, "scalar_operand": 4.2}
 KERNEL_SOURCES = ("vsc_seed.hip", "vsc_kernels.hip", "vsc_sort.hip", "vsc_device.h", "vsc_internal.h")
 
 
+# pair-node forest walk: 15.2 vector instructions per step (2 levels), ~40 SIMD-cycles at the costs of tools/micro/valu_kinds.hip
+FOREST_CYCLES_PER_INSTRUCTION = 2.6
+
+
 def kernel_sources_sha():
     """What the committed counters under profiles/ are keyed by: a hash of the kernels' sources.  A lookup made with other
     kernels than the ones that were profiled prints null instead of a stale number."""
@@ -733,10 +737,28 @@ def main():
                                 "8 B record + 4 B side word read, 16 B vsc_hit + 64 B packed feature row written per hit (record and side word "
                                 "a second time from L2)" if rows_fused else "8 B record read + 16 B vsc_hit written per hit")]
         if streamed and not rows_fused:
+            extra = {}
+            if forest is not None:
+                # the forest walk is bound by vector-instruction issue: the committed counters of the kernel (same
+                # sources, else null) x the cost of its instruction mix (tools/micro/valu_kinds.hip: 16 instructions, 40 SIMD-cycles)
+                fc = None
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("_kernel_sources_sha") == kernel_sources_sha():
+                        fc = tj.get("c5/forest:counters")
+                except Exception:
+                    fc = None
+                extra["valu"] = {"issue": None if not fc else {
+                    "valu_per_simd_cycle": fc["valu_per_simd_cycle"], "cycles_per_instruction_of_the_mix": FOREST_CYCLES_PER_INSTRUCTION,
+                    "frac": fc["valu_per_simd_cycle"] * FOREST_CYCLES_PER_INSTRUCTION,
+                    "lds_array_cycles_per_cu_cycle": fc["lds_array_cycles_per_cu_cycle"],
+                    "source": "SQ_INSTS_VALU, SQ_LDS_IDX_ACTIVE / GRBM_GUI_ACTIVE of profiles/*_seed_pmc.json (forest) x the issue costs of "
+                              "profiles/r04_valu_kinds_microbench.txt"}}
             kernels.append(kernel_entry("rf_predict_kernel<fused>" if forest is not None else "score_packed_kernel", score_ms,
                                         (18.0 if forest is not None else 80.0) * hits_local,
-                                        "16 B vsc_hit read + 2 B of votes written per hit (the forest walk is LDS-bound, DESIGN.md 4.6)"
-                                        if forest is not None else "16 B vsc_hit read + 64 B packed row written per hit"))
+                                        "16 B vsc_hit read + 2 B of votes written per hit (the forest walk is bound by vector-instruction issue, "
+                                        "not memory: valu.issue; DESIGN.md 4.6)"
+                                        if forest is not None else "16 B vsc_hit read + 64 B packed row written per hit", **extra))
         whole = survey_bytes / (ms_per_step * 1e-3) / 1e9
         dominant = max(kernels, key=lambda k: k["ms"] or 0.0)
         out = {

@@ -136,6 +136,11 @@ for name in ("bench_c4", "bench_c5", "bench_c5_two_pass", "bench_c5_classify", "
     path = os.path.join(src, name + ".json")
     if os.path.exists(path) and os.path.getsize(path):
         shutil.copy(path, os.path.join(dst, "%s_%s.json" % (tag, name)))
+if forest.get("pair"):
+    fp = forest["pair"]
+    traffic["c5/forest:counters"] = {"valu_per_simd_cycle": fp["derived"]["valu_wave_instr_per_simd_cycle"],
+                                     "lds_array_cycles_per_cu_cycle": fp["derived"]["lds_array_cycles_per_cu_cycle"],
+                                     "valu_per_lds_instr": fp["derived"]["valu_per_lds_instr"], "rocprof_avg_ms": fp["rocprof_avg_ms"]}
 traffic["_kernel_sources_sha"] = kernel_sources_sha()
 traffic["_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh, digested into profiles/%s_seed_pmc.json (FETCH_SIZE x 2 + WRITE_SIZE per launch of the search kernel)" % tag
 json.dump(traffic, open(traffic_path, "w"))
