@@ -684,10 +684,14 @@ def main():
             structure_model = "planes streamed once per pass (0.375 B/base) + 12 B per hit written + 8 B per read"
         else:
             kernel, ops_per_compare = "seed_sliced_kernel", LANE_OPS_PER_COMPARE["sliced"]
-            k_seg = max_mm // 3
-            list_entries = n_guides * 3 * (1, 22, 211)[k_seg]
+            # read-list entries (SeedPlan, vsc_internal.h): segments 0 and 1 within k01 substitutions, one entry for all PAM
+            # classes; segment 2 per class within what the class leaves - the synthetic reads end in GG: GG sites leave
+            # max_mm, GA sites max_mm - 1
+            nbr = lambda k: 0 if k < 0 else (1, 22, 211)[k]
+            k01 = (max_mm - 1) // 3 if max_mm else 0
+            list_entries = n_guides * (2 * nbr(k01) + nbr(max_mm - 2 * k01 - 2) + nbr(max_mm - 1 - 2 * k01 - 2))
             structure_bytes = float(stream_bytes) + 16.0 * list_entries + 16.0 * hits_local
-            structure_model = ("bit-sliced sites of the visited buckets (4 B each, read once) + read-list entries (16 B each) + "
+            structure_model = ("bit-sliced sites of the visited buckets (3.5 B each, read once) + read-list entries (16 B each) + "
                                "per hit one 8 B site record read and one 8 B record written")
         compares = float(pairs_local)
         lane_ops = compares * ops_per_compare / (scan_avg_ms * 1e-3)

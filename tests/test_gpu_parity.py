@@ -81,17 +81,17 @@ def test_seed_search_with_a_chunk_per_wave_and_per_workgroup(ctx, oracle, hooks,
     assert got.tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("pam21", [-1, 0])
+@pytest.mark.parametrize("tight", [-1, 0])
 @pytest.mark.parametrize("shared", [0, 1])
 @pytest.mark.parametrize("seed,max_mm,extra_pam", [(301, 8, None), (302, 5, None), (303, 1, None), (304, 0, None),
-                                                   (305, 6, "GT"), (306, 6, "AG")])
-def test_seed_search_reads_that_mismatch_the_first_pam_letter(ctx, oracle, hooks, pam21, shared, seed, max_mm, extra_pam):
-    """Every site of an index built for GG / GA (or with an extra PAM that also starts with G) has G at read position 21,
-    so the sliced comparison leaves that position out and takes the read's mismatch there from its budget
-    (sliced_within<true>).  Reads with A, C, T and G at position 21 (and any letter at 22), sites planted at every
-    distance up to the limit: the records are the oracle's, with the shortcut (default), without it (hook) and for an
-    index whose extra PAM starts with another letter (the general comparison by itself)."""
-    hooks(seed_shared=shared, seed_pam21=pam21)
+                                                   (305, 6, "GT"), (306, 6, "AG"), (327, 7, "GA"), (308, 4, "TT"), (309, 3, None), (310, 2, "CG"), (311, 6, None), (312, 5, "GA")])
+def test_seed_search_reads_that_mismatch_the_pam(ctx, oracle, hooks, tight, shared, seed, max_mm, extra_pam):
+    """A chunk of the seed index holds sites of ONE PAM (its class), so the sliced comparison leaves read positions 21
+    and 22 out: the read's mismatches with the class's PAM are taken from the budget of its list entries, and the third
+    segment's neighbourhood follows what is left (SeedPlan).  Reads with every letter at positions 21 and 22, sites
+    planted at every distance up to the limit, indexes with an extra PAM: the records are the oracle's, with the tight
+    cut (default) and with floor(m / 3) in all three segments (hook)."""
+    hooks(seed_shared=shared, seed_tight=tight)
     rng = np.random.default_rng(seed)
     guides = [random_seq(rng, 21) + p for p in ("AG", "CG", "TG", "GG", "GA", "AA", "TC", "CT", "GT", "AG", "GG", "TA") for _ in range(6)]
     contigs = make_genome(seed, [60000, 23, 25000, 64], guides[::3], max_mm, n_plant=500, n_runs=4)

@@ -70,9 +70,9 @@ class DebugParams(C.Structure):
                 ("sort_max_bits", C.c_uint32), ("sort_xcd", C.c_int32), ("sort_debug", C.c_uint32),
                 ("sort_optimistic", C.c_int32), ("sort_slot_cap", C.c_uint32), ("score_chunk", C.c_uint64),
                 ("score_slices", C.c_int32), ("score_slice_shift", C.c_uint32), ("seed_shared", C.c_int32),
-                ("seed_group_out", C.c_int32), ("seed_pam21", C.c_int32), ("rf_form", C.c_int32),
+                ("seed_group_out", C.c_int32), ("seed_tight", C.c_int32), ("rf_form", C.c_int32),
                 ("reserved", C.c_uint32 * 1)]
-    SIGNED_DEFAULT = ("sort_xcd", "sort_optimistic", "score_slices", "seed_shared", "seed_group_out", "seed_pam21", "rf_form")
+    SIGNED_DEFAULT = ("sort_xcd", "sort_optimistic", "score_slices", "seed_shared", "seed_group_out", "seed_tight", "rf_form")
 
     @classmethod
     def defaults(cls):

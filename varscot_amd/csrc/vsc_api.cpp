@@ -401,6 +401,15 @@ void fill_pam(ScanArgs &a, const vsc_search_params *params)
     }
 }
 
+// the PAM set as the seed index numbers it: class c = PAM c, (first letter << 2 | second letter) << 4 c
+uint32_t pam_code_set(const ScanArgs &a)
+{
+    uint32_t codes = 0;
+    for (uint32_t c = 0; c < a.n_pam; ++c)
+        codes |= ((((a.pam[c].ah & 2u) | (a.pam[c].al & 1u)) << 2) | (a.pam[c].bh & 2u) | (a.pam[c].bl & 1u)) << (4 * c);
+    return codes;
+}
+
 void fill_genome(ScanArgs &a, const vsc_ctx *ctx, const vsc_genome *genome)
 {
     a.hi = genome->d_hi;
@@ -476,7 +485,9 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         if (e == hipSuccess) e = r;
     };
     HostTimer ht;
-    constexpr uint32_t kKeys = 2 * kBuckets;  // (bucket, strand) pairs: inside a bucket '+' sites precede '-' sites
+    constexpr uint32_t kKeys = 8 * kBuckets;  // (bucket, class, strand) triples: inside a bucket the sites lie class by class (four
+                                              // slots, kSeedClasses in use), inside a class '+' sites precede '-' sites
+    const uint32_t pam_codes = pam_code_set(a);
     // Allocations follow the phases, so that the peak stays at 84 bytes per site:
     //   extract   sx, sl, sp (12 B/site) -> rec16 (16)                          then sx, sl, sp go
     //   order     rec16 (16) + two buffers of sort records (16: the context's pooled keys_a / keys_b, which the searches use
@@ -503,11 +514,11 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
     ht.lap("index: emit pass");
     // ---- the three tables: the sites ordered by (bucket of the table's segment, strand) -----------------------------------
     // A counting sort in the shape of the memory system, by the bin sort's own partition kernels (vsc_sort.hip; rounds 1-3
-    // used rocPRIM's radix sort here): one 8-byte record (key << 32 | site index) per site, level 1 on the top 8 of the 15
-    // key bits, level 2 on the other 7 inside every level-1 bin (256 segments) - each level one read and one write of the
-    // records, a tile's records of a bin leaving as one contiguous piece.  The order inside a (bucket, strand) group is
+    // used rocPRIM's radix sort here): one 8-byte record (key << 32 | site index) per site, level 1 on the top 8 of the 17
+    // key bits, level 2 on the other 9 inside every level-1 bin (256 segments) - each level one read and one write of the
+    // records, a tile's records of a bin leaving as one contiguous piece.  The order inside a (bucket, class, strand) group is
     // whatever the tiles' reservations give: nothing depends on it.  The level-2 histogram IS the table of group starts.
-    constexpr unsigned kKeyBits = 2 * kSegBases + 1, kBits1 = 8, kBits2 = kKeyBits - kBits1;
+    constexpr unsigned kKeyBits = 2 * kSegBases + 3, kBits1 = 8, kBits2 = kKeyBits - kBits1;
     constexpr uint32_t kBins1 = 1u << kBits1, kBins2 = 1u << kBits2;
     step(ctx->keys_a.ensure(std::max<uint64_t>(S, 1) * sizeof(uint64_t)));
     step(ctx->keys_b.ensure(std::max<uint64_t>(S, 1) * sizeof(uint64_t)));
@@ -516,14 +527,14 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
     const size_t seg_bytes = (kBins1 * sizeof(SortSeg) + 255) / 256 * 256;
     step(ctx->sort_segs.ensure(seg_bytes + (kBins1 + 1) * sizeof(uint32_t)));
     uint4 *const sites16 = (uint4 *)full.p;
-    std::vector<uint32_t> bs(kKeys + 1, 0);  // bs[2 b + strand] = first site of bucket b on that strand (over all three tables)
+    std::vector<uint32_t> bs(kKeys + 1, 0);  // bs[8 b + 2 class + strand] = first site of that group (over all three tables)
     ht.lap("index: order buffers");
     for (int s = 0; s < kSegments && e == hipSuccess && S > 0; ++s) {
         uint64_t *ra = (uint64_t *)ctx->keys_a.p, *rb = (uint64_t *)ctx->keys_b.p;
         SortSeg *d_segs = (SortSeg *)ctx->sort_segs.p;
         uint32_t *d_tile0 = (uint32_t *)((char *)ctx->sort_segs.p + seg_bytes);
         uint32_t *tabs = (uint32_t *)ctx->sort_tabs.p;
-        step(launch_seed_keys((const uint4 *)rec16.p, S, s, ra, st));
+        step(launch_seed_keys((const uint4 *)rec16.p, S, s, pam_codes, a.n_pam, ra, st));
         // level 1: one segment, 256 bins
         std::vector<SortSeg> &segs = ctx->host_segs;
         std::vector<uint32_t> &tile0 = ctx->host_tile0;
@@ -553,7 +564,7 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         step(hipMemcpyAsync(h1.data(), l1.hist, kBins1 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         step(hipStreamSynchronize(st));
         if (e != hipSuccess) break;
-        // level 2: every level-1 bin is a segment of its own, 128 bins each
+        // level 2: every level-1 bin is a segment of its own, 512 bins each
         segs.assign(kBins1, SortSeg{});
         tile0.assign(kBins1 + 1, 0);
         uint64_t at = 0, t2 = 0;
@@ -588,9 +599,9 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         step(hipMemcpyAsync(h2.data(), l2.hist, h2.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         step(hipStreamSynchronize(st));  // (the host tables of this table's levels go out of use here)
         if (e != hipSuccess) break;
-        uint64_t run = (uint64_t)s * S;  // key = level-1 bin << 7 | level-2 bin: the groups lie in key order
+        uint64_t run = (uint64_t)s * S;  // key = level-1 bin << 9 | level-2 bin: the groups lie in key order
         for (size_t k = 0; k < h2.size(); ++k) {
-            bs[(size_t)s * 2 * kBucketsPerSeg + k] = (uint32_t)run;
+            bs[(size_t)s * 8 * kBucketsPerSeg + k] = (uint32_t)run;
             run += h2[k];
         }
         if (run != (uint64_t)(s + 1) * S) {
@@ -614,28 +625,31 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         return e;
     }
     ht.lap("index: site records");
-    // chunks: at most kSlicedChunk sites of one bucket each; the sites of a chunk also exist bit-sliced, in
-    // blocks of 32, from block `vfirst` on.  Word z: bucket | rank in the chunk of its first '-' site << 16
+    // chunks: at most kSlicedChunk sites of one bucket and class each; the sites of a chunk also exist bit-sliced, in
+    // blocks of 32, from block `vfirst` on.  Word z: bucket | rank in the chunk of its first '-' site << 16 | class << 29
     // (| edge flag << 28, set on the device below)
     const uint64_t chunk_sites = kSlicedChunk;
     std::vector<uint32_t> ctab;  // {first site, site count, z, first vertical block} per chunk
-    ctab.reserve(4 * (3 * S / chunk_sites + kBuckets));
+    ctab.reserve(4 * (3 * S / chunk_sites + (size_t)kSeedClasses * kBuckets));
     uint64_t n_blocks = 0;
     for (uint32_t b = 0; b < (uint32_t)kBuckets; ++b) {
-        const uint64_t minus = bs[2 * b + 1];
-        for (uint64_t p = bs[2 * b]; p < bs[2 * b + 2]; p += chunk_sites) {
-            const uint64_t count = std::min<uint64_t>(chunk_sites, bs[2 * b + 2] - p);
-            const uint64_t minus_from = minus <= p ? 0 : std::min<uint64_t>(minus - p, count);
-            ctab.push_back((uint32_t)p);
-            ctab.push_back((uint32_t)count);
-            ctab.push_back(b | (uint32_t)(minus_from << kChunkMinusShift));
-            ctab.push_back((uint32_t)n_blocks);
-            n_blocks += (count + kSlicedSites - 1) / kSlicedSites;
+        for (uint32_t c = 0; c < 4; ++c) {
+            const size_t k = 8 * (size_t)b + 2 * c;
+            const uint64_t minus = bs[k + 1];
+            for (uint64_t p = bs[k]; p < bs[k + 2]; p += chunk_sites) {
+                const uint64_t count = std::min<uint64_t>(chunk_sites, bs[k + 2] - p);
+                const uint64_t minus_from = minus <= p ? 0 : std::min<uint64_t>(minus - p, count);
+                ctab.push_back((uint32_t)p);
+                ctab.push_back((uint32_t)count);
+                ctab.push_back(b | (uint32_t)(minus_from << kChunkMinusShift) | (c << kChunkClassShift));
+                ctab.push_back((uint32_t)n_blocks);
+                n_blocks += (count + kSlicedSites - 1) / kSlicedSites;
+            }
         }
     }
     g->ix_chunks = (uint32_t)(ctab.size() / 4);
     const size_t cb = std::max<size_t>(ctab.size(), 4) * sizeof(uint32_t);
-    const size_t vb = std::max<uint64_t>(n_blocks, 1) * 2 * kRestBases * sizeof(uint32_t);
+    const size_t vb = std::max<uint64_t>(n_blocks, 1) * kVertWords * sizeof(uint32_t);
     step(hipMalloc((void **)&g->d_ix_chunk_tab, cb));
     if (e == hipSuccess && !ctab.empty())
         step(hipMemcpyAsync(g->d_ix_chunk_tab, ctab.data(), ctab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -678,7 +692,8 @@ struct IndexFileHeader {
     uint32_t chunks, n_contigs;
     uint8_t has_extra_pam;
     char extra_pam[2];
-    uint8_t pad[5];
+    uint8_t layout;  // kIndexLayout
+    uint8_t pad[4];
 };
 static_assert(sizeof(IndexFileHeader) == 80, "index file header layout");
 constexpr char kIndexMagic[8] = {'V', 'S', 'C', 'S', 'E', 'E', 'D', 0};
@@ -718,18 +733,19 @@ hipError_t genome_fingerprint(vsc_ctx *ctx, const vsc_genome *g, uint64_t *out)
 // happens to match its header must not become out-of-bounds device reads.
 bool chunk_table_ok(const std::vector<uint32_t> &ctab, uint64_t S, uint64_t vert_bytes, std::string *why)
 {
-    const uint64_t n_blocks = vert_bytes / (2 * kRestBases * sizeof(uint32_t));
+    const uint64_t n_blocks = vert_bytes / (kVertWords * sizeof(uint32_t));
     uint64_t expect_site = 0, expect_block = 0;
-    uint32_t last_bucket = 0;
+    uint32_t last_group = 0;  // bucket << 2 | class: the chunks lie in this order
     for (size_t c = 0; c * 4 < ctab.size(); ++c) {
         const uint64_t first = ctab[4 * c], count = ctab[4 * c + 1], vfirst = ctab[4 * c + 3];
         const uint32_t z = ctab[4 * c + 2], bucket = z & kChunkBucketMask, minus_from = (z >> kChunkMinusShift) & 0xFFFu;
+        const uint32_t cls = z >> kChunkClassShift;
         const uint64_t blocks = (count + kSlicedSites - 1) / kSlicedSites;
         const char *bad = nullptr;
         if (count == 0 || count > (uint64_t)kSlicedChunk) bad = "site count";
         else if (first != expect_site || first + count > 3 * S) bad = "first site";
         else if (vfirst != expect_block || vfirst + blocks > n_blocks) bad = "first block";
-        else if (bucket >= (uint32_t)kBuckets || bucket < last_bucket) bad = "bucket";
+        else if (bucket >= (uint32_t)kBuckets || cls >= (uint32_t)kSeedClasses || (bucket << 2 | cls) < last_group) bad = "bucket";
         else if (minus_from > count) bad = "strand boundary";
         if (bad) {
             *why = "chunk " + std::to_string(c) + ": bad " + bad;
@@ -737,7 +753,7 @@ bool chunk_table_ok(const std::vector<uint32_t> &ctab, uint64_t S, uint64_t vert
         }
         expect_site = first + count;
         expect_block = vfirst + blocks;
-        last_bucket = bucket;
+        last_group = bucket << 2 | cls;
     }
     if (expect_site != 3 * S) {
         *why = "the chunks do not cover the site table";
@@ -800,6 +816,7 @@ int vsc_genome_index_save(vsc_ctx *ctx, const vsc_genome *genome, const char *pa
     h.seg_bases = kSegBases;
     h.sliced_chunk = kSlicedChunk;
     h.sliced_sites = kSlicedSites;
+    h.layout = (uint8_t)kIndexLayout;
     h.sites = genome->index_sites;
     h.own_words = genome->own_words;
     h.vert_bytes = genome->ix_vert_bytes;
@@ -838,14 +855,14 @@ int vsc_genome_index_load(vsc_ctx *ctx, vsc_genome *genome, const char *path)
     if (std::fread(&h, sizeof h, 1, fc.f) != 1 || std::memcmp(h.magic, kIndexMagic, sizeof h.magic) != 0)
         return fail(ctx, VSC_ERR_INVALID, (std::string("vsc_genome_index_load: ") + path + " is not a seed index file").c_str());
     if (h.abi != VSC_ABI_VERSION || h.seg_bases != (uint32_t)kSegBases || h.sliced_chunk != (uint32_t)kSlicedChunk ||
-        h.sliced_sites != (uint32_t)kSlicedSites)
+        h.sliced_sites != (uint32_t)kSlicedSites || h.layout != (uint8_t)kIndexLayout)
         return fail(ctx, VSC_ERR_INVALID, "vsc_genome_index_load: the file was written by another version of the library");
     uint64_t fp = 0;
     VSC_HIP(ctx, genome_fingerprint(ctx, genome, &fp));
     if (h.own_words != genome->own_words || h.n_contigs != genome->n_contigs || h.fingerprint != fp)
         return fail(ctx, VSC_ERR_INVALID, "vsc_genome_index_load: the file belongs to another genome");
     const uint64_t S = h.sites;
-    if (3 * S >= (1ull << 32) || h.edge_words != (3 * S + 31) / 32 + 1 || h.vert_bytes % (2 * kRestBases * sizeof(uint32_t)) != 0)
+    if (3 * S >= (1ull << 32) || h.edge_words != (3 * S + 31) / 32 + 1 || h.vert_bytes % (kVertWords * sizeof(uint32_t)) != 0)
         return fail(ctx, VSC_ERR_INVALID, "vsc_genome_index_load: inconsistent header");
     {
         // the arrays the header announces must be what the file holds (a cut or padded file is refused before
@@ -864,7 +881,7 @@ int vsc_genome_index_load(vsc_ctx *ctx, vsc_genome *genome, const char *path)
         if (e == hipSuccess) e = r;
     };
     const uint64_t sb = std::max<uint64_t>(3 * S, 1) * sizeof(uint2), eb = h.edge_words * sizeof(uint32_t);
-    const uint64_t cb = std::max<uint64_t>(h.chunks, 1) * sizeof(uint4), vb = std::max<uint64_t>(h.vert_bytes, 2 * kRestBases * sizeof(uint32_t));
+    const uint64_t cb = std::max<uint64_t>(h.chunks, 1) * sizeof(uint4), vb = std::max<uint64_t>(h.vert_bytes, kVertWords * sizeof(uint32_t));
     step(hipMalloc((void **)&genome->d_ix_sites, sb));
     step(hipMalloc((void **)&genome->d_ix_edge, eb));
     step(hipMalloc((void **)&genome->d_ix_chunk_tab, cb));
@@ -1259,22 +1276,35 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
     } else {
         // ---- per-bucket read lists: a counting sort of the reads' segment neighbourhoods over the buckets ------
-        const uint32_t k_seg = params->max_mismatches / kSegments;
-        const uint32_t n_nbr = k_seg == 0 ? 1u : (k_seg == 1 ? 22u : 211u);
-        const uint64_t n_pairs = (uint64_t)n_guides * kSegments * n_nbr;
-        const uint64_t list_cap = n_pairs + (uint64_t)kBuckets * (kGuideUnroll - 1) + 2 * kGuideUnroll;
-        VSC_HIP_H(ctx->seed_off.ensure((kBuckets + 1) * sizeof(uint32_t)));
-        VSC_HIP_H(ctx->seed_poff.ensure((kBuckets + 1) * sizeof(uint32_t)));
+        // The cut of the pigeonhole (SeedPlan, vsc_internal.h): segments 0 and 1 within k01 substitutions, segment 2 within what the
+        // site's PAM class leaves of the limit - 2 k01 - 2.  Hook seed_tight = 0: floor(m / 3) everywhere (the round-3 cut).
+        const uint32_t m = params->max_mismatches;
+        auto nbr = [](int k) { return k < 0 ? 0u : (k == 0 ? 1u : (k == 1 ? 22u : 211u)); };
+        SeedPlan plan{};
+        plan.max_mm = m;
+        plan.tight = ctx->dbg.seed_tight != 0;
+        plan.k01 = plan.tight ? (m ? (m - 1) / kSegments : 0u) : m / kSegments;
+        const int k2_max = plan.tight ? (int)m - 2 * (int)plan.k01 - 2 : (int)plan.k01;
+        plan.n_nbr = nbr(std::max<int>((int)plan.k01, k2_max));
+        {
+            ScanArgs pa{};
+            vsc_search_params ip{};
+            ip.has_extra_pam = genome->index_has_extra_pam;
+            ip.extra_pam[0] = genome->index_extra_pam[0];
+            ip.extra_pam[1] = genome->index_extra_pam[1];
+            fill_pam(pa, &ip);  // the classes of the index, in the order build_index gave them
+            plan.n_pam = pa.n_pam;
+            plan.pam_codes = pam_code_set(pa);
+        }
+        // entries: one per (read, neighbour within k01) of segments 0 and 1, one per class and neighbour of segment 2
+        const uint64_t n_pairs = (uint64_t)n_guides * (2 * nbr((int)plan.k01) + plan.n_pam * nbr(k2_max));
+        const uint64_t list_cap = n_pairs + (uint64_t)kLists * (kGuideUnroll - 1) + 2 * kGuideUnroll;
+        VSC_HIP_H(ctx->seed_off.ensure((kLists + 1) * sizeof(uint32_t)));
+        VSC_HIP_H(ctx->seed_poff.ensure((kLists + 1) * sizeof(uint32_t)));
         VSC_HIP_H(ctx->seed_lrest.ensure(list_cap * sizeof(uint4)));
         VSC_HIP_H(hipMemsetAsync(ctx->seed_lrest.p, 0xFF, list_cap * sizeof(uint4), ctx->stream));  // padding: y = ~0, skipped
-        // GG and GA start with the same letter, and so does the index unless -P added a PAM that starts differently:
-        // read position 21 then needs no per-site comparison - the read lists take a mismatch there out of the
-        // budget of their entries (seed_enum_kernel, sliced_within)
-        sa.pam21 = 2u;
-        if (genome->index_has_extra_pam && base_code(genome->index_extra_pam[0]) != 2) sa.pam21 = 4u;
-        if (ctx->dbg.seed_pam21 == 0) sa.pam21 = 4u;
-        VSC_HIP_H(launch_seed_lists((const uint2 *)ctx->guides.p, n_guides, n_nbr, params->max_mismatches, sa.pam21, (uint32_t *)ctx->seed_off.p,
-                                    (uint32_t *)ctx->seed_poff.p, (uint4 *)ctx->seed_lrest.p, ctx->stream));
+        VSC_HIP_H(launch_seed_lists((const uint2 *)ctx->guides.p, n_guides, plan, (uint32_t *)ctx->seed_off.p, (uint32_t *)ctx->seed_poff.p,
+                                    (uint4 *)ctx->seed_lrest.p, ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
         sa.chunk_tab = genome->d_ix_chunk_tab;
         sa.n_chunks = genome->ix_chunks;
@@ -1286,7 +1316,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         sa.poff = (const uint32_t *)ctx->seed_poff.p;
         sa.max_mm = params->max_mismatches;
         sa.k_half = params->max_mismatches / 2;
-        sa.k_seg = k_seg;
+        sa.k_seg = plan.k01;
         sa.contig_end = genome->d_contig_end;
         sa.n_contigs = genome->n_contigs;
         sa.counters = (unsigned long long *)ctx->counters.p;
@@ -1295,7 +1325,8 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         // dense searches (c3: 129 reads per bucket) share a chunk between the four waves of a workgroup, sparse ones
         // (c2: 13) keep a chunk per wave - see seed_sliced_kernel.  Measured at <= 8 mismatches (tools/
         // experiments.sh shared-threshold): 51 reads per bucket 12.1 vs 11.4 ms, 77: 15.9 vs 16.0, 103: 19.9 vs 20.7
-        seed_shared = n_pairs / kBuckets >= 72;
+        // (reads per list of segments 0 and 1 - and of segment 2 wherever it is searched as widely)
+        seed_shared = (uint64_t)n_guides * nbr((int)plan.k01) / kBucketsPerSeg >= 72;
         if (ctx->dbg.seed_shared >= 0) seed_shared = ctx->dbg.seed_shared == 1;
         const uint32_t n_grabs = (sa.n_chunks + kSlicedGrab - 1) / kSlicedGrab;
         const uint32_t n_waves_max = (uint32_t)ctx->n_cus * groups_per_cu * kWavesPerGroup;
@@ -1428,7 +1459,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
     } else {
         t.sites = genome->index_sites;
         t.pairs += cnt[kCntSites];
-        t.genome_bytes += cnt[kCntVisited] * sizeof(uint32_t);  // sites visited, 4 bytes each bit-sliced
+        t.genome_bytes += cnt[kCntVisited] * kVertWords * sizeof(uint32_t) / kSlicedSites;  // sites visited, 3.5 bytes each bit-sliced
         double fullest = 0;
         for (int q = 0; q < n_parts; ++q) {
             const uint64_t placed = cnt[kCntPart + 4 * q], real = placed - cnt[kCntPart + 4 * q + 1];

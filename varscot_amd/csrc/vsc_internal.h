@@ -33,8 +33,16 @@ constexpr int kBuckets = kSegments * kBucketsPerSeg;
 constexpr int kSeedHitCap = 256;                // smallest block of records a wave reserves per atomic
 constexpr int kSlicedSites = 32;                // sites per lane of the bit-sliced comparison (one bit each)
 constexpr int kSlicedChunk = kWave * kSlicedSites;  // 2048 sites per wave and chunk
-constexpr int kRestBases = VSC_READ_LEN - kSegBases;  // 16 read positions outside the seed segment
-constexpr int kListBudgetShift = 28;            // list entry y: read index | mismatches left for the rest positions << 28
+constexpr int kRestBases = VSC_READ_LEN - kSegBases;  // 16 read positions outside the seed segment (what a site record keeps)
+constexpr int kCmpBases = 2 * kSegBases;        // ... of which the comparison counts 14: the other two segments.  Read positions
+                                                // 21 and 22 are the PAM, and a chunk holds sites of ONE PAM (its class)
+constexpr int kVertWords = 2 * kCmpBases;       // words of a bit-sliced block of 32 sites: hi and lo plane bit of the 14 positions
+constexpr int kSeedClasses = 3;                 // PAMs an index can hold: GG, GA (+ -P); class of a site = which one its window ends in
+// read lists: one per bucket for segments 0 and 1 (shared by the classes - an entry holds a budget per class), one per
+// (class, bucket) for segment 2, whose neighbourhood depends on what the class leaves of the mismatch limit (seed_enum_kernel)
+constexpr int kLists = (kSegments - 1 + kSeedClasses) * kBucketsPerSeg;
+constexpr int kListBudgetShift = 16;            // list entry y: read index | per class c: mismatches left for the 14 compared positions
+constexpr uint32_t kListNoBudget = 15;          //   << (16 + 4 c), 15 = the read has no business with that class (list padding: all ones)
 constexpr int kTokLaneShift = 26;               // sliced hit token, high word: read of the pass (14 bits) | chunk slot << 14 | lane << 26
 constexpr int kTokSlotShift = 14;
 constexpr uint32_t kTokReadMask = (1u << kTokSlotShift) - 1u;
@@ -42,10 +50,12 @@ constexpr int kSlicedResolve = 3;                // sliced kernel: resolve when 
                                                 // gathers of the later passes overlap the earlier ones)
 constexpr int kSlicedTokCap = 512;  // per-wave LDS ring of 8-byte hit tokens (a power of two: the slot is an AND): a group of four reads adds <= 256
 // chunk table word z: bucket (16 bits) | rank in the chunk of its first '-' site (0 .. 2048) << 16 | "holds a window
-// that is followed by N" << 28
+// that is followed by N" << 28 | class of its sites << 29
 constexpr uint32_t kChunkBucketMask = 0xFFFFu;
 constexpr int kChunkMinusShift = 16;
 constexpr int kChunkEdgeBit = 28;
+constexpr int kChunkClassShift = 29;
+constexpr uint32_t kIndexLayout = 2;            // seed index layout (index files of another layout are refused)
 constexpr int kSlicedWavesPerSimd = 6;          // resident waves of the sliced kernel per SIMD (registers and LDS allow five)
 constexpr int kSlicedGrab = 8;                  // chunks of 2048 sites per grab of the work counter (sliced kernel)
 
@@ -210,23 +220,35 @@ struct ScoreArgs {
     uint32_t n_segs;
 };
 
+// How one search cuts the pigeonhole (seed_enum_kernel).  A site of class c (its PAM) leaves a read left_c = max_mm -
+// (mismatches of the read's last two letters with that PAM) for read positions 0..20.  Segments 0 and 1 are searched within
+// k01 substitutions, segment 2 within left_c - 2 k01 - 2 (none if negative): a window that fails all three has at least
+// (k01 + 1) + (k01 + 1) + (left_c - 2 k01 - 1) = left_c + 1 mismatches.  k01 = floor((max_mm - 1) / 3) keeps the third
+// threshold <= 2 for every max_mm <= 8.  tight = 0: the round-3 cut - floor(max_mm / 3) in all three segments.
+struct SeedPlan {
+    uint32_t max_mm, k01, tight;
+    uint32_t n_nbr;      // neighbours enumerated per (read, segment): 1 / 22 / 211 = the largest threshold in use
+    uint32_t n_pam;
+    uint32_t pam_codes;  // class c: (first letter << 2 | second letter) << 4 c
+};
+
 struct SeedArgs {
-    const uint4 *chunk_tab;        // [n_chunks] {first site, site count, bucket | first '-' rank << 16 | edge << 28, first vertical block}
-    const uint32_t *vert;          // bit-sliced copies of the sites: 32 words per block of 32 sites (see seed_transpose_kernel)
-    const uint4 *list_rest;        // per list entry {rest(hi) | rest(lo) << 16, read | budget << 28, hi, lo}
+    const uint4 *chunk_tab;        // [n_chunks] {first site, site count, bucket | first '-' rank << 16 | edge << 28 | class << 29, first vertical block}
+    const uint32_t *vert;          // bit-sliced copies of the sites: kVertWords words per block of 32 sites (see seed_transpose_kernel)
+    const uint4 *list_rest;        // per list entry {rest(hi) | rest(lo) << 16, read | budget per class << 16 .., hi, lo}
     const uint2 *sites;            // {rest(hi) | rest(lo) << 16, position} per site
     const uint32_t *edge_bits;     // 1 bit per site: its window is followed by N
     const uint2 *guides;           // (hi plane, lo plane) per read
     uint32_t n_chunks;
-    const uint32_t *poff;          // [kBuckets + 1] first list entry of every bucket (multiples of kGuideUnroll)
-    uint32_t max_mm, k_half, k_seg;
+    const uint32_t *poff;          // [kLists + 1] first entry of every read list (multiples of kGuideUnroll)
+    uint32_t max_mm, k_half;
+    uint32_t k_seg;                // substitutions searched in segments 0 and 1 (SeedPlan.k01): what the duplicate rule tests
     const uint32_t *contig_end;
     uint32_t n_contigs;
     uint64_t *hit_recs;            // out: packed records (layout above), region p = [p * part_cap, (p + 1) * part_cap)
     uint32_t *hit_side;            // null, or (per-hit feature rows wanted): one word beside every record = the site's lo plane in read
                                    // orientation; its hi plane then sits in the record's low 23 bits in place of the mismatch mask
     uint32_t group_out;            // 1: the four waves of a workgroup share their open blocks (chunk-sharing kernel only)
-    uint32_t pam21;                // base code every site has at read position 21 (first PAM letter), or >= 4: not all the same
     uint32_t reserve;              // records a wave reserves per atomic on its region's cursor: a power of two, 64 .. 1024
     uint32_t reserve_log2;
     uint32_t pos_pad;              // left shift of the position field of a record
@@ -320,9 +342,9 @@ hipError_t launch_merge_packed(const uint64_t *seg_src, const uint64_t *seg_dst,
 hipError_t launch_plane_hash(const uint32_t *hi, const uint32_t *lo, const uint32_t *nm, uint64_t n_words, unsigned long long *out,
                              hipStream_t stream);
 // vsc_seed.hip
-hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint64_t *sort_records, hipStream_t stream);
-hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t max_mm, uint32_t pam21, uint32_t *count,
-                             uint32_t *poff, uint4 *list_rest, hipStream_t stream);
+hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint32_t pam_codes, uint32_t n_pam, uint64_t *sort_records, hipStream_t stream);
+hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, const SeedPlan &plan, uint32_t *count, uint32_t *poff, uint4 *list_rest,
+                             hipStream_t stream);
 hipError_t launch_seed_pack16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, uint64_t n, uint4 *rec, hipStream_t stream);
 hipError_t launch_seed_gather16(const uint4 *rec, const uint64_t *sorted, uint64_t n, uint4 *out, hipStream_t stream);
 hipError_t launch_seed_compact(const uint4 *sites16, uint64_t n_per_table, uint64_t n, uint2 *sites8, uint32_t *edge_bits,

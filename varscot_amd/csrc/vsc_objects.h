@@ -47,7 +47,7 @@ inline vsc_debug_params default_debug_params()
     d.score_slices = -1;
     d.seed_shared = -1;
     d.seed_group_out = -1;
-    d.seed_pam21 = -1;
+    d.seed_tight = -1;
     d.rf_form = -1;
     return d;
 }

@@ -10,12 +10,20 @@
 // 14-bit code of its 7 segment bases ("bucket").  A search enumerates, per read and segment, the
 // 1 / 22 / 211 seven-mers within k substitutions of the read's segment, which turns into one list of
 // reads per bucket; a wave then compares a chunk of one bucket's sites only with that bucket's reads:
-// 3 * 211 / 16384 = 3.9 % of all (site, read) pairs at m = 6..8.  A pair is accepted on exactly the
+// 3 * 211 / 16384 = 3.9 % of all (site, read) pairs at m = 8.  A pair is accepted on exactly the
 // streaming scan's criterion - at most m mismatches over all 23 positions, the right-edge rule - so the
 // accepted set is identical; a pair that qualifies in several segments is reported by the first only.
 //
-// seed_sliced_kernel compares bit-sliced: 32 sites per lane and instruction, only the 16 positions outside
-// the bucket's segment are counted, the segment adds the list entry's known distance; hits are resolved
+// Round 4: the cut is as tight as the PAM allows.  Inside a bucket the sites are grouped by their PAM (the "class":
+// GG, GA or -P's), a chunk holds sites of one class, so the read's mismatches with the chunk's PAM are known before
+// any site is looked at: they come out of the budget, read positions 21 and 22 leave the comparison, and the
+// segments' thresholds follow what is LEFT for positions 0..20 (SeedPlan): a read that ends in GG meets the GA sites
+// with one mismatch spent, so their third segment is searched within one substitution instead of two (22 buckets
+// instead of 211) - 15 % fewer pairs at m = 8; at m = 6 the thresholds are (1, 1, 2) / (1, 1, 1) instead of (2, 2, 2):
+// a quarter of the pairs.
+//
+// seed_sliced_kernel compares bit-sliced: 32 sites per lane and instruction, only the 14 positions of the other two
+// segments are counted, the segment adds the list entry's known distance and the PAM the class's; hits are resolved
 // from the site records and leave the kernel as packed 8-byte records (vsc_internal.h), one output region
 // per 64 reads.
 #include "vsc_internal.h"
@@ -31,16 +39,27 @@ __device__ __forceinline__ uint32_t segment_key(uint32_t x, uint32_t l, int s)
 // ------------------------------------------------------------------------------------------------
 // index build
 // ------------------------------------------------------------------------------------------------
-// One 8-byte sort record per site and table: (bucket << 1 | strand) << 32 | index of the site.  The bin sort's partition
-// kernels (vsc_sort.hip) order them by the 15 key bits in two levels (8 + 7 bits); the index then fetches the site.
-__global__ __launch_bounds__(256) void seed_key_kernel(const uint4 *rec, uint64_t n, int seg, uint64_t *out)
+// (first PAM letter << 2 | second) of a 23-base plane pair in read orientation
+__device__ __forceinline__ uint32_t pam_code(uint32_t x, uint32_t l)
+{
+    return (((x >> 21) & 1u) << 3) | (((l >> 21) & 1u) << 2) | (((x >> 22) & 1u) << 1) | ((l >> 22) & 1u);
+}
+
+// One 8-byte sort record per site and table: ((bucket << 2 | class) << 1 | strand) << 32 | index of the site.  The bin sort's
+// partition kernels (vsc_sort.hip) order them by the 17 key bits in two levels (8 + 9 bits); the index then fetches the site.
+__global__ __launch_bounds__(256) void seed_key_kernel(const uint4 *rec, uint64_t n, int seg, uint32_t pam_codes, uint32_t n_pam, uint64_t *out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4 r = rec[i];  // {hi plane | strand | edge, lo plane, position, 0}
-    // bucket, then strand: inside a bucket the '+' sites precede the '-' sites, so that a chunk needs one number
-    // (where its '-' sites begin) instead of a strand bit per site record
-    const uint32_t key = (segment_key(r.x, r.y, seg) << 1) | ((r.x >> kSiteStrandBit) & 1u);
+    // class = the first PAM of the set the site ends in (the extraction only emits sites that end in one of them)
+    const uint32_t code = pam_code(r.x, r.y);
+    uint32_t cls = 0;
+    for (uint32_t c = n_pam; c-- > 0;)
+        if (((pam_codes >> (4 * c)) & 15u) == code) cls = c;
+    // bucket, class, then strand: inside a (bucket, class) group the '+' sites precede the '-' sites, so that a chunk needs
+    // one number (where its '-' sites begin) instead of a strand bit per site record
+    const uint32_t key = (((segment_key(r.x, r.y, seg) << 2) | cls) << 1) | ((r.x >> kSiteStrandBit) & 1u);
     out[i] = ((uint64_t)key << 32) | (uint32_t)i;
 }
 
@@ -62,10 +81,10 @@ __global__ __launch_bounds__(256) void seed_gather16_kernel(const uint4 *rec, co
     out[i] = rec[(uint32_t)sorted[i]];  // the low word of a sort record is the site's index
 }
 
-hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint64_t *out, hipStream_t stream)
+hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint32_t pam_codes, uint32_t n_pam, uint64_t *out, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(seed_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, n, seg, out);
+    hipLaunchKernelGGL(seed_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, n, seg, pam_codes, n_pam, out);
     return hipGetLastError();
 }
 
@@ -184,38 +203,59 @@ __device__ __forceinline__ uint32_t rest_of(uint32_t v, uint32_t seg)
     return (v & 0x3FFFu) | ((v >> (3 * kSegBases)) << (2 * kSegBases));
 }
 
-// One thread per (read, segment, neighbour).  kScatter = false: count[bucket]++.  kScatter = true: the list entry
-// goes to poff[bucket] + (cursor[bucket]++) - x = rest(hi) | rest(lo) << 16, y = read index | mismatch budget << 28,
-// z / w = the full hi / lo planes.
-// The entry also carries what the comparison may still spend on the 16 rest positions: max_mm - seed distance, less
-// one if every site of the index has base `pam21` (< 4) at read position 21 and the read has another one there (the
-// comparison then leaves that position out, sliced_within<true>).  A read that has nothing left to spend on a bucket
-// gets no entry in its list.
+// One thread per (read, segment, neighbour).  kScatter = false: count[list]++.  kScatter = true: the list entry goes to
+// poff[list] + (cursor[list]++) - x = rest(hi) | rest(lo) << 16, y = read index | per class: budget << (16 + 4 c), z / w =
+// the full hi / lo planes.
+// budget = what the comparison may still spend on the 14 positions of the other two segments against a site of class c:
+// max_mm - mismatches of the read's last two letters with the class's PAM - seed distance (15: the read has nothing to do
+// with that class).  Segments 0 and 1 keep ONE list per bucket, whose entries serve every class; segment 2 a list per
+// (class, bucket), because which of its neighbours a read visits depends on what the class leaves it (SeedPlan).
 template <bool kScatter>
-__global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t max_mm,
-                                                        uint32_t pam21, uint32_t *count, const uint32_t *poff, uint4 *list_rest)
+__global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uint32_t n_guides, const SeedPlan plan, uint32_t *count,
+                                                        const uint32_t *poff, uint4 *list_rest)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t total = (uint64_t)n_guides * kSegments * n_nbr;
+    const uint64_t total = (uint64_t)n_guides * kSegments * plan.n_nbr;
     if (i >= total) return;
-    const uint32_t n = (uint32_t)(i % n_nbr);
-    const uint32_t s = (uint32_t)((i / n_nbr) % kSegments);
-    const uint32_t g = (uint32_t)(i / ((uint64_t)n_nbr * kSegments));
+    const uint32_t n = (uint32_t)(i % plan.n_nbr);
+    const uint32_t s = (uint32_t)((i / plan.n_nbr) % kSegments);
+    const uint32_t g = (uint32_t)(i / ((uint64_t)plan.n_nbr * kSegments));
     const uint2 gp = guides[g];
     uint32_t d;
     const uint32_t b = seed_neighbour(gp, s, n, &d);
-    if (pam21 < 4u && ((((gp.x >> 21) & 1u) << 1) | ((gp.y >> 21) & 1u)) != pam21) ++d;
-    if (d > max_mm) return;
-    const uint32_t at = atomicAdd(&count[b], 1u);
-    if (kScatter)
-        list_rest[poff[b] + at] = make_uint4(rest_of(gp.x, s) | (rest_of(gp.y, s) << 16), g | ((max_mm - d) << kListBudgetShift), gp.x, gp.y);
+    const uint32_t mine = pam_code(gp.x, gp.y);
+    const uint32_t rest = rest_of(gp.x, s) | (rest_of(gp.y, s) << 16);
+    constexpr uint32_t kNone = (kListNoBudget << kListBudgetShift) | (kListNoBudget << (kListBudgetShift + 4)) |
+                               (kListNoBudget << (kListBudgetShift + 8)) | (kListNoBudget << (kListBudgetShift + 12));
+    uint32_t shared = kNone;  // segments 0 and 1: the budgets of all classes in one entry
+    for (uint32_t c = 0; c < plan.n_pam; ++c) {
+        const uint32_t diff = mine ^ ((plan.pam_codes >> (4 * c)) & 15u);
+        const uint32_t spent = ((diff & 12u) ? 1u : 0u) + ((diff & 3u) ? 1u : 0u);
+        if (spent + d > plan.max_mm) continue;
+        const uint32_t left = plan.max_mm - spent;  // for read positions 0..20
+        const int thr = (s < 2 || !plan.tight) ? (int)plan.k01 : (int)left - 2 * (int)plan.k01 - 2;
+        if ((int)d > thr) continue;
+        const uint32_t field = kListBudgetShift + 4 * c;
+        if (s < 2) {
+            shared = (shared & ~(15u << field)) | ((left - d) << field);
+            continue;
+        }
+        const uint32_t list = b + c * (uint32_t)kBucketsPerSeg;  // b = 2 x 16384 + code
+        const uint32_t at = atomicAdd(&count[list], 1u);
+        if (kScatter) list_rest[poff[list] + at] = make_uint4(rest, g | ((kNone & ~(15u << field)) | ((left - d) << field)), gp.x, gp.y);
+    }
+    if (s < 2 && shared != kNone) {
+        const uint32_t at = atomicAdd(&count[b], 1u);
+        if (kScatter) list_rest[poff[b] + at] = make_uint4(rest, g | shared, gp.x, gp.y);
+    }
 }
 
-// poff[b] = sum over b' < b of roundup4(count[b']); the counts are cleared for pass 2; one workgroup, kBuckets + 1 outputs
+// poff[b] = sum over b' < b of roundup4(count[b']); the counts are cleared for pass 2; one workgroup, kLists + 1 outputs
 __global__ __launch_bounds__(1024) void seed_pad_scan_kernel(uint32_t *count, uint32_t *poff)
 {
     __shared__ uint32_t partial[1024];
-    constexpr uint32_t per = kBuckets / 1024;  // 48
+    constexpr uint32_t per = kLists / 1024;  // 80
+    static_assert(kLists % 1024 == 0, "lists per thread");
     const uint32_t t = threadIdx.x;
     uint32_t sum = 0;
     for (uint32_t i = 0; i < per; ++i) sum += (count[t * per + i] + (kGuideUnroll - 1)) & ~(uint32_t)(kGuideUnroll - 1);
@@ -234,21 +274,21 @@ __global__ __launch_bounds__(1024) void seed_pad_scan_kernel(uint32_t *count, ui
         run += (count[b] + (kGuideUnroll - 1)) & ~(uint32_t)(kGuideUnroll - 1);
         count[b] = 0;
     }
-    if (t == 1023) poff[kBuckets] = run;
+    if (t == 1023) poff[kLists] = run;
 }
 
-// count: kBuckets words of scratch; poff: kBuckets + 1 list starts (multiples of kGuideUnroll); list_rest: the lists,
+// count: kLists words of scratch; poff: kLists + 1 list starts (multiples of kGuideUnroll); list_rest: the lists,
 // pre-filled with the padding pattern (y = ~0) by the caller
-hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, uint32_t n_nbr, uint32_t max_mm, uint32_t pam21, uint32_t *count,
-                             uint32_t *poff, uint4 *list_rest, hipStream_t stream)
+hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, const SeedPlan &plan, uint32_t *count, uint32_t *poff, uint4 *list_rest,
+                             hipStream_t stream)
 {
-    const uint64_t total = (uint64_t)n_guides * kSegments * n_nbr;
-    hipError_t e = hipMemsetAsync(count, 0, (size_t)kBuckets * sizeof(uint32_t), stream);
+    const uint64_t total = (uint64_t)n_guides * kSegments * plan.n_nbr;
+    hipError_t e = hipMemsetAsync(count, 0, (size_t)kLists * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (total) hipLaunchKernelGGL(seed_enum_kernel<false>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, n_nbr, max_mm, pam21, count, (const uint32_t *)nullptr, (uint4 *)nullptr);
+    if (total) hipLaunchKernelGGL(seed_enum_kernel<false>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, plan, count, (const uint32_t *)nullptr, (uint4 *)nullptr);
     hipLaunchKernelGGL(seed_pad_scan_kernel, dim3(1), dim3(1024), 0, stream, count, poff);
-    if (total) hipLaunchKernelGGL(seed_enum_kernel<true>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, n_nbr, max_mm, pam21, count, (const uint32_t *)poff, list_rest);
+    if (total) hipLaunchKernelGGL(seed_enum_kernel<true>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, plan, count, (const uint32_t *)poff, list_rest);
     return hipGetLastError();
 }
 
@@ -268,21 +308,20 @@ struct SeedWave {
 
 // A per-pair comparison (xor, or, popcount, compare) spends 4 VALU instructions per (site, read) pair and lane.
 // Here a lane holds 32 sites "vertically": one word per read position and plane, bit i = site i.  One VALU instruction then
-// works on 32 pairs:  16 positions x 2 (mismatch vector) + a carry-save adder tree (11 full + 4 half
-// adders, 2 instructions each) + a 5-instruction bit-sliced "count <= budget" = ~67 instructions per 32
-// pairs, no popcount, no per-pair branch.  Only the 16 positions OUTSIDE the bucket's seed segment are
-// compared: all sites of a bucket share the segment, whose distance d to the read is a property of
-// the list entry (0, 1 or 2 substitutions), so the budget for the rest is m - d (the entry carries it).  With the
-// GG / GA PAM set read position 21 leaves the comparison as well (kPam21, see sliced_within): 57 instructions.
+// works on 32 pairs:  14 positions x 2 (mismatch vector) + a carry-save adder tree (10 full adders + 1 half adder, 2
+// instructions each) + a 4-instruction bit-sliced "count <= budget" = 55 instructions per 32 pairs, no popcount, no
+// per-pair branch.  Only the 14 positions of the OTHER TWO segments are compared: all sites of a bucket share the segment,
+// whose distance d to the read is a property of the list entry (0, 1 or 2 substitutions), and all sites of a chunk share
+// their PAM, so the budget for the rest is what the class leaves of m, less d (the entry carries it per class).
 //
-// Vertical block of 32 sites (32 words): words 0..15 = hi-plane bit of rest position q = 0..15, words 16..31 =
+// Vertical block of 32 sites (28 words): words 0..13 = hi-plane bit of rest position q = 0..13, words 14..27 =
 // lo-plane bit.  Block b of a chunk holds the chunk's sites [32 b, 32 b + 32); the blocks of a chunk are
 // stored interleaved by word quad (see seed_transpose_kernel) so that a wave's loads are contiguous.
 __device__ __forceinline__ uint32_t rest_position(uint32_t q, uint32_t seg)
 {
     if (seg == 0) return q + kSegBases;
     if (seg == 1) return q < (uint32_t)kSegBases ? q : q + kSegBases;
-    return q < 2u * kSegBases ? q : q + kSegBases;
+    return q;  // (q < 14)
 }
 
 // One wave per chunk: 64 sites per step, two blocks; word j of a block is the ballot of one plane bit.
@@ -299,19 +338,19 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) void seed_transpose_kernel(c
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (i < ct.y) v = sites[ct.x + i];
         uint32_t mine = 0;
-        for (uint32_t q = 0; q < (uint32_t)kRestBases; ++q) {
+        for (uint32_t q = 0; q < (uint32_t)kCmpBases; ++q) {
             const uint32_t p = rest_position(q, seg);
             const uint64_t bh = __ballot((v.x >> p) & 1u), bl = __ballot((v.y >> p) & 1u);
             // lanes 0..31 assemble block 2k (low halves), lanes 32..63 block 2k + 1 (high halves)
             const uint32_t wh = lane < 32 ? (uint32_t)bh : (uint32_t)(bh >> 32);
             const uint32_t wl = lane < 32 ? (uint32_t)bl : (uint32_t)(bl >> 32);
             if ((lane & 31u) == q) mine = wh;
-            if ((lane & 31u) == q + kRestBases) mine = wl;
+            if ((lane & 31u) == q + kCmpBases) mine = wl;
         }
         const uint32_t block = 2 * k + (lane >> 5), j = lane & 31u;
         const uint32_t nb = (ct.y + kSlicedSites - 1) / kSlicedSites;  // blocks of this chunk
         // chunk layout [word quad j / 4][block][j % 4]: the 16-byte loads of a wave (lane = block) coalesce
-        if (block < nb) vert[(size_t)ct.w * 32 + ((size_t)(j >> 2) * nb + block) * 4 + (j & 3u)] = mine;
+        if (block < nb && j < (uint32_t)kVertWords) vert[(size_t)ct.w * kVertWords + ((size_t)(j >> 2) * nb + block) * 4 + (j & 3u)] = mine;
     }
 }
 
@@ -362,60 +401,36 @@ __device__ __forceinline__ void count7(const uint32_t *m, uint32_t &b0, uint32_t
 }
 
 // Bit i of the result: site i of this lane's block is valid, within `budget` mismatches of the read on the
-// 16 rest positions, and NOT already reported by an earlier segment.  rx = rest(hi) | rest(lo) << 16 of the
-// read (wave-uniform), budget <= 15 (what the list entry leaves of max_mm: seed_enum_kernel).
-// Whatever the bucket's segment, the 16 rest positions are [7 positions of another segment][7 of the third]
-// [read positions 21, 22], so the adder tree first counts the two groups of seven (3 bits each) and then
-// adds them and the last two inputs: the same 30 instructions as a flat tree, and the group counts give
-// the duplicate test for free - a pair with <= k mismatches in an EARLIER segment (group A for segments 1
-// and 2, also group B for segment 2) was reported from that segment's bucket.  Without this 40 % of the
-// candidates at m = 8 (1.67 qualifying segments per hit on average) went through the hit path only to be
-// dropped there.
-template <bool kPam21>
-__device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[2 * kRestBases], uint32_t rx, uint32_t budget,
-                                                  uint32_t valid, uint32_t seg, const uint32_t (&kv)[2])
+// 14 compared positions, and NOT already reported by an earlier segment.  rx = rest(hi) | rest(lo) << 16 of the
+// read (wave-uniform), budget <= 8 (what the chunk's class and the seed distance leave of max_mm: seed_enum_kernel).
+// Whatever the bucket's segment, the compared positions are [7 positions of another segment][7 of the third], so the adder
+// tree counts the two groups of seven (3 bits each) and adds them: the group counts give the duplicate test for free - a
+// pair with <= k mismatches in an EARLIER segment (group A for segments 1 and 2, also group B for segment 2) was reported
+// from that segment's bucket.  Without this 40 % of the candidates at m = 8 (1.67 qualifying segments per hit on average)
+// went through the hit path only to be dropped there.
+// History: 72 instructions with read positions 21 and 22 in the comparison (5-bit count), 57 + 3 once the index's common
+// first PAM letter had left it (round 3), 55 + 3 now that the chunk's class settles both PAM letters.
+__device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[kVertWords], uint32_t rx, uint32_t budget, uint32_t valid, uint32_t seg,
+                                                  const uint32_t (&kv)[2])
 {
-    uint32_t mm[kRestBases];
+    uint32_t mm[kCmpBases];
 #pragma unroll
-    for (int q = 0; q < kRestBases; ++q) {  // (hi ^ read hi) | (lo ^ read lo)
-        if (kPam21 && q == 2 * kSegBases) continue;  // the caller's business, see below
-        mm[q] = bitop3<0xF6>(v[q] ^ spread(rx, q), v[kRestBases + q], spread(rx, kRestBases + q));
-    }
+    for (int q = 0; q < kCmpBases; ++q)  // (hi ^ read hi) | (lo ^ read lo)
+        mm[q] = bitop3<0xF6>(v[q] ^ spread(rx, q), v[kCmpBases + q], spread(rx, kRestBases + q));
     uint32_t a0, a1, a2, b0, b1, b2;
     count7(mm, a0, a1, a2);
     count7(mm + kSegBases, b0, b1, b2);
-    uint32_t ok;
-    if (kPam21) {
-        // Read position 21 holds the same base in EVERY site of the index (the PAM set is GG / GA): whether the read
-        // mismatches there is known before any site is looked at: the read lists have it taken out of `budget` already.
-        // A + B + mm[15] is a 4-bit count: three full adders and a 4-bit comparison instead of three full and four half
-        // adders and a 5-bit one - 57 instead of 68 instructions per (chunk, read) in a kernel that is bound by them.
-        uint32_t t0, t1, t2, k0, k1, k2;
-        full_add(a0, b0, mm[15], t0, k0);
-        full_add(a1, b1, k0, t1, k1);
-        full_add(a2, b2, k1, t2, k2);
-        uint32_t le = ~t0 | spread(budget, 0);
-        le = bitop3<0x8E>(t1, spread(budget, 1), le);
-        le = bitop3<0x8E>(t2, spread(budget, 2), le);
-        le = bitop3<0x8E>(k2, spread(budget, 3), le);
-        ok = le & valid;
-    } else {
-        // A + B + mm[14] + mm[15] -> c4 .. c0
-        uint32_t t0, t1, t2, k0, k1, k2, j0, j1, j2, c0, c1, c2, c3, c4;
-        full_add(a0, b0, mm[14], t0, k0);
-        half_add(t0, mm[15], c0, j0);
-        full_add(a1, b1, k0, t1, k1);
-        half_add(t1, j0, c1, j1);
-        full_add(a2, b2, k1, t2, k2);
-        half_add(t2, j1, c2, j2);
-        half_add(k2, j2, c3, c4);
-        // count <= budget, from the least significant bit up: le_i = (~c_i & b_i) | (~(c_i ^ b_i) & le_{i-1})
-        uint32_t le = ~c0 | spread(budget, 0);
-        le = bitop3<0x8E>(c1, spread(budget, 1), le);
-        le = bitop3<0x8E>(c2, spread(budget, 2), le);
-        le = bitop3<0x8E>(c3, spread(budget, 3), le);
-        ok = bitop3<0x20>(le, c4, valid);  // le & ~c4 & valid
-    }
+    // A + B: a 4-bit count
+    uint32_t t0, t1, t2, k0, k1, k2;
+    half_add(a0, b0, t0, k0);
+    full_add(a1, b1, k0, t1, k1);
+    full_add(a2, b2, k1, t2, k2);
+    // count <= budget, from the least significant bit up: le_i = (~c_i & b_i) | (~(c_i ^ b_i) & le_{i-1})
+    uint32_t le = ~t0 | spread(budget, 0);
+    le = bitop3<0x8E>(t1, spread(budget, 1), le);
+    le = bitop3<0x8E>(t2, spread(budget, 2), le);
+    le = bitop3<0x8E>(k2, spread(budget, 3), le);
+    uint32_t ok = le & valid;
     // Not reported by an earlier segment's bucket: its group count > k_seg.  k_seg <= 2 (VSC_MAX_MISMATCHES / 3), so
     // bit 2 of the count alone says "greater"; kv = bits 0 and 1 of k_seg, spread, in VECTOR registers: an instruction
     // with a scalar operand issues at 4.2 cycles per SIMD, with vector operands only at 2.6 (tools/micro/valu_rate.hip).
@@ -691,7 +706,7 @@ __device__ __forceinline__ void sliced_resolve(const SeedArgs &a, SeedWave &w)
 }
 
 // entry g0 + lane of a read list [g0, g1) (past the end: padding, y = ~0): its first half - rest planes, read |
-// distance << 30; the read's full planes in the second half are for the enumeration's own use
+// budget per class; the read's full planes in the second half are for the enumeration's own use
 __device__ __forceinline__ uint2 sliced_load_list(const SeedArgs &a, uint32_t g0, uint32_t g1, uint32_t lane)
 {
     uint2 e = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
@@ -704,13 +719,13 @@ __device__ __forceinline__ uint2 sliced_load_list(const SeedArgs &a, uint32_t g0
 
 // this lane's block of the chunk's bit-sliced sites (lanes past the chunk's last block: zeros)
 __device__ __forceinline__ void sliced_load_sites(const SeedArgs &a, const v4u &ct, bool wanted, uint32_t lane,
-                                                  uint32_t (&v)[2 * kRestBases])
+                                                  uint32_t (&v)[kVertWords])
 {
     const uint32_t nb = (ct.y + kSlicedSites - 1) / kSlicedSites;
     const bool mine = wanted && lane < nb;
-    const uint4 *vp = (const uint4 *)(a.vert + (size_t)ct.w * (2 * kRestBases)) + lane;
+    const uint4 *vp = (const uint4 *)(a.vert + (size_t)ct.w * kVertWords) + lane;
 #pragma unroll
-    for (int j = 0; j < 2 * kRestBases / 4; ++j) {
+    for (int j = 0; j < kVertWords / 4; ++j) {
         uint4 x = make_uint4(0u, 0u, 0u, 0u);
         if (mine) x = vp[(size_t)j * nb];
         v[4 * j] = x.x;
@@ -730,8 +745,7 @@ static_assert((kSlicedTokCap & (kSlicedTokCap - 1)) == 0 && kSlicedTokCap >= (kS
 // per wave every gather of a hit fetched its line from the fabric again (FETCH_SIZE 65 GB per c3 search; 17 GB with
 // one workgroup per CU resident, tools/experiments.sh groups).  For sparse searches (c2: 13 reads per bucket) a chunk visit
 // is mostly the load of its bit-sliced block, which every sharing wave repeats: those keep a chunk per wave.
-// kPam21: all sites have base a.pam21 at read position 21 (sliced_within)
-template <bool kShared, bool kPam21>
+template <bool kShared>
 __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(kSlicedWavesPerSimd, kSlicedWavesPerSimd))) void seed_sliced_kernel(
     const SeedArgs a)
 {
@@ -758,6 +772,11 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     for (int i = 0; i < 2; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(kv[i]) : "s"(spread(a.k_seg, i)));
     const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
     const const_u32_ptr poff = (const_u32_ptr)(uintptr_t)a.poff;
+    // the read list of a chunk (word z of its table entry): its bucket's, for segment 2 its class's list of that bucket
+    auto list_of = [](uint32_t z) {
+        const uint32_t bucket = z & kChunkBucketMask;
+        return bucket + (bucket >= 2u * kBucketsPerSeg ? ((z >> kChunkClassShift) & 3u) * (uint32_t)kBucketsPerSeg : 0u);
+    };
     const uint32_t lane_tag = w.lane << kTokLaneShift;
     unsigned long long pairs = 0, visited = 0;
 
@@ -813,14 +832,14 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
         v4u t0 = ctab[first];                             // chunk c
         v4u t1 = ctab[min(first + 1, last - 1)];          // chunk c + 1
         uint32_t p0a, p0b;
-        my_part(poff[t0.z & kChunkBucketMask], poff[(t0.z & kChunkBucketMask) + 1], wave_u, p0a, p0b);
+        my_part(poff[list_of(t0.z)], poff[list_of(t0.z) + 1], wave_u, p0a, p0b);
         uint2 nl = sliced_load_list(a, p0a, p0b, w.lane);
-        uint32_t p1a = poff[t1.z & kChunkBucketMask], p1b = poff[(t1.z & kChunkBucketMask) + 1];
+        uint32_t p1a = poff[list_of(t1.z)], p1b = poff[list_of(t1.z) + 1];
         v4u t2 = ctab[min(first + 2, last - 1)];          // chunk c + 2
         for (uint32_t c = first; c < last; ++c) {
             const v4u cur = t0;
             const uint32_t g0 = p0a, g1 = p0b;
-            uint32_t v[2 * kRestBases];
+            uint32_t v[kVertWords];
             sliced_load_sites(a, cur, g0 != g1, w.lane, v);
             // advance the pipeline before the comparison so that its loads overlap it
             t0 = t1;
@@ -828,8 +847,8 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
             uint2 tile = nl;
             nl = sliced_load_list(a, p0a, c + 1 < last ? p0b : p0a, w.lane);
             t1 = t2;
-            p1a = poff[t1.z & kChunkBucketMask];
-            p1b = poff[(t1.z & kChunkBucketMask) + 1];
+            p1a = poff[list_of(t1.z)];
+            p1b = poff[list_of(t1.z) + 1];
             t2 = ctab[min(c + 3, last - 1)];
             if (g0 == g1) continue;  // no read has this bucket in its neighbourhood
             const uint32_t slot_tag = (c - first) << kTokSlotShift;  // the tokens of this chunk carry its slot in the grab
@@ -839,6 +858,8 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
             }
             wave_sync();
             const uint32_t seg = (cur.z & kChunkBucketMask) / (uint32_t)kBucketsPerSeg;
+            // where an entry keeps the budget of this chunk's class: s_bfe_u32's operand (offset | width << 16)
+            const uint32_t budget_field = uniform((kListBudgetShift + 4u * ((cur.z >> kChunkClassShift) & 3u)) | (4u << 16));
             // sites of this lane's block that exist
             const int32_t left = (int32_t)cur.y - (int32_t)(w.lane * kSlicedSites);
             const uint32_t valid = left >= kSlicedSites ? 0xFFFFFFFFu : (left > 0 ? (1u << left) - 1u : 0u);
@@ -862,13 +883,15 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
 #pragma unroll
                     for (int u = 0; u < kGuideUnroll; ++u) {
                         const uint32_t ry = uniform(rd[u].y);
-                        if (ry == 0xFFFFFFFFu) continue;  // list padding
+                        // what is left of max_mm for the compared positions against this chunk's class (seed_enum_kernel)
+                        uint32_t budget;
+                        asm("s_bfe_u32 %0, %1, %2" : "=s"(budget) : "s"(ry), "s"(budget_field) : "scc");
+                        if (budget == kListNoBudget) continue;  // list padding, or a read that cannot reach this class
                         const uint32_t rx = uniform(rd[u].x);
-                        const uint32_t budget = ry >> kListBudgetShift;  // what is left of max_mm for the rest positions (seed_enum_kernel)
-                        const uint32_t word = sliced_within<kPam21>(v, rx, budget, valid, seg, kv);
+                        const uint32_t word = sliced_within(v, rx, budget, valid, seg, kv);
                         const uint64_t b = __ballot(word != 0);
                         if (b == 0) continue;
-                        const uint32_t gid = ry & ((1u << kListBudgetShift) - 1u);
+                        const uint32_t gid = ry & kTokReadMask;
                         if (word != 0)
                             w.tok[ring_slot(lanes_below(b, ring_tail(w)))] = make_uint2(word, gid | slot_tag | lane_tag);
                         w.ntok += (uint32_t)__popcll(b);
@@ -895,11 +918,8 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
 hipError_t launch_seed_sliced(const SeedArgs &args, int n_groups, bool shared, hipStream_t stream)
 {
     const dim3 grid(n_groups), block(kWave * kWavesPerGroup);
-    const bool pam21 = args.pam21 < 4u;
-    if (shared && pam21) hipLaunchKernelGGL((seed_sliced_kernel<true, true>), grid, block, 0, stream, args);
-    else if (shared) hipLaunchKernelGGL((seed_sliced_kernel<true, false>), grid, block, 0, stream, args);
-    else if (pam21) hipLaunchKernelGGL((seed_sliced_kernel<false, true>), grid, block, 0, stream, args);
-    else hipLaunchKernelGGL((seed_sliced_kernel<false, false>), grid, block, 0, stream, args);
+    if (shared) hipLaunchKernelGGL((seed_sliced_kernel<true>), grid, block, 0, stream, args);
+    else hipLaunchKernelGGL((seed_sliced_kernel<false>), grid, block, 0, stream, args);
     return hipGetLastError();
 }
 
