@@ -29,6 +29,8 @@
 #include "vsc_internal.h"
 #include "vsc_device.h"
 
+#include <type_traits>
+
 namespace vsc {
 
 __device__ __forceinline__ uint32_t segment_key(uint32_t x, uint32_t l, int s)
@@ -410,7 +412,8 @@ __device__ __forceinline__ void count7(const uint32_t *m, uint32_t &b0, uint32_t
 // went through the hit path only to be dropped there.
 // History: 72 instructions with read positions 21 and 22 in the comparison (5-bit count), 57 + 3 once the index's common
 // first PAM letter had left it (round 3), 55 + 3 now that the chunk's class settles both PAM letters.
-__device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[kVertWords], uint32_t rx, uint32_t budget, uint32_t valid, uint32_t seg,
+template <uint32_t kSeg>
+__device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[kVertWords], uint32_t rx, uint32_t budget, uint32_t valid,
                                                   const uint32_t (&kv)[2])
 {
     uint32_t mm[kCmpBases];
@@ -434,8 +437,8 @@ __device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[kVertWords
     // Not reported by an earlier segment's bucket: its group count > k_seg.  k_seg <= 2 (VSC_MAX_MISMATCHES / 3), so
     // bit 2 of the count alone says "greater"; kv = bits 0 and 1 of k_seg, spread, in VECTOR registers: an instruction
     // with a scalar operand issues at 4.2 cycles per SIMD, with vector operands only at 2.6 (tools/micro/valu_rate.hip).
-    if (seg >= 1) ok = bitop3<0xD0>(ok, a2, bitop3<0x8E>(a1, kv[1], ~a0 | kv[0]));  // ok & (a2 | ~le)
-    if (seg >= 2) ok = bitop3<0xD0>(ok, b2, bitop3<0x8E>(b1, kv[1], ~b0 | kv[0]));
+    if (kSeg >= 1) ok = bitop3<0xD0>(ok, a2, bitop3<0x8E>(a1, kv[1], ~a0 | kv[0]));  // ok & (a2 | ~le)
+    if (kSeg >= 2) ok = bitop3<0xD0>(ok, b2, bitop3<0x8E>(b1, kv[1], ~b0 | kv[0]));
     return ok;
 }
 
@@ -880,22 +883,30 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
                     uint2 rd[kGuideUnroll];
 #pragma unroll
                     for (int u = 0; u < kGuideUnroll; ++u) rd[u] = lt[gi + u];  // same address in every lane
+                    // (the duplicate test differs by segment - none, group A, groups A and B; left as a run-time `if` inside
+                    // the comparison the compiler computes all of it and selects: one copy of the four comparisons per segment)
+                    auto compare_group = [&](auto segment) {
+                        constexpr uint32_t kSeg = decltype(segment)::value;
 #pragma unroll
-                    for (int u = 0; u < kGuideUnroll; ++u) {
-                        const uint32_t ry = uniform(rd[u].y);
-                        // what is left of max_mm for the compared positions against this chunk's class (seed_enum_kernel)
-                        uint32_t budget;
-                        asm("s_bfe_u32 %0, %1, %2" : "=s"(budget) : "s"(ry), "s"(budget_field) : "scc");
-                        if (budget == kListNoBudget) continue;  // list padding, or a read that cannot reach this class
-                        const uint32_t rx = uniform(rd[u].x);
-                        const uint32_t word = sliced_within(v, rx, budget, valid, seg, kv);
-                        const uint64_t b = __ballot(word != 0);
-                        if (b == 0) continue;
-                        const uint32_t gid = ry & kTokReadMask;
-                        if (word != 0)
-                            w.tok[ring_slot(lanes_below(b, ring_tail(w)))] = make_uint2(word, gid | slot_tag | lane_tag);
-                        w.ntok += (uint32_t)__popcll(b);
-                    }
+                        for (int u = 0; u < kGuideUnroll; ++u) {
+                            const uint32_t ry = uniform(rd[u].y);
+                            // what is left of max_mm for the compared positions against this chunk's class (seed_enum_kernel)
+                            uint32_t budget;
+                            asm("s_bfe_u32 %0, %1, %2" : "=s"(budget) : "s"(ry), "s"(budget_field) : "scc");
+                            if (budget == kListNoBudget) continue;  // list padding, or a read that cannot reach this class
+                            const uint32_t rx = uniform(rd[u].x);
+                            const uint32_t word = sliced_within<kSeg>(v, rx, budget, valid, kv);
+                            const uint64_t b = __ballot(word != 0);
+                            if (b == 0) continue;
+                            const uint32_t gid = ry & kTokReadMask;
+                            if (word != 0)
+                                w.tok[ring_slot(lanes_below(b, ring_tail(w)))] = make_uint2(word, gid | slot_tag | lane_tag);
+                            w.ntok += (uint32_t)__popcll(b);
+                        }
+                    };
+                    if (seg == 0) compare_group(std::integral_constant<uint32_t, 0>{});
+                    else if (seg == 1) compare_group(std::integral_constant<uint32_t, 1>{});
+                    else compare_group(std::integral_constant<uint32_t, 2>{});
                     // a group of four reads adds at most 4 x 64 tokens, a resolve leaves fewer than 64
                     if (w.ntok >= (uint32_t)kSlicedResolve * kWave) sliced_resolve<false>(a, w);
                 }
