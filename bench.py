@@ -690,8 +690,8 @@ def main():
             nbr = lambda k: 0 if k < 0 else (1, 22, 211)[k]
             k01 = (max_mm - 1) // 3 if max_mm else 0
             list_entries = n_guides * (2 * nbr(k01) + nbr(max_mm - 2 * k01 - 2) + nbr(max_mm - 1 - 2 * k01 - 2))
-            structure_bytes = float(stream_bytes) + 16.0 * list_entries + 16.0 * hits_local
-            structure_model = ("bit-sliced sites of the visited buckets (3.5 B each, read once) + read-list entries (16 B each) + "
+            structure_bytes = float(stream_bytes) + 8.0 * list_entries + 16.0 * hits_local
+            structure_model = ("bit-sliced sites of the visited buckets (3.5 B each, read once) + read-list entries (8 B each) + "
                                "per hit one 8 B site record read and one 8 B record written")
         compares = float(pairs_local)
         lane_ops = compares * ops_per_compare / (scan_avg_ms * 1e-3)

@@ -1301,15 +1301,15 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         const uint64_t list_cap = n_pairs + (uint64_t)kLists * (kGuideUnroll - 1) + 2 * kGuideUnroll;
         VSC_HIP_H(ctx->seed_off.ensure((kLists + 1) * sizeof(uint32_t)));
         VSC_HIP_H(ctx->seed_poff.ensure((kLists + 1) * sizeof(uint32_t)));
-        VSC_HIP_H(ctx->seed_lrest.ensure(list_cap * sizeof(uint4)));
-        VSC_HIP_H(hipMemsetAsync(ctx->seed_lrest.p, 0xFF, list_cap * sizeof(uint4), ctx->stream));  // padding: y = ~0, skipped
+        VSC_HIP_H(ctx->seed_lrest.ensure(list_cap * sizeof(uint2)));
+        VSC_HIP_H(hipMemsetAsync(ctx->seed_lrest.p, 0xFF, list_cap * sizeof(uint2), ctx->stream));  // padding: y = ~0, skipped
         VSC_HIP_H(launch_seed_lists((const uint2 *)ctx->guides.p, n_guides, plan, (uint32_t *)ctx->seed_off.p, (uint32_t *)ctx->seed_poff.p,
-                                    (uint4 *)ctx->seed_lrest.p, ctx->stream));
+                                    (uint2 *)ctx->seed_lrest.p, ctx->stream));
         VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
         sa.chunk_tab = genome->d_ix_chunk_tab;
         sa.n_chunks = genome->ix_chunks;
         sa.vert = genome->d_ix_vert;
-        sa.list_rest = (const uint4 *)ctx->seed_lrest.p;
+        sa.list_rest = (const uint2 *)ctx->seed_lrest.p;
         sa.sites = genome->d_ix_sites;
         sa.edge_bits = genome->d_ix_edge;
         sa.guides = (const uint2 *)ctx->guides.p;

@@ -235,7 +235,7 @@ struct SeedPlan {
 struct SeedArgs {
     const uint4 *chunk_tab;        // [n_chunks] {first site, site count, bucket | first '-' rank << 16 | edge << 28 | class << 29, first vertical block}
     const uint32_t *vert;          // bit-sliced copies of the sites: kVertWords words per block of 32 sites (see seed_transpose_kernel)
-    const uint4 *list_rest;        // per list entry {rest(hi) | rest(lo) << 16, read | budget per class << 16 .., hi, lo}
+    const uint2 *list_rest;        // per list entry {rest(hi) | rest(lo) << 16, read | budget per class << 16 ..}
     const uint2 *sites;            // {rest(hi) | rest(lo) << 16, position} per site
     const uint32_t *edge_bits;     // 1 bit per site: its window is followed by N
     const uint2 *guides;           // (hi plane, lo plane) per read
@@ -343,7 +343,7 @@ hipError_t launch_plane_hash(const uint32_t *hi, const uint32_t *lo, const uint3
                              hipStream_t stream);
 // vsc_seed.hip
 hipError_t launch_seed_keys(const uint4 *rec, uint64_t n, int seg, uint32_t pam_codes, uint32_t n_pam, uint64_t *sort_records, hipStream_t stream);
-hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, const SeedPlan &plan, uint32_t *count, uint32_t *poff, uint4 *list_rest,
+hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, const SeedPlan &plan, uint32_t *count, uint32_t *poff, uint2 *list_rest,
                              hipStream_t stream);
 hipError_t launch_seed_pack16(const uint32_t *x, const uint32_t *l, const uint32_t *pos, uint64_t n, uint4 *rec, hipStream_t stream);
 hipError_t launch_seed_gather16(const uint4 *rec, const uint64_t *sorted, uint64_t n, uint4 *out, hipStream_t stream);

@@ -206,15 +206,14 @@ __device__ __forceinline__ uint32_t rest_of(uint32_t v, uint32_t seg)
 }
 
 // One thread per (read, segment, neighbour).  kScatter = false: count[list]++.  kScatter = true: the list entry goes to
-// poff[list] + (cursor[list]++) - x = rest(hi) | rest(lo) << 16, y = read index | per class: budget << (16 + 4 c), z / w =
-// the full hi / lo planes.
+// poff[list] + (cursor[list]++) - x = rest(hi) | rest(lo) << 16, y = read index | per class: budget << (16 + 4 c).
 // budget = what the comparison may still spend on the 14 positions of the other two segments against a site of class c:
 // max_mm - mismatches of the read's last two letters with the class's PAM - seed distance (15: the read has nothing to do
 // with that class).  Segments 0 and 1 keep ONE list per bucket, whose entries serve every class; segment 2 a list per
 // (class, bucket), because which of its neighbours a read visits depends on what the class leaves it (SeedPlan).
 template <bool kScatter>
 __global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uint32_t n_guides, const SeedPlan plan, uint32_t *count,
-                                                        const uint32_t *poff, uint4 *list_rest)
+                                                        const uint32_t *poff, uint2 *list_rest)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total = (uint64_t)n_guides * kSegments * plan.n_nbr;
@@ -244,11 +243,11 @@ __global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uin
         }
         const uint32_t list = b + c * (uint32_t)kBucketsPerSeg;  // b = 2 x 16384 + code
         const uint32_t at = atomicAdd(&count[list], 1u);
-        if (kScatter) list_rest[poff[list] + at] = make_uint4(rest, g | ((kNone & ~(15u << field)) | ((left - d) << field)), gp.x, gp.y);
+        if (kScatter) list_rest[poff[list] + at] = make_uint2(rest, g | ((kNone & ~(15u << field)) | ((left - d) << field)));
     }
     if (s < 2 && shared != kNone) {
         const uint32_t at = atomicAdd(&count[b], 1u);
-        if (kScatter) list_rest[poff[b] + at] = make_uint4(rest, g | shared, gp.x, gp.y);
+        if (kScatter) list_rest[poff[b] + at] = make_uint2(rest, g | shared);
     }
 }
 
@@ -281,14 +280,14 @@ __global__ __launch_bounds__(1024) void seed_pad_scan_kernel(uint32_t *count, ui
 
 // count: kLists words of scratch; poff: kLists + 1 list starts (multiples of kGuideUnroll); list_rest: the lists,
 // pre-filled with the padding pattern (y = ~0) by the caller
-hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, const SeedPlan &plan, uint32_t *count, uint32_t *poff, uint4 *list_rest,
+hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, const SeedPlan &plan, uint32_t *count, uint32_t *poff, uint2 *list_rest,
                              hipStream_t stream)
 {
     const uint64_t total = (uint64_t)n_guides * kSegments * plan.n_nbr;
     hipError_t e = hipMemsetAsync(count, 0, (size_t)kLists * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (total) hipLaunchKernelGGL(seed_enum_kernel<false>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, plan, count, (const uint32_t *)nullptr, (uint4 *)nullptr);
+    if (total) hipLaunchKernelGGL(seed_enum_kernel<false>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, plan, count, (const uint32_t *)nullptr, (uint2 *)nullptr);
     hipLaunchKernelGGL(seed_pad_scan_kernel, dim3(1), dim3(1024), 0, stream, count, poff);
     if (total) hipLaunchKernelGGL(seed_enum_kernel<true>, dim3(blocks), dim3(256), 0, stream, guides, n_guides, plan, count, (const uint32_t *)poff, list_rest);
     return hipGetLastError();
@@ -298,6 +297,8 @@ hipError_t launch_seed_lists(const uint2 *guides, uint32_t n_guides, const SeedP
 // bit-sliced comparison
 // ------------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
+typedef uint32_t v8u __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) v8u *const_v8u_ptr;  // a group of four 8-byte list entries, scalar-loaded
 
 struct SeedWave {
     uint2 *tok;      // pending hit tokens (see sliced_fetch)
@@ -706,17 +707,17 @@ __device__ __forceinline__ void sliced_resolve(const SeedArgs &a, SeedWave &w)
         f = nf;
         have = n != 0;
     }
+    // (wave-uniform, but computed on the vector unit in here: handed back as scalars, or the comparison loop's token
+    // bookkeeping - three instructions per read - stays on the vector unit as well)
+    w.ntok = uniform(w.ntok);
+    w.thead = uniform(w.thead);
 }
 
-// entry g0 + lane of a read list [g0, g1) (past the end: padding, y = ~0): its first half - rest planes, read |
-// budget per class; the read's full planes in the second half are for the enumeration's own use
+// entry g0 + lane of a read list [g0, g1) (past the end: padding, y = ~0): rest planes, read | budget per class
 __device__ __forceinline__ uint2 sliced_load_list(const SeedArgs &a, uint32_t g0, uint32_t g1, uint32_t lane)
 {
     uint2 e = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (g0 + lane < g1) {
-        const uint4 *const at = a.list_rest + (g0 + lane);
-        e = *(const uint2 *)at;
-    }
+    if (g0 + lane < g1) e = a.list_rest[g0 + lane];
     return e;
 }
 
@@ -775,6 +776,8 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     for (int i = 0; i < 2; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(kv[i]) : "s"(spread(a.k_seg, i)));
     const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
     const const_u32_ptr poff = (const_u32_ptr)(uintptr_t)a.poff;
+    const const_v8u_ptr lgrp = (const_v8u_ptr)(uintptr_t)a.list_rest;
+    constexpr bool kScalarLists = kShared;
     // the read list of a chunk (word z of its table entry): its bucket's, for segment 2 its class's list of that bucket
     auto list_of = [](uint32_t z) {
         const uint32_t bucket = z & kChunkBucketMask;
@@ -836,7 +839,10 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
         v4u t1 = ctab[min(first + 1, last - 1)];          // chunk c + 1
         uint32_t p0a, p0b;
         my_part(poff[list_of(t0.z)], poff[list_of(t0.z) + 1], wave_u, p0a, p0b);
-        uint2 nl = sliced_load_list(a, p0a, p0b, w.lane);
+        uint2 nl = make_uint2(0u, 0u);
+        v8u ng = {};  // kScalarLists: the first group of the next chunk's part
+        if (kScalarLists) ng = lgrp[(p0a < p0b ? p0a : 0u) / (uint32_t)kGuideUnroll];
+        else nl = sliced_load_list(a, p0a, p0b, w.lane);
         uint32_t p1a = poff[list_of(t1.z)], p1b = poff[list_of(t1.z) + 1];
         v4u t2 = ctab[min(first + 2, last - 1)];          // chunk c + 2
         for (uint32_t c = first; c < last; ++c) {
@@ -848,7 +854,9 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
             t0 = t1;
             my_part(p1a, p1b, (wave_u + (c + 1 - first)) % (uint32_t)kWavesPerGroup, p0a, p0b);
             uint2 tile = nl;
-            nl = sliced_load_list(a, p0a, c + 1 < last ? p0b : p0a, w.lane);
+            v8u grp = ng;
+            if (kScalarLists) ng = lgrp[(p0a < p0b && c + 1 < last ? p0a : 0u) / (uint32_t)kGuideUnroll];
+            else nl = sliced_load_list(a, p0a, c + 1 < last ? p0b : p0a, w.lane);
             t1 = t2;
             p1a = poff[list_of(t1.z)];
             p1b = poff[list_of(t1.z) + 1];
@@ -860,7 +868,8 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
                 w.info[c - first] = cur.z;
             }
             wave_sync();
-            const uint32_t seg = (cur.z & kChunkBucketMask) / (uint32_t)kBucketsPerSeg;
+            // (uniform(): taken for divergent, the choice between the segments' copies of the comparison becomes three masked passes)
+            const uint32_t seg = uniform((cur.z & kChunkBucketMask) / (uint32_t)kBucketsPerSeg);
             // where an entry keeps the budget of this chunk's class: s_bfe_u32's operand (offset | width << 16)
             const uint32_t budget_field = uniform((kListBudgetShift + 4u * ((cur.z >> kChunkClassShift) & 3u)) | (4u << 16));
             // sites of this lane's block that exist
@@ -869,7 +878,57 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
             pairs += (unsigned long long)cur.y * (g1 - g0);
             // (the block of a shared chunk comes from HBM once: counted by the wave of rank 0)
             if (!kShared || (wave_u + (c - first)) % (uint32_t)kWavesPerGroup == 0) visited += cur.y;
-            // The read list goes through LDS in tiles of 64 entries: one coalesced vector load per tile,
+            // the four comparisons of a group of list entries (ex, ey: wave-uniform).  The duplicate test differs by segment - none,
+            // group A, groups A and B; left as a run-time `if` inside the comparison the compiler computes all of it and
+            // selects: one copy of the four comparisons per segment
+            auto compare_four = [&](const uint32_t (&ex)[kGuideUnroll], const uint32_t (&ey)[kGuideUnroll]) {
+                // first free ring slot and tokens added, as scalars for the length of the group (s_add by hand: left to the
+                // compiler the wave's token counters live in vector registers - the resolve computes them there - and every
+                // read pays three vector instructions for their bookkeeping)
+                const uint32_t tail0 = uniform(w.thead + w.ntok);
+                uint32_t tail = tail0;
+                auto compare_group = [&](auto segment) {
+                    constexpr uint32_t kSeg = decltype(segment)::value;
+#pragma unroll
+                    for (int u = 0; u < kGuideUnroll; ++u) {
+                        const uint32_t ry = ey[u];
+                        // what is left of max_mm for the compared positions against this chunk's class (seed_enum_kernel)
+                        uint32_t budget;
+                        asm("s_bfe_u32 %0, %1, %2" : "=s"(budget) : "s"(ry), "s"(budget_field) : "scc");
+                        if (budget == kListNoBudget) continue;  // list padding, or a read that cannot reach this class
+                        const uint32_t word = sliced_within<kSeg>(v, ex[u], budget, valid, kv);
+                        const uint64_t b = __ballot(word != 0);
+                        if (b == 0) continue;
+                        const uint32_t gid = ry & kTokReadMask;
+                        if (word != 0) w.tok[ring_slot(lanes_below(b, tail))] = make_uint2(word, gid | slot_tag | lane_tag);
+                        const uint32_t cnt = (uint32_t)__popcll(b);
+                        const uint32_t tail_was = tail;  // (asm operands cannot name the captures themselves)
+                        uint32_t tail_now;
+                        asm("s_add_i32 %0, %1, %2" : "=s"(tail_now) : "s"(tail_was), "s"(cnt) : "scc");
+                        tail = tail_now;
+                    }
+                };
+                if (seg == 0) compare_group(std::integral_constant<uint32_t, 0>{});
+                else if (seg == 1) compare_group(std::integral_constant<uint32_t, 1>{});
+                else compare_group(std::integral_constant<uint32_t, 2>{});
+                w.ntok += tail - tail0;
+                // a group of four reads adds at most 4 x 64 tokens, a resolve leaves fewer than 64
+                if (w.ntok >= (uint32_t)kSlicedResolve * kWave) sliced_resolve<false>(a, w);
+            };
+            if (kScalarLists) {
+                // Dense searches (the chunk-sharing kernel: a wave's part of a list is ~30 entries): the entries come as scalar
+                // loads of a whole group (32 bytes), the next group requested before the current one is compared - no LDS
+                // tile, no broadcast read, no v_readfirstlane per entry (two vector instructions per read in a kernel that
+                // is bound by them).  The first group of a chunk's part was requested a chunk ago.
+                for (uint32_t gi = g0; gi < g1; gi += kGuideUnroll) {
+                    const v8u e = grp;
+                    grp = lgrp[(gi + kGuideUnroll < g1 ? gi + kGuideUnroll : gi) / (uint32_t)kGuideUnroll];
+                    const uint32_t ex[kGuideUnroll] = {e[0], e[2], e[4], e[6]}, ey[kGuideUnroll] = {e[1], e[3], e[5], e[7]};
+                    compare_four(ex, ey);
+                }
+                continue;
+            }
+            // Sparse searches: the read list goes through LDS in tiles of 64 entries: one coalesced vector load per tile,
             // issued a whole tile (or chunk) ahead, then one broadcast LDS read per entry.  Scalar loads of
             // the entries, a group at a time, left ~1 us of scalar-cache miss latency per group exposed
             // whenever a bucket has only a handful of reads.
@@ -883,32 +942,13 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
                     uint2 rd[kGuideUnroll];
 #pragma unroll
                     for (int u = 0; u < kGuideUnroll; ++u) rd[u] = lt[gi + u];  // same address in every lane
-                    // (the duplicate test differs by segment - none, group A, groups A and B; left as a run-time `if` inside
-                    // the comparison the compiler computes all of it and selects: one copy of the four comparisons per segment)
-                    auto compare_group = [&](auto segment) {
-                        constexpr uint32_t kSeg = decltype(segment)::value;
+                    uint32_t ex[kGuideUnroll], ey[kGuideUnroll];
 #pragma unroll
-                        for (int u = 0; u < kGuideUnroll; ++u) {
-                            const uint32_t ry = uniform(rd[u].y);
-                            // what is left of max_mm for the compared positions against this chunk's class (seed_enum_kernel)
-                            uint32_t budget;
-                            asm("s_bfe_u32 %0, %1, %2" : "=s"(budget) : "s"(ry), "s"(budget_field) : "scc");
-                            if (budget == kListNoBudget) continue;  // list padding, or a read that cannot reach this class
-                            const uint32_t rx = uniform(rd[u].x);
-                            const uint32_t word = sliced_within<kSeg>(v, rx, budget, valid, kv);
-                            const uint64_t b = __ballot(word != 0);
-                            if (b == 0) continue;
-                            const uint32_t gid = ry & kTokReadMask;
-                            if (word != 0)
-                                w.tok[ring_slot(lanes_below(b, ring_tail(w)))] = make_uint2(word, gid | slot_tag | lane_tag);
-                            w.ntok += (uint32_t)__popcll(b);
-                        }
-                    };
-                    if (seg == 0) compare_group(std::integral_constant<uint32_t, 0>{});
-                    else if (seg == 1) compare_group(std::integral_constant<uint32_t, 1>{});
-                    else compare_group(std::integral_constant<uint32_t, 2>{});
-                    // a group of four reads adds at most 4 x 64 tokens, a resolve leaves fewer than 64
-                    if (w.ntok >= (uint32_t)kSlicedResolve * kWave) sliced_resolve<false>(a, w);
+                    for (int u = 0; u < kGuideUnroll; ++u) {
+                        ex[u] = uniform(rd[u].x);
+                        ey[u] = uniform(rd[u].y);
+                    }
+                    compare_four(ex, ey);
                 }
             }
         }
