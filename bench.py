@@ -492,8 +492,8 @@ def main():
 
     # per-step sums of the library's device timings (vsc_timing): every step function returns
     # (objects to close, records of this rank's final result, sums)
-    T_SUM = ("scan_ms", "sort_ms", "finalize_ms", "prep_ms", "score_ms", "hits", "pairs", "genome_bytes", "sort_bytes")
-    T_MAX = ("sort_levels", "sort_bin_bits", "passes", "sites", "read_passes")
+    T_SUM = ("scan_ms", "sort_ms", "finalize_ms", "prep_ms", "score_ms", "hits", "pairs", "genome_bytes", "sort_bytes", "list_entries")
+    T_MAX = ("sort_levels", "sort_bin_bits", "passes", "sites", "read_passes", "seed_cut")
 
     def new_acc():
         return dict.fromkeys(T_SUM + T_MAX, 0)
@@ -684,12 +684,9 @@ def main():
             structure_model = "planes streamed once per pass (0.375 B/base) + 12 B per hit written + 8 B per read"
         else:
             kernel, ops_per_compare = "seed_sliced_kernel", LANE_OPS_PER_COMPARE["sliced"]
-            # read-list entries (SeedPlan, vsc_internal.h): segments 0 and 1 within k01 substitutions, one entry for all PAM
-            # classes; segment 2 per class within what the class leaves - the synthetic reads end in GG: GG sites leave
-            # max_mm, GA sites max_mm - 1
-            nbr = lambda k: 0 if k < 0 else (1, 22, 211)[k]
-            k01 = (max_mm - 1) // 3 if max_mm else 0
-            list_entries = n_guides * (2 * nbr(k01) + nbr(max_mm - 2 * k01 - 2) + nbr(max_mm - 1 - 2 * k01 - 2))
+            # read-list entries: as many as the library made (vsc_timing.list_entries; the cut of the pigeonhole - SeedPlan,
+            # vsc_internal.h - is its cost model's choice: vsc_timing.seed_cut)
+            list_entries = sums["list_entries"] / args.steps
             structure_bytes = float(stream_bytes) + 8.0 * list_entries + 16.0 * hits_local
             structure_model = ("bit-sliced sites of the visited buckets (3.5 B each, read once) + read-list entries (8 B each) + "
                                "per hit one 8 B site record read and one 8 B record written")
@@ -800,6 +797,9 @@ def main():
             "kernels_ms": {"search": scan_avg_ms, "prep": sums["prep_ms"] / args.steps, "sort": sums["sort_ms"] / args.steps,
                            "finalize": sums["finalize_ms"] / args.steps,
                            "score": (sums["score_ms"] / args.steps) if streamed else None},
+            "seed_cut": (None if algorithm == "scan" else
+                         {"segments_0_1_within": sums["seed_cut"], "segment_2_within": "what the site's PAM leaves of the limit - 2 x %d - 2" % sums["seed_cut"],
+                          "list_entries_per_step": sums["list_entries"] / args.steps, "chosen_by": "the library's cost model (vsc_api.cpp)"}),
             "setup": {"genome_generate_s": t_gen, "genome_hbm_bytes": genome.device_bytes, "index_build_ms": index_ms},
         }
         if exchanges is not None:

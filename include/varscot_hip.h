@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VSC_ABI_VERSION 4
+#define VSC_ABI_VERSION 5
 
 #define VSC_OK 0
 #define VSC_ERR_INVALID (-22)  /* EINVAL: bad argument (e.g. mismatches outside 0..8)          */
@@ -114,6 +114,10 @@ typedef struct {
     uint32_t read_passes;    /* passes over the read set (a pass takes at most 16 384 reads) */
     uint32_t sort_fallbacks; /* sort levels that started without a histogram pass (fixed bin slots) and had to run again with
                                 one because a bin outgrew its slot (repeat-rich genomes; the genome remembers) */
+    uint64_t list_entries;   /* VSC_ALGO_SEED: entries of the per-bucket read lists the last pass made (8 bytes each, padding included) */
+    uint32_t seed_cut;       /* VSC_ALGO_SEED: substitutions within which read segments 0 and 1 were searched (the third: what the
+                                site's PAM leaves of the limit - 2 x this - 2) */
+    uint32_t reserved;
 } vsc_timing;
 
 /* ---- context ------------------------------------------------------------------------------- */

@@ -31,7 +31,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared | declared_dbg:
         assert hasattr(L, name), name
     version = int(re.search(r"#define\s+VSC_ABI_VERSION\s+(\d+)", text).group(1))
-    assert va.lib().vsc_abi_version() == version == 4
+    assert va.lib().vsc_abi_version() == version == 5
 
 
 def test_the_library_reads_no_environment_variable():

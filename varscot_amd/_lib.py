@@ -40,7 +40,8 @@ class Timing(C.Structure):
                 ("index_ms", C.c_double), ("sites", C.c_uint64), ("pairs", C.c_uint64), ("hits", C.c_uint64),
                 ("genome_bytes", C.c_uint64), ("passes", C.c_uint32), ("algorithm", C.c_uint32),
                 ("sort_bytes", C.c_uint64), ("sort_levels", C.c_uint32), ("sort_bin_bits", C.c_uint32),
-                ("read_passes", C.c_uint32), ("sort_fallbacks", C.c_uint32)]
+                ("read_passes", C.c_uint32), ("sort_fallbacks", C.c_uint32), ("list_entries", C.c_uint64), ("seed_cut", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -450,6 +450,8 @@ void free_index(vsc_genome *g)
     g->ix_chunks = 0;
 }
 
+void class_counts(vsc_genome *g, const std::vector<uint32_t> &ctab);
+
 // Builds the seed index of a resident genome: extract the PAM-valid sites of both strands, then file
 // them once per segment in bucket order.  All temporaries are released before returning.
 hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *params, std::string *why)
@@ -648,6 +650,7 @@ hipError_t build_index(vsc_ctx *ctx, vsc_genome *g, const vsc_search_params *par
         }
     }
     g->ix_chunks = (uint32_t)(ctab.size() / 4);
+    class_counts(g, ctab);
     const size_t cb = std::max<size_t>(ctab.size(), 4) * sizeof(uint32_t);
     const size_t vb = std::max<uint64_t>(n_blocks, 1) * kVertWords * sizeof(uint32_t);
     step(hipMalloc((void **)&g->d_ix_chunk_tab, cb));
@@ -760,6 +763,18 @@ bool chunk_table_ok(const std::vector<uint32_t> &ctab, uint64_t S, uint64_t vert
         return false;
     }
     return true;
+}
+
+// sites and chunks per PAM class (what the search's cost model wants to know about the index)
+void class_counts(vsc_genome *g, const std::vector<uint32_t> &ctab)
+{
+    for (int c = 0; c < 4; ++c) g->ix_class_sites[c] = g->ix_class_chunks[c] = 0;
+    for (size_t c = 0; c * 4 < ctab.size(); ++c) {
+        const uint32_t cls = ctab[4 * c + 2] >> kChunkClassShift;
+        g->ix_class_sites[cls] += ctab[4 * c + 1];
+        g->ix_class_chunks[cls] += 1;
+    }
+    for (int c = 0; c < 4; ++c) g->ix_class_sites[c] /= kSegments;  // every site is filed once per table
 }
 
 struct FileCloser {
@@ -905,6 +920,7 @@ int vsc_genome_index_load(vsc_ctx *ctx, vsc_genome *genome, const char *path)
             free_index(genome);
             return fail(ctx, VSC_ERR_INVALID, (std::string("vsc_genome_index_load: ") + path + " is damaged (" + why + ")").c_str());
         }
+        class_counts(genome, ctab);
     }
     genome->ix_chunks = h.chunks;
     genome->ix_vert_bytes = vb;
@@ -1282,10 +1298,6 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         auto nbr = [](int k) { return k < 0 ? 0u : (k == 0 ? 1u : (k == 1 ? 22u : 211u)); };
         SeedPlan plan{};
         plan.max_mm = m;
-        plan.tight = ctx->dbg.seed_tight != 0;
-        plan.k01 = plan.tight ? (m ? (m - 1) / kSegments : 0u) : m / kSegments;
-        const int k2_max = plan.tight ? (int)m - 2 * (int)plan.k01 - 2 : (int)plan.k01;
-        plan.n_nbr = nbr(std::max<int>((int)plan.k01, k2_max));
         {
             ScanArgs pa{};
             vsc_search_params ip{};
@@ -1296,6 +1308,66 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
             plan.n_pam = pa.n_pam;
             plan.pam_codes = pam_code_set(pa);
         }
+        plan.tight = ctx->dbg.seed_tight != 0;
+        int k2_max = 0;
+        if (!plan.tight) {
+            plan.k01 = m / kSegments;
+            k2_max = (int)plan.k01;
+        } else {
+            // reads per (class, what the class leaves them for positions 0..20)
+            uint32_t left_reads[kSeedClasses][VSC_MAX_MISMATCHES + 1] = {};
+            int left_max = -1;
+            for (uint32_t i = 0; i < n_guides; ++i) {
+                const uint32_t x = gp[2 * (size_t)i], l = gp[2 * (size_t)i + 1];
+                const uint32_t mine = (((x >> 21) & 1u) << 3) | (((l >> 21) & 1u) << 2) | (((x >> 22) & 1u) << 1) | ((l >> 22) & 1u);
+                for (uint32_t c = 0; c < plan.n_pam; ++c) {
+                    const uint32_t diff = mine ^ ((plan.pam_codes >> (4 * c)) & 15u);
+                    const uint32_t spent = ((diff & 12u) ? 1u : 0u) + ((diff & 3u) ? 1u : 0u);
+                    if (spent > m) continue;
+                    left_reads[c][m - spent]++;
+                    left_max = std::max(left_max, (int)(m - spent));
+                }
+            }
+            // Every k01 in 0..2 that keeps the third threshold within two substitutions is a valid cut; they differ in what they
+            // cost.  Fewer buckets per read = fewer comparisons (what a dense search is bound by: c3), but a table whose lists
+            // are short still has nearly all of its chunks loaded for a read or two each (what a sparse search is bound by: at
+            // 1 000 reads and m = 6 the cut (2, 2, 0) compares 2.6 x the pairs of (1, 1, 2) and loads 17 % fewer blocks).
+            // cost = max(block bytes at 4.2 TB/s, chunk visits x 215 SIMD-cycles over all SIMDs at 2 GHz)
+            double cost[3] = {-1, -1, -1};  // < 0: not a valid cut
+            for (int k = 0; k <= 2; ++k) {
+                if (left_max - 2 * k - 2 > 2) continue;
+                double bytes = 0, visits = 0, chunks_all = 0, sites_all = 0;
+                uint64_t reads_any = 0;
+                for (uint32_t c = 0; c < plan.n_pam; ++c) {
+                    const double chunks_c = (double)genome->ix_class_chunks[c] / kSegments;
+                    chunks_all += chunks_c;
+                    sites_all += (double)genome->ix_class_sites[c];
+                    double e2 = 0;  // entries of class c's lists of segment 2
+                    uint64_t reads_c = 0;
+                    for (int left = 0; left <= (int)m; ++left) {
+                        e2 += (double)left_reads[c][left] * nbr(left - 2 * k - 2);
+                        reads_c += left_reads[c][left];
+                    }
+                    reads_any = std::max(reads_any, reads_c);
+                    const double per_list = e2 / kBucketsPerSeg;
+                    bytes += (1.0 - std::exp(-per_list)) * (double)genome->ix_class_sites[c] * kVertWords * 4 / kSlicedSites;
+                    visits += per_list * chunks_c;
+                }
+                const double per_list01 = (double)reads_any * nbr(k) / kBucketsPerSeg;
+                bytes += 2 * (1.0 - std::exp(-per_list01)) * sites_all * kVertWords * 4 / kSlicedSites;
+                visits += 2 * per_list01 * chunks_all;
+                cost[k] = std::max(bytes / 4.2e12, visits * 215.0 / ((double)ctx->n_cus * 4 * 2.0e9));
+            }
+            int best_k = -1;
+            for (int k = 0; k <= 2; ++k)
+                if (cost[k] >= 0 && (best_k < 0 || cost[k] < cost[best_k])) best_k = k;
+            const int forced = ctx->dbg.seed_tight >= 1 ? ctx->dbg.seed_tight - 1 : -1;  // hook: 1 + k01
+            if (forced >= 0 && forced <= 2 && cost[forced] >= 0) best_k = forced;
+            if (best_k < 0) best_k = (int)(m ? (m - 1) / kSegments : 0u);  // (no read can reach any class: nothing to search)
+            plan.k01 = (uint32_t)best_k;
+            k2_max = std::min<int>(2, (int)m - 2 * best_k - 2);
+        }
+        plan.n_nbr = nbr(std::max<int>((int)plan.k01, k2_max));
         // entries: one per (read, neighbour within k01) of segments 0 and 1, one per class and neighbour of segment 2
         const uint64_t n_pairs = (uint64_t)n_guides * (2 * nbr((int)plan.k01) + plan.n_pam * nbr(k2_max));
         const uint64_t list_cap = n_pairs + (uint64_t)kLists * (kGuideUnroll - 1) + 2 * kGuideUnroll;
@@ -1382,9 +1454,16 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         }
         VSC_HIP_H(hipEventRecord(ctx->ev[2], ctx->stream));
         VSC_HIP_H(hipMemcpyAsync(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+        uint32_t list_total = 0;
+        if (algo == VSC_ALGO_SEED)
+            VSC_HIP_H(hipMemcpyAsync(&list_total, (const uint32_t *)ctx->seed_poff.p + kLists, sizeof list_total, hipMemcpyDeviceToHost, ctx->stream));
         VSC_HIP_H(hipStreamSynchronize(ctx->stream));
         ht.lap("search kernel + sync");
         t.passes++;
+        if (algo == VSC_ALGO_SEED) {
+            t.list_entries = list_total;
+            t.seed_cut = sa.k_seg;
+        }
         if (!cnt[kCntOverflow]) break;
         if (tries >= 2) return fail(ctx, VSC_ERR_DEVICE, "vsc_search: hit buffer overflowed repeatedly");
         // the counters hold the true totals (SEED: records placed + records lost per region, + one block per wave)

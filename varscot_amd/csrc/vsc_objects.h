@@ -120,6 +120,8 @@ struct vsc_genome {
     uint2 *d_ix_sites = nullptr;    // 8-byte site records {rest planes, position}
     uint32_t *d_ix_edge = nullptr;  // 1 bit per site: window followed by N
     uint32_t ix_chunks = 0;
+    uint64_t ix_class_sites[4] = {};   // sites per PAM class in one table, chunks per class over all three (the search's cost model)
+    uint64_t ix_class_chunks[4] = {};
     uint64_t ix_vert_bytes = 0, ix_edge_words = 0;  // sizes of d_ix_vert / d_ix_edge (the index file stores them)
     uint64_t index_bytes = 0;
     double index_ms = 0;
