@@ -9,7 +9,7 @@
 //
 //   bin_hist_kernel       one streaming read: records per (region, bin), bin = the top <= 11 key bits
 //   bin_scan_kernel       bin starts (exclusive scan per region)
-//   bin_partition_kernel  one read + one write: a workgroup takes a tile of 16 384 records, ranks them per bin
+//   bin_partition_kernel  one read + one write: a workgroup takes a tile of 8 192 records, ranks them per bin
 //                         with LDS atomics, reserves room in every bin with one coalesced returning atomic
 //                         per bin, regroups the tile by bin in LDS and writes each bin's records as one
 //                         contiguous piece.  Pieces of different tiles land in a bin in arbitrary order.
@@ -204,7 +204,11 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
 {
     __shared__ uint64_t s_rec[kSortTile];
     __shared__ uint32_t s_cnt[(1 << kSortMaxBinBits) + kWave];  // records per bin, then their first slot in s_rec (+ spares)
-    __shared__ uint32_t s_gbase[1 << kSortMaxBinBits];  // where this tile's records of a bin go in the bin
+    // Where this tile's records of a bin go in the bin: a thread keeps the answers of the bins it asked for in registers
+    // until the tile is regrouped, then s_cnt[b] becomes "destination of slot i, less i" (a second table of 8 KB would
+    // keep two workgroups from sharing a CU's LDS).  Level 0 (kPairs) looks bins up in the scanned counters: it keeps both.
+    __shared__ uint32_t s_gbase[kPairs ? (1 << kSortMaxBinBits) : 1];
+    __shared__ uint32_t s_over[(1 << kSortMaxBinBits) / 32 + 1];  // slot mode: bins that outgrew their slot (nothing is written for them); [last]: any
     __shared__ uint32_t s_wave[kSortThreads / kWave];
     const uint32_t t = threadIdx.x;
     const uint32_t nbins = 1u << a.bin_bits;
@@ -221,6 +225,7 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
     const uint32_t first = (tile - a.seg_tile0[seg]) * (uint32_t)kSortTile;
     const uint32_t n = min(sg.n_in - first, (uint32_t)kSortTile);
     for (uint32_t b = t; b < nbins + kWave; b += kSortThreads) s_cnt[b] = 0;
+    for (uint32_t b = t; b < (1u << kSortMaxBinBits) / 32u + 1u; b += kSortThreads) s_over[b] = 0;
     block_sync();
     // records of the tile in registers; sentinels (and the slots past the tile) take no part.  Branch-free on
     // purpose (clamped loads + selects): with conditional stores into r[] / bin[] the compiler keeps the arrays
@@ -256,20 +261,39 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
     }
     block_sync();
     // room in the bins: consecutive lanes take consecutive bins (one coalesced returning atomic per 64 bins)
-    for (uint32_t b = t; b < nbins; b += kSortThreads) {
-        const uint32_t c = s_cnt[b];
+    constexpr int kOwnBins = (1 << kSortMaxBinBits) / kSortThreads;
+    uint32_t own_at[kOwnBins];
+#pragma unroll
+    for (int j = 0; j < kOwnBins; ++j) {
+        const uint32_t b = t + (uint32_t)j * kSortThreads;
+        const uint32_t c = b < nbins ? s_cnt[b] : 0u;
         uint32_t at = c ? atomicAdd(&a.cursor[((size_t)seg << a.bin_bits) + b], c) : 0u;
         if (a.slot_cap && c && at + c > a.slot_cap) {  // the bin outgrew its slot: this level is repeated with a histogram
             atomicOr(a.overflow, 1u);
-            at = 0xFFFFFFFFu;
+            atomicOr(&s_over[b >> 5], 1u << (b & 31u));
+            s_over[(1u << kSortMaxBinBits) / 32u] = 1u;
         }
-        s_gbase[b] = at;
+        own_at[j] = at;
+        if (kPairs && b < nbins) s_gbase[b] = at;
     }
     const uint32_t total = block_exclusive_scan<kSortThreads>(s_cnt, nbins, s_wave);  // barriers inside
 #pragma unroll
-    for (int k = 0; k < kSortItems; ++k)
-        if (!(r[k] >> 63)) s_rec[s_cnt[bin[k] & 0xFFFFu] + (bin[k] >> 16)] = r[k];
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t slot = s_cnt[bin[k] & 0xFFFFu] + (bin[k] >> 16);
+        if (!(r[k] >> 63)) s_rec[slot] = r[k];
+        if (kSide) bin[k] = slot;  // (the side word follows into the same slot, when s_cnt no longer holds the bins' first slots)
+    }
     block_sync();
+    if (!kPairs) {
+        // slot i of the regrouped tile, a record of bin b, goes to record s_cnt[b] + i of the bin's place (the sum wraps)
+#pragma unroll
+        for (int j = 0; j < kOwnBins; ++j) {
+            const uint32_t b = t + (uint32_t)j * kSortThreads;
+            if (b < nbins) s_cnt[b] = own_at[j] - s_cnt[b];
+        }
+        block_sync();
+    }
+    const bool any_over = s_over[(1u << kSortMaxBinBits) / 32u] != 0u;
     // the tile, grouped by bin: neighbouring lanes write neighbouring records of a bin
     uint32_t slot_bin[kSide ? kSortItems / 2 : 1];  // kSide: the bin of every slot this thread writes, two to a word
     if (kSide) {
@@ -290,10 +314,12 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
         } else {
             b = (uint32_t)(x >> a.bin_shift) & (nbins - 1u);
         }
+        const uint32_t in_bin = kPairs ? s_gbase[b] + (i - s_cnt[b]) : s_cnt[b] + i;
+        const bool skip = any_over && ((s_over[b >> 5] >> (b & 31u)) & 1u);
         if (a.slot_cap) {
-            if (s_gbase[b] != 0xFFFFFFFFu) a.out[(((uint64_t)seg << a.bin_bits) + b) * a.slot_cap + s_gbase[b] + (i - s_cnt[b])] = x;
+            if (!skip) a.out[(((uint64_t)seg << a.bin_bits) + b) * a.slot_cap + in_bin] = x;
         } else {
-            a.out[sg.out_off + s_gbase[b] + (i - s_cnt[b])] = x;
+            a.out[sg.out_off + in_bin] = x;
         }
         if (kSide) {
             const uint32_t j = i / kSortThreads;  // this thread's j-th slot
@@ -308,17 +334,19 @@ __global__ __launch_bounds__(kSortThreads) void bin_partition_kernel(const SortA
         uint32_t *const s_side = (uint32_t *)s_rec;
 #pragma unroll
         for (int k = 0; k < kSortItems; ++k)
-            if (!(r[k] >> 63)) s_side[s_cnt[bin[k] & 0xFFFFu] + (bin[k] >> 16)] = side[k];
+            if (!(r[k] >> 63)) s_side[bin[k]] = side[k];
         block_sync();
 #pragma unroll
         for (int j = 0; j < kSortItems; ++j) {
             const uint32_t i = t + (uint32_t)j * kSortThreads;
             if (i < total) {
                 const uint32_t b = (slot_bin[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                const uint32_t in_bin = s_cnt[b] + i;  // (kSide is never level 0)
+                const bool skip = any_over && ((s_over[b >> 5] >> (b & 31u)) & 1u);
                 if (a.slot_cap) {
-                    if (s_gbase[b] != 0xFFFFFFFFu) a.side_out[(((uint64_t)seg << a.bin_bits) + b) * a.slot_cap + s_gbase[b] + (i - s_cnt[b])] = s_side[i];
+                    if (!skip) a.side_out[(((uint64_t)seg << a.bin_bits) + b) * a.slot_cap + in_bin] = s_side[i];
                 } else {
-                    a.side_out[sg.out_off + s_gbase[b] + (i - s_cnt[b])] = s_side[i];
+                    a.side_out[sg.out_off + in_bin] = s_side[i];
                 }
             }
         }
