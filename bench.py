@@ -44,8 +44,8 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz (32-bit integer lane-ops / s)
 LANE_OPS_PER_COMPARE = {"scan": 3.5,     # v_xor + v_bitop3 + v_bcnt + 1/2 v_min3 per (site, read) pair
-                        "sliced": 1.875}  # 60 instructions per read and 32 sites: 15 x 2 mismatch vectors (read position 21 is the
-                                          # lists' business with the GG / GA PAM set) + 22 adder tree + 5 test + 3 duplicate test
+                        "sliced": 1.8125}  # 58 instructions per read and 32 sites: 14 x 2 mismatch vectors (the PAM positions are the
+                                           # chunk's class) + 22 adder tree + 5 test + 3 duplicate test (0 / 3 / 6 by segment)
 # measured issue cost of a vector instruction (tools/micro/valu_rate.hip -> profiles/r03_valu_rate_microbench.txt, cycles per
 # SIMD at 2.4 GHz with six waves resident): 2.6 with vector operands only, 4.2 with one scalar operand
 VALU_ISSUE_CYCLES = {"vector_operands": 2.6, "scalar_operand": 4.2}
