@@ -251,31 +251,57 @@ __global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uin
     }
 }
 
-// poff[b] = sum over b' < b of roundup4(count[b']); the counts are cleared for pass 2; one workgroup, kLists + 1 outputs
+// poff[b] = sum over b' < b of roundup4(count[b']); the counts are cleared for pass 2; one workgroup, kLists + 1 outputs.
+// A wave owns 5 120 consecutive lists: 80 coalesced rows of 64, all loaded before the first is looked at; every row is scanned
+// across the lanes by six DPP adds (no LDS), the rows' totals are chained on the scalar unit, the waves' totals meet in
+// LDS once.  (Round 3's form - a thread summing its 48 consecutive counters one dependent, uncoalesced load after the
+// other - took 0.17 ms: most of what a 1 000-read search spends on its lists.)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    // row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes (lanes without a source add 0), then lane 15 of rows 0 and 2 into
+    // rows 1 and 3 (row_bcast:15, rows 0b1010), then lane 31 into rows 2 and 3 (row_bcast:31, rows 0b1100)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+    return x;
+}
+
 __global__ __launch_bounds__(1024) void seed_pad_scan_kernel(uint32_t *count, uint32_t *poff)
 {
-    __shared__ uint32_t partial[1024];
-    constexpr uint32_t per = kLists / 1024;  // 80
-    static_assert(kLists % 1024 == 0, "lists per thread");
-    const uint32_t t = threadIdx.x;
-    uint32_t sum = 0;
-    for (uint32_t i = 0; i < per; ++i) sum += (count[t * per + i] + (kGuideUnroll - 1)) & ~(uint32_t)(kGuideUnroll - 1);
-    partial[t] = sum;
+    constexpr int kWaves = 1024 / kWave, kPerWave = kLists / kWaves, kRows = kPerWave / kWave;  // 16, 5 120, 80
+    static_assert(kLists % (kWaves * kWave) == 0 && kRows % 8 == 0, "whole rows per wave, eight at a time");
+    __shared__ uint32_t s_total[kWaves];
+    const uint32_t lane = threadIdx.x % kWave, wave = uniform(threadIdx.x / kWave);
+    uint32_t *const c = count + wave * kPerWave + lane;
+    auto padded = [](uint32_t n) { return (n + (uint32_t)(kGuideUnroll - 1)) & ~(uint32_t)(kGuideUnroll - 1); };
+    // pass 1: the wave's total (a lane adds up its column, the columns meet in the last lane of a scan)
+    uint32_t column = 0;
+#pragma unroll 16
+    for (int i = 0; i < kRows; ++i) column += padded(c[i * kWave]);
+    const uint32_t mine = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(column), kWave - 1);
+    if (lane == 0) s_total[wave] = mine;
     block_sync();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = t >= d ? partial[t - d] : 0;
-        block_sync();
-        partial[t] += v;
-        block_sync();
+    uint32_t run = 0;  // padded entries of all lists before row i of this wave
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) run += (uint32_t)w < wave ? s_total[w] : 0u;
+    // pass 2: the rows again (from L2), eight in flight
+    uint32_t *const p = poff + wave * kPerWave + lane;
+    for (int i0 = 0; i0 < kRows; i0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = padded(c[(i0 + j) * kWave]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t inc = wave_inclusive_scan(v[j]);
+            p[(i0 + j) * kWave] = run + inc - v[j];
+            c[(i0 + j) * kWave] = 0;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)inc, kWave - 1);
+        }
     }
-    uint32_t run = partial[t] - sum;  // exclusive prefix of this thread's range
-    for (uint32_t i = 0; i < per; ++i) {
-        const uint32_t b = t * per + i;
-        poff[b] = run;
-        run += (count[b] + (kGuideUnroll - 1)) & ~(uint32_t)(kGuideUnroll - 1);
-        count[b] = 0;
-    }
-    if (t == 1023) poff[kLists] = run;
+    if (threadIdx.x == 1023) poff[kLists] = run;
 }
 
 // count: kLists words of scratch; poff: kLists + 1 list starts (multiples of kGuideUnroll); list_rest: the lists,
