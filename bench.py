@@ -798,7 +798,8 @@ def main():
                            "finalize": sums["finalize_ms"] / args.steps,
                            "score": (sums["score_ms"] / args.steps) if streamed else None},
             "seed_cut": (None if algorithm == "scan" else
-                         {"segments_0_1_within": sums["seed_cut"], "segment_2_within": "what the site's PAM leaves of the limit - 2 x %d - 2" % sums["seed_cut"],
+                         {"segment_0_within": sums["seed_cut"] & 15, "segment_1_within": sums["seed_cut"] >> 4,
+                          "segment_2_within": "what the site's PAM leaves of the limit - %d - %d - 2" % (sums["seed_cut"] & 15, sums["seed_cut"] >> 4),
                           "list_entries_per_step": sums["list_entries"] / args.steps, "chosen_by": "the library's cost model (vsc_api.cpp)"}),
             "setup": {"genome_generate_s": t_gen, "genome_hbm_bytes": genome.device_bytes, "index_build_ms": index_ms},
         }

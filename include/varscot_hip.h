@@ -115,8 +115,8 @@ typedef struct {
     uint32_t sort_fallbacks; /* sort levels that started without a histogram pass (fixed bin slots) and had to run again with
                                 one because a bin outgrew its slot (repeat-rich genomes; the genome remembers) */
     uint64_t list_entries;   /* VSC_ALGO_SEED: entries of the per-bucket read lists the last pass made (8 bytes each, padding included) */
-    uint32_t seed_cut;       /* VSC_ALGO_SEED: substitutions within which read segments 0 and 1 were searched (the third: what the
-                                site's PAM leaves of the limit - 2 x this - 2) */
+    uint32_t seed_cut;       /* VSC_ALGO_SEED: k0 | k1 << 4 - substitutions within which read segments 0 and 1 were searched (the third:
+                                what the site's PAM leaves of the limit - k0 - k1 - 2) */
     uint32_t reserved;
 } vsc_timing;
 

@@ -32,7 +32,7 @@ typedef struct {
     int32_t seed_shared;         /* -1 default; 0 / 1: one chunk per wave / one chunk per workgroup in seed_sliced_kernel */
     int32_t seed_group_out;      /* -1 default (on with chunk sharing); 0 / 1: per-wave / workgroup-shared open output blocks */
     int32_t seed_tight;          /* -1 default: segment thresholds follow what the site's PAM leaves of the limit, the cut chosen by the
-                                    cost model; 0: floor(m / 3) in all three; 1 + k: segments 0 and 1 within k substitutions (if that is a valid cut) */
+                                    cost model; 0: floor(m / 3) in all three; 1 + k0 + 3 k1: segments 0 / 1 within k0 / k1 substitutions (if that is a valid cut) */
     int32_t rf_form;             /* -1 default (the best node form the forest allows); 0: plain nodes; 1: at most the compact form; 2 = -1 */
     uint32_t reserved[1];
 } vsc_debug_params;

@@ -63,7 +63,7 @@ def one(ctx, seed):
         # sort knobs: smaller LDS capacity / fewer bits per level force partition levels and the oversize path
         hooks = {}
         for k, choices in (("sort_cap", [0, 0, 64, 1000]), ("sort_max_bits", [0, 0, 2, 5]), ("seed_reserve", [0, 64, 1024]),
-                           ("seed_shared", [-1, 0, 1, 1]), ("seed_group_out", [-1, 0, 1]), ("seed_tight", [-1, -1, 0, 1, 2, 3]),
+                           ("seed_shared", [-1, 0, 1, 1]), ("seed_group_out", [-1, 0, 1]), ("seed_tight", [-1, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9]),
                            ("sort_optimistic", [-1, -1, 0, 1]), ("sort_slot_cap", [0, 0, 24, 300])):
             hooks[k] = choices[int(rng.integers(0, len(choices)))]
         ctx.set_debug(**hooks)

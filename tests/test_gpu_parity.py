@@ -81,7 +81,7 @@ def test_seed_search_with_a_chunk_per_wave_and_per_workgroup(ctx, oracle, hooks,
     assert got.tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("tight", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("tight", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("shared", [0, 1])
 @pytest.mark.parametrize("seed,max_mm,extra_pam", [(301, 8, None), (302, 5, None), (303, 1, None), (304, 0, None),
                                                    (305, 6, "GT"), (306, 6, "AG"), (327, 7, "GA"), (308, 4, "TT"), (309, 3, None), (310, 2, "CG"), (311, 6, None), (312, 5, "GA")])
@@ -91,7 +91,8 @@ def test_seed_search_reads_that_mismatch_the_pam(ctx, oracle, hooks, tight, shar
     segment's neighbourhood follows what is left (SeedPlan).  Reads with every letter at positions 21 and 22, sites
     planted at every distance up to the limit, indexes with an extra PAM: the records are the oracle's, with the tight
     cut the cost model picks (default), with floor(m / 3) in all three segments (hook 0) and with every other valid
-    cut (hook 1 + k: segments 0 and 1 within k substitutions, the third within what is left)."""
+    cut (hook 1 + k0 + 3 k1: segments 0 / 1 within k0 / k1 substitutions, the third within what is left; cuts that are
+    not valid for the case fall back to the model's)."""
     hooks(seed_shared=shared, seed_tight=tight)
     rng = np.random.default_rng(seed)
     guides = [random_seq(rng, 21) + p for p in ("AG", "CG", "TG", "GG", "GA", "AA", "TC", "CT", "GT", "AG", "GG", "TA") for _ in range(6)]

@@ -1292,8 +1292,9 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         VSC_HIP_H(hipEventRecord(ctx->ev[7], ctx->stream));
     } else {
         // ---- per-bucket read lists: a counting sort of the reads' segment neighbourhoods over the buckets ------
-        // The cut of the pigeonhole (SeedPlan, vsc_internal.h): segments 0 and 1 within k01 substitutions, segment 2 within what the
-        // site's PAM class leaves of the limit - 2 k01 - 2.  Hook seed_tight = 0: floor(m / 3) everywhere (the round-3 cut).
+        // The cut of the pigeonhole (SeedPlan, vsc_internal.h): segment 0 within k0 substitutions, segment 1 within k1, segment 2
+        // within what the site's PAM class leaves of the limit - k0 - k1 - 2.  Hook seed_tight = 0: floor(m / 3) everywhere (the
+        // round-3 cut); 1 + k0 + 3 k1: that cut, if it is a valid one.
         const uint32_t m = params->max_mismatches;
         auto nbr = [](int k) { return k < 0 ? 0u : (k == 0 ? 1u : (k == 1 ? 22u : 211u)); };
         SeedPlan plan{};
@@ -1311,8 +1312,8 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         plan.tight = ctx->dbg.seed_tight != 0;
         int k2_max = 0;
         if (!plan.tight) {
-            plan.k01 = m / kSegments;
-            k2_max = (int)plan.k01;
+            plan.k0 = plan.k1 = m / kSegments;
+            k2_max = (int)plan.k0;
         } else {
             // reads per (class, what the class leaves them for positions 0..20)
             uint32_t left_reads[kSeedClasses][VSC_MAX_MISMATCHES + 1] = {};
@@ -1328,48 +1329,54 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
                     left_max = std::max(left_max, (int)(m - spent));
                 }
             }
-            // Every k01 in 0..2 that keeps the third threshold within two substitutions is a valid cut; they differ in what they
-            // cost.  Fewer buckets per read = fewer comparisons (what a dense search is bound by: c3), but a table whose lists
-            // are short still has nearly all of its chunks loaded for a read or two each (what a sparse search is bound by: at
-            // 1 000 reads and m = 6 the cut (2, 2, 0) compares 2.6 x the pairs of (1, 1, 2) and loads 17 % fewer blocks).
+            // Every (k0, k1) in 0..2 that keeps the third threshold within two substitutions is a valid cut; they differ in what
+            // they cost.  Fewer buckets per read = fewer comparisons (what a dense search is bound by: c3), but a table whose
+            // lists are short still has nearly all of its chunks loaded for a read or two each (what a sparse search is bound by:
+            // at 1 000 reads and m = 6 the cut (2, 2, 0) compares 2.6 x the pairs of (1, 1, 2) and loads 14 % fewer blocks).
             // cost = max(block bytes at 4.2 TB/s, chunk visits x 215 SIMD-cycles over all SIMDs at 2 GHz)
-            double cost[3] = {-1, -1, -1};  // < 0: not a valid cut
-            for (int k = 0; k <= 2; ++k) {
-                if (left_max - 2 * k - 2 > 2) continue;
-                double bytes = 0, visits = 0, chunks_all = 0, sites_all = 0;
-                uint64_t reads_any = 0;
-                for (uint32_t c = 0; c < plan.n_pam; ++c) {
-                    const double chunks_c = (double)genome->ix_class_chunks[c] / kSegments;
-                    chunks_all += chunks_c;
-                    sites_all += (double)genome->ix_class_sites[c];
-                    double e2 = 0;  // entries of class c's lists of segment 2
-                    uint64_t reads_c = 0;
-                    for (int left = 0; left <= (int)m; ++left) {
-                        e2 += (double)left_reads[c][left] * nbr(left - 2 * k - 2);
-                        reads_c += left_reads[c][left];
-                    }
-                    reads_any = std::max(reads_any, reads_c);
-                    const double per_list = e2 / kBucketsPerSeg;
-                    bytes += (1.0 - std::exp(-per_list)) * (double)genome->ix_class_sites[c] * kVertWords * 4 / kSlicedSites;
-                    visits += per_list * chunks_c;
-                }
-                const double per_list01 = (double)reads_any * nbr(k) / kBucketsPerSeg;
-                bytes += 2 * (1.0 - std::exp(-per_list01)) * sites_all * kVertWords * 4 / kSlicedSites;
-                visits += 2 * per_list01 * chunks_all;
-                cost[k] = std::max(bytes / 4.2e12, visits * 215.0 / ((double)ctx->n_cus * 4 * 2.0e9));
+            double cost[9];  // [k0 + 3 k1]; < 0: not a valid cut
+            double chunks_all = 0, sites_all = 0;
+            uint64_t reads_any = 0;
+            for (uint32_t c = 0; c < plan.n_pam; ++c) {
+                chunks_all += (double)genome->ix_class_chunks[c] / kSegments;
+                sites_all += (double)genome->ix_class_sites[c];
+                uint64_t reads_c = 0;
+                for (int left = 0; left <= (int)m; ++left) reads_c += left_reads[c][left];
+                reads_any = std::max(reads_any, reads_c);
             }
-            int best_k = -1;
-            for (int k = 0; k <= 2; ++k)
-                if (cost[k] >= 0 && (best_k < 0 || cost[k] < cost[best_k])) best_k = k;
-            const int forced = ctx->dbg.seed_tight >= 1 ? ctx->dbg.seed_tight - 1 : -1;  // hook: 1 + k01
-            if (forced >= 0 && forced <= 2 && cost[forced] >= 0) best_k = forced;
-            if (best_k < 0) best_k = (int)(m ? (m - 1) / kSegments : 0u);  // (no read can reach any class: nothing to search)
-            plan.k01 = (uint32_t)best_k;
-            k2_max = std::min<int>(2, (int)m - 2 * best_k - 2);
+            const double block_bytes = (double)kVertWords * 4 / kSlicedSites;  // per site
+            for (int cut = 0; cut < 9; ++cut) {
+                const int k0 = cut % 3, k1 = cut / 3;
+                cost[cut] = -1;
+                if (left_max - k0 - k1 - 2 > 2) continue;
+                double bytes = 0, visits = 0;
+                for (uint32_t c = 0; c < plan.n_pam; ++c) {
+                    double e2 = 0;  // entries of class c's lists of segment 2
+                    for (int left = 0; left <= (int)m; ++left) e2 += (double)left_reads[c][left] * nbr(left - k0 - k1 - 2);
+                    const double per_list = e2 / kBucketsPerSeg;
+                    bytes += (1.0 - std::exp(-per_list)) * (double)genome->ix_class_sites[c] * block_bytes;
+                    visits += per_list * (double)genome->ix_class_chunks[c] / kSegments;
+                }
+                for (int k : {k0, k1}) {  // segments 0 and 1: one list per bucket for all classes
+                    const double per_list = (double)reads_any * nbr(k) / kBucketsPerSeg;
+                    bytes += (1.0 - std::exp(-per_list)) * sites_all * block_bytes;
+                    visits += per_list * chunks_all;
+                }
+                cost[cut] = std::max(bytes / 4.2e12, visits * 215.0 / ((double)ctx->n_cus * 4 * 2.0e9));
+            }
+            int best = -1;
+            for (int cut = 0; cut < 9; ++cut)
+                if (cost[cut] >= 0 && (best < 0 || cost[cut] < cost[best])) best = cut;
+            const int forced = ctx->dbg.seed_tight >= 1 ? ctx->dbg.seed_tight - 1 : -1;  // hook: 1 + k0 + 3 k1
+            if (forced >= 0 && forced < 9 && cost[forced] >= 0) best = forced;
+            if (best < 0) best = 4 * (int)(m ? (m - 1) / kSegments : 0u);  // (no read can reach any class: nothing to search)
+            plan.k0 = (uint32_t)(best % 3);
+            plan.k1 = (uint32_t)(best / 3);
+            k2_max = std::min<int>(2, (int)m - (int)plan.k0 - (int)plan.k1 - 2);
         }
-        plan.n_nbr = nbr(std::max<int>((int)plan.k01, k2_max));
-        // entries: one per (read, neighbour within k01) of segments 0 and 1, one per class and neighbour of segment 2
-        const uint64_t n_pairs = (uint64_t)n_guides * (2 * nbr((int)plan.k01) + plan.n_pam * nbr(k2_max));
+        plan.n_nbr = nbr(std::max<int>(std::max<int>((int)plan.k0, (int)plan.k1), k2_max));
+        // entries: one per (read, neighbour within the threshold) of segments 0 and 1, one per class and neighbour of segment 2
+        const uint64_t n_pairs = (uint64_t)n_guides * (nbr((int)plan.k0) + nbr((int)plan.k1) + plan.n_pam * nbr(k2_max));
         const uint64_t list_cap = n_pairs + (uint64_t)kLists * (kGuideUnroll - 1) + 2 * kGuideUnroll;
         VSC_HIP_H(ctx->seed_off.ensure((kLists + 1) * sizeof(uint32_t)));
         VSC_HIP_H(ctx->seed_poff.ensure((kLists + 1) * sizeof(uint32_t)));
@@ -1388,7 +1395,8 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         sa.poff = (const uint32_t *)ctx->seed_poff.p;
         sa.max_mm = params->max_mismatches;
         sa.k_half = params->max_mismatches / 2;
-        sa.k_seg = plan.k01;
+        sa.k_seg0 = plan.k0;
+        sa.k_seg1 = plan.k1;
         sa.contig_end = genome->d_contig_end;
         sa.n_contigs = genome->n_contigs;
         sa.counters = (unsigned long long *)ctx->counters.p;
@@ -1398,7 +1406,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         // (c2: 13) keep a chunk per wave - see seed_sliced_kernel.  Measured at <= 8 mismatches (tools/
         // experiments.sh shared-threshold): 51 reads per bucket 12.1 vs 11.4 ms, 77: 15.9 vs 16.0, 103: 19.9 vs 20.7
         // (reads per list of segments 0 and 1 - and of segment 2 wherever it is searched as widely)
-        seed_shared = (uint64_t)n_guides * nbr((int)plan.k01) / kBucketsPerSeg >= 72;
+        seed_shared = (uint64_t)n_guides * nbr((int)std::max(plan.k0, plan.k1)) / kBucketsPerSeg >= 72;
         if (ctx->dbg.seed_shared >= 0) seed_shared = ctx->dbg.seed_shared == 1;
         const uint32_t n_grabs = (sa.n_chunks + kSlicedGrab - 1) / kSlicedGrab;
         const uint32_t n_waves_max = (uint32_t)ctx->n_cus * groups_per_cu * kWavesPerGroup;
@@ -1462,7 +1470,7 @@ int search_pass(vsc_ctx *ctx, const vsc_genome *genome, const uint64_t *guides, 
         t.passes++;
         if (algo == VSC_ALGO_SEED) {
             t.list_entries = list_total;
-            t.seed_cut = sa.k_seg;
+            t.seed_cut = sa.k_seg0 | (sa.k_seg1 << 4);
         }
         if (!cnt[kCntOverflow]) break;
         if (tries >= 2) return fail(ctx, VSC_ERR_DEVICE, "vsc_search: hit buffer overflowed repeatedly");

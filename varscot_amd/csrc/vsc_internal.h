@@ -222,12 +222,13 @@ struct ScoreArgs {
 };
 
 // How one search cuts the pigeonhole (seed_enum_kernel).  A site of class c (its PAM) leaves a read left_c = max_mm -
-// (mismatches of the read's last two letters with that PAM) for read positions 0..20.  Segments 0 and 1 are searched within
-// k01 substitutions, segment 2 within left_c - 2 k01 - 2 (none if negative): a window that fails all three has at least
-// (k01 + 1) + (k01 + 1) + (left_c - 2 k01 - 1) = left_c + 1 mismatches.  k01 = floor((max_mm - 1) / 3) keeps the third
-// threshold <= 2 for every max_mm <= 8.  tight = 0: the round-3 cut - floor(max_mm / 3) in all three segments.
+// (mismatches of the read's last two letters with that PAM) for read positions 0..20.  Segment 0 is searched within k0
+// substitutions, segment 1 within k1, segment 2 within left_c - k0 - k1 - 2 (not at all if negative): a window that fails all
+// three has at least (k0 + 1) + (k1 + 1) + (left_c - k0 - k1 - 1) = left_c + 1 mismatches.  Every (k0, k1) in 0..2 that keeps
+// the third threshold <= 2 is a valid cut; the host picks one by cost (vsc_api.cpp).  tight = 0: the round-3 cut -
+// floor(max_mm / 3) in all three segments.
 struct SeedPlan {
-    uint32_t max_mm, k01, tight;
+    uint32_t max_mm, k0, k1, tight;
     uint32_t n_nbr;      // neighbours enumerated per (read, segment): 1 / 22 / 211 = the largest threshold in use
     uint32_t n_pam;
     uint32_t pam_codes;  // class c: (first letter << 2 | second letter) << 4 c
@@ -243,7 +244,7 @@ struct SeedArgs {
     uint32_t n_chunks;
     const uint32_t *poff;          // [kLists + 1] first entry of every read list (multiples of kGuideUnroll)
     uint32_t max_mm, k_half;
-    uint32_t k_seg;                // substitutions searched in segments 0 and 1 (SeedPlan.k01): what the duplicate rule tests
+    uint32_t k_seg0, k_seg1;       // substitutions searched in segments 0 and 1 (SeedPlan.k0, .k1): what the duplicate rule tests
     const uint32_t *contig_end;
     uint32_t n_contigs;
     uint64_t *hit_recs;            // out: packed records (layout above), region p = [p * part_cap, (p + 1) * part_cap)

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uin
         const uint32_t spent = ((diff & 12u) ? 1u : 0u) + ((diff & 3u) ? 1u : 0u);
         if (spent + d > plan.max_mm) continue;
         const uint32_t left = plan.max_mm - spent;  // for read positions 0..20
-        const int thr = (s < 2 || !plan.tight) ? (int)plan.k01 : (int)left - 2 * (int)plan.k01 - 2;
+        const int thr = s == 0 ? (int)plan.k0 : (s == 1 ? (int)plan.k1 : (plan.tight ? (int)left - (int)plan.k0 - (int)plan.k1 - 2 : (int)plan.k0));
         if ((int)d > thr) continue;
         const uint32_t field = kListBudgetShift + 4 * c;
         if (s < 2) {
@@ -441,7 +441,7 @@ __device__ __forceinline__ void count7(const uint32_t *m, uint32_t &b0, uint32_t
 // first PAM letter had left it (round 3), 55 + 3 now that the chunk's class settles both PAM letters.
 template <uint32_t kSeg>
 __device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[kVertWords], uint32_t rx, uint32_t budget, uint32_t valid,
-                                                  const uint32_t (&kv)[2])
+                                                  const uint32_t (&kv)[4])
 {
     uint32_t mm[kCmpBases];
 #pragma unroll
@@ -461,11 +461,12 @@ __device__ __forceinline__ uint32_t sliced_within(const uint32_t (&v)[kVertWords
     le = bitop3<0x8E>(t2, spread(budget, 2), le);
     le = bitop3<0x8E>(k2, spread(budget, 3), le);
     uint32_t ok = le & valid;
-    // Not reported by an earlier segment's bucket: its group count > k_seg.  k_seg <= 2 (VSC_MAX_MISMATCHES / 3), so
-    // bit 2 of the count alone says "greater"; kv = bits 0 and 1 of k_seg, spread, in VECTOR registers: an instruction
+    // Not reported by an earlier segment's bucket: its group count > that segment's threshold.  A threshold is <= 2, so
+    // bit 2 of the count alone says "greater"; kv = bits 0 and 1 of the thresholds of segments 0 (kv[0], kv[1]) and 1 (kv[2],
+    // kv[3]), spread, in VECTOR registers: an instruction
     // with a scalar operand issues at 4.2 cycles per SIMD, with vector operands only at 2.6 (tools/micro/valu_rate.hip).
     if (kSeg >= 1) ok = bitop3<0xD0>(ok, a2, bitop3<0x8E>(a1, kv[1], ~a0 | kv[0]));  // ok & (a2 | ~le)
-    if (kSeg >= 2) ok = bitop3<0xD0>(ok, b2, bitop3<0x8E>(b1, kv[1], ~b0 | kv[0]));
+    if (kSeg >= 2) ok = bitop3<0xD0>(ok, b2, bitop3<0x8E>(b1, kv[3], ~b0 | kv[2]));  // (segment 2: group B = segment 1)
     return ok;
 }
 
@@ -797,9 +798,9 @@ __global__ __launch_bounds__(kWave *kWavesPerGroup) __attribute__((amdgpu_waves_
     for (uint32_t q = w.lane; q < (uint32_t)kParts; q += kWave) w.parts[q] = a.reserve;  // no block yet = a used-up one
 
     uint2 *const lt = s_list[wave];
-    uint32_t kv[2];  // bits 0 and 1 of k_seg, spread (the duplicate test of sliced_within)
+    uint32_t kv[4];  // bits 0 and 1 of the thresholds of segments 0 and 1, spread (the duplicate test of sliced_within)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(kv[i]) : "s"(spread(a.k_seg, i)));
+    for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(kv[i]) : "s"(spread(i < 2 ? a.k_seg0 : a.k_seg1, i & 1)));
     const const_v4u_ptr ctab = (const_v4u_ptr)(uintptr_t)a.chunk_tab;
     const const_u32_ptr poff = (const_u32_ptr)(uintptr_t)a.poff;
     const const_v8u_ptr lgrp = (const_v8u_ptr)(uintptr_t)a.list_rest;
