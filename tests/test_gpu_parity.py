@@ -81,6 +81,28 @@ def test_seed_search_with_a_chunk_per_wave_and_per_workgroup(ctx, oracle, hooks,
     assert got.tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("max_mm", range(0, 9))
+def test_seed_search_reports_a_valid_cut(ctx, oracle, hooks, max_mm):
+    """vsc_timing.seed_cut = k0 | k1 << 4: whatever the cost model (or a hook) picks must keep the third segment's threshold -
+    what the most generous PAM class leaves of the limit, less k0 + k1 + 2 - within two substitutions, and the records must be
+    the oracle's.  Reads that end in GG leave the whole limit against GG sites."""
+    rng = np.random.default_rng(900 + max_mm)
+    guides = random_guides(rng, 40, pam="GG")
+    contigs = make_genome(900 + max_mm, [50000, 30000], guides[:10], max_mm, n_plant=200, n_runs=2)
+    want = oracle.search_fast(contigs, guides, max_mm)
+    for hook in (-1, 0, 3, 7, 9):
+        hooks(seed_tight=hook)
+        got = gpu_search(ctx, contigs, guides, max_mm, algo="seed")
+        cut = ctx.timing()["seed_cut"]
+        k0, k1 = cut & 15, cut >> 4
+        assert k0 <= 2 and k1 <= 2
+        if hook == 0:
+            assert k0 == k1 == max_mm // 3
+        else:
+            assert max_mm - k0 - k1 - 2 <= 2
+        assert got.tobytes() == want.tobytes()
+
+
 @pytest.mark.parametrize("tight", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("shared", [0, 1])
 @pytest.mark.parametrize("seed,max_mm,extra_pam", [(301, 8, None), (302, 5, None), (303, 1, None), (304, 0, None),
