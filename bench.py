@@ -57,13 +57,18 @@ FOREST_CYCLES_PER_INSTRUCTION = 2.6
 
 
 def kernel_sources_sha():
-    """What the committed counters under profiles/ are keyed by: a hash of the kernels' sources.  A lookup made with other
-    kernels than the ones that were profiled prints null instead of a stale number."""
+    """What the committed counters under profiles/ are keyed by: a hash of the kernels' CODE - comments, blank lines and
+    trailing blanks aside, so that rewording a comment does not orphan a profile.  A lookup made with other kernels than the
+    ones that were profiled prints null instead of a stale number."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "varscot_amd", "csrc", name), "rb") as f:
-            h.update(name.encode() + b"\0" + f.read())
+        with open(os.path.join(ROOT, "varscot_amd", "csrc", name), "r") as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)  # (no string literal of these files holds a comment marker)
+        lines = [re.sub(r"//.*", "", ln).rstrip() for ln in text.split("\n")]
+        h.update(name.encode() + b"\0" + "\n".join(ln for ln in lines if ln.strip()).encode())
     return h.hexdigest()[:16]
 
 

@@ -19,8 +19,8 @@
 // any site is looked at: they come out of the budget, read positions 21 and 22 leave the comparison, and the
 // segments' thresholds follow what is LEFT for positions 0..20 (SeedPlan): a read that ends in GG meets the GA sites
 // with one mismatch spent, so their third segment is searched within one substitution instead of two (22 buckets
-// instead of 211) - 15 % fewer pairs at m = 8; at m = 6 the thresholds are (1, 1, 2) / (1, 1, 1) instead of (2, 2, 2):
-// a quarter of the pairs.
+// instead of 211) - 15 % fewer pairs at m = 8; at m = 6 thresholds like (1, 1, 2) / (1, 1, 1) or (0, 2, 2) / (0, 2, 1) stand
+// in for (2, 2, 2): a quarter to two thirds of the pairs, or a whole table left unloaded - the host picks by cost.
 //
 // seed_sliced_kernel compares bit-sliced: 32 sites per lane and instruction, only the 14 positions of the other two
 // segments are counted, the segment adds the list entry's known distance and the PAM the class's; hits are resolved
@@ -252,9 +252,9 @@ __global__ __launch_bounds__(256) void seed_enum_kernel(const uint2 *guides, uin
 }
 
 // poff[b] = sum over b' < b of roundup4(count[b']); the counts are cleared for pass 2; one workgroup, kLists + 1 outputs.
-// A wave owns 5 120 consecutive lists: 80 coalesced rows of 64, all loaded before the first is looked at; every row is scanned
-// across the lanes by six DPP adds (no LDS), the rows' totals are chained on the scalar unit, the waves' totals meet in
-// LDS once.  (Round 3's form - a thread summing its 48 consecutive counters one dependent, uncoalesced load after the
+// A wave owns 5 120 consecutive lists: 80 coalesced rows of 64, read twice (the second time from L2): first for the wave's
+// total - the waves' totals meet in LDS once -, then row by row, eight in flight: every row is scanned across the lanes by
+// six DPP adds (no LDS), the rows' totals are chained on the scalar unit.  (Round 3's form - a thread summing its 48 consecutive counters one dependent, uncoalesced load after the
 // other - took 0.17 ms: most of what a 1 000-read search spends on its lists.)
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
 {
