@@ -62,9 +62,12 @@ def read_sam(text, genome):
         if not line or line.startswith("@"):
             continue
         f = line.split("\t")
+        # a record that cannot be parsed ends the reading (SeqAn's exception, caught at :413-417: what was read is kept)
+        if len(f) < 11 or not (f[1].isdigit() and f[3].isdigit()) or int(f[3]) == 0:
+            break
         pos = int(f[3]) - 1
         strand = "-" if int(f[1]) & 16 else "+"
-        md = [x[5:] for x in f[11:] if x.startswith("MD:Z:")][-1]
+        md = ([x[5:] for x in f[11:] if x.startswith("MD:Z:")] or [""])[-1]
         out.append(Pot(f[0], f[2], pos, strand, genome.region(f[2], pos, pos + 23, strand), pyoracle.md_positions(md)))
     return out
 

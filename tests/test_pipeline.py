@@ -44,8 +44,13 @@ def read_fasta(path):
 
 @pytest.fixture(scope="module")
 def scenario(tmp_path_factory):
-    d = tmp_path_factory.mktemp("pipeline")
-    rng = np.random.default_rng(20240)
+    return build_scenario(tmp_path_factory.mktemp("pipeline"))
+
+
+def build_scenario(d, seed=20240):
+    """A small genome with on-targets, planted off-targets and variants next to them, written into directory d
+    (also what tests/test_mergers.py feeds the host tools with, from the oracle's SAM text)."""
+    rng = np.random.default_rng(seed)
     contigs = {"chr1": random_seq(rng, 30000), "chr2": random_seq(rng, 18000), "chrM": random_seq(rng, 3000)}
     # on-targets: 23-mers ending in GG taken from the genome (forward) or placed as reverse complement
     targets = []

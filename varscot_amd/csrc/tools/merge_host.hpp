@@ -121,7 +121,14 @@ inline std::vector<OffTarget> read_sam(const std::string &path, const Genome &ge
     if (!in) throw std::runtime_error("ERROR: Could not open BAM file.");
     std::vector<OffTarget> out;
     std::string line;
-    while (std::getline(in, line)) {
+    // A record that cannot be parsed ends the reading, as SeqAn's exception does in the reference (caught at :413-417: the
+    // message goes to stdout, the records read so far are kept and the tool carries on with them).
+    auto number = [](const std::string &s, unsigned long &v) {
+        char *end = nullptr;
+        v = std::strtoul(s.c_str(), &end, 10);
+        return !s.empty() && end && *end == '\0';
+    };
+    for (size_t line_no = 1; std::getline(in, line); ++line_no) {
         if (line.empty() || line[0] == '@') continue;
         std::vector<std::string> f;
         size_t b = 0;
@@ -131,12 +138,16 @@ inline std::vector<OffTarget> read_sam(const std::string &path, const Genome &ge
             if (e == std::string::npos) break;
             b = e + 1;
         }
-        if (f.size() < 11) continue;
+        unsigned long flag = 0, pos1 = 0;
+        if (f.size() < 11 || !number(f[1], flag) || !number(f[3], pos1) || pos1 == 0) {
+            std::cout << "Malformed alignment record in line " << line_no << " of " << path << ": reading stops here." << std::endl;
+            break;
+        }
         OffTarget p;
         p.target = f[0];
         p.chr = f[2];
-        p.pos = (uint32_t)(std::strtoul(f[3].c_str(), nullptr, 10) - 1);
-        p.strand = (std::strtoul(f[1].c_str(), nullptr, 10) & 16u) ? '-' : '+';
+        p.pos = (uint32_t)(pos1 - 1);
+        p.strand = (flag & 16u) ? '-' : '+';
         p.sequence = genome.region(p.chr, p.pos, p.pos + 23, p.strand);
         p.snp_type = "REF";
         std::string md;
