@@ -91,6 +91,15 @@ def test_tools_take_reference_bases_from_the_packed_genome(workdir):
     side, trace = outputs({}, "stem")
     assert trace.count("from the packed genome") == 2 and side == text
     os.remove(d / "g.vsc")
+    # a packed genome whose contig table points outside its planes (a damaged file with a valid stamp) is not trusted:
+    # the tools fall back to the FASTA text instead of reading past the mapping
+    raw = bytearray((d / "pk.vsc").read_bytes())
+    assert raw[:8] == b"VSCIDX02"
+    raw[40 + 24 + 8:40 + 24 + 12] = (0xFFFFFFF0).to_bytes(4, "little")   # the second contig's length
+    (d / "g.fa.vsc").write_bytes(bytes(raw))
+    bad, trace = outputs({}, "bad")
+    assert trace.count("from the FASTA text") == 2 and bad == text
+    os.remove(d / "g.fa.vsc")
     # the FASTA changes after packing (one base; the size stays): the packed genome is no longer taken
     seqs[0] = seqs[0][:511] + ("A" if seqs[0][511] != "A" else "C") + seqs[0][512:]
     write_fasta(d / "g.fa", names, seqs)

@@ -264,7 +264,11 @@ public:
             name_bytes += 4 + l;
         }
         if (v2) p += (8 - name_bytes % 8) % 8;
-        need(n_words * 12);
+        if (n_words > (uint64_t)(end - p) / 12) throw std::runtime_error("Truncated index " + path);
+        // (regions are clamped to their contig's length, bases() trusts the table: a contig must lie inside the planes)
+        for (const vsc_contig &c : contigs)
+            if ((uint64_t)c.offset > n_words * 32 || (uint64_t)c.length > n_words * 32 - (uint64_t)c.offset)
+                throw std::runtime_error("Corrupt contig table in " + path);
         if (((uintptr_t)p & 3u) == 0) {
             hi = (const uint32_t *)p;
             lo = hi + n_words;
