@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -387,7 +388,9 @@ int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides,
     std::condition_variable cv;
     std::vector<uint32_t> produced(n, 0);  // batches shard r has searched, scored and packed
     uint32_t transferred = 0;              // batches whose exchange slots have been read out
-    int failed = VSC_OK;
+    // (written under `mu`, which is what the waits re-check it under; atomic because this thread's loops also look at it between
+    // two waits, without the lock)
+    std::atomic<int> failed{VSC_OK};
     std::string why;
     std::vector<double> search_ms(n, 0), score_ms(n, 0);
     std::vector<uint64_t> shard_hits(n, 0);
@@ -504,7 +507,7 @@ int run_batches(vsc_multi *m, const vsc_multi_genome *g, const uint64_t *guides,
         std::vector<std::thread> &p;
         std::mutex &mu;
         std::condition_variable &cv;
-        int &failed;
+        std::atomic<int> &failed;
         bool done = false;
         ~Joiner()
         {
