@@ -6,7 +6,7 @@
 #   tsan   ThreadSanitizer build: vsc_windows_build (VCF parsed in chunks on all threads, blocks assembled independently, bit
 #          streams stitched at shared boundary words with atomics) and the tools' threaded packing (bidir_index)
 # Builds go to build/sanitize/ (not tracked); the log to profiles/<TAG>_sanitizers_cpu.txt.
-# vsc_multi.cpp's thread pool needs devices: its threads are covered by the GPU tests, not here.
+# vsc_multi.cpp's engine needs devices: its threads run under the sanitizers over a host stand-in, tools/multi_tsan/run.sh.
 set -o pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd); TAG=${TAG:-r04}; LOG=$ROOT/profiles/${TAG}_sanitizers_cpu.txt
 HIPCC=/opt/rocm/bin/hipcc; CXX=/opt/rocm/lib/llvm/bin/clang++
