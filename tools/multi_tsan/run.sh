@@ -1,6 +1,8 @@
 #!/bin/bash
-# run.sh - csrc/vsc_multi.cpp (the multi-device engine as it is shipped) linked with a host stand-in of the device layer and
-# run under ThreadSanitizer, then under AddressSanitizer + UBSan, on the CPU.  Builds in a temporary directory; the log goes to
+# run.sh - host code that needs a device, under the sanitizers on the CPU (GPU sanitizers are not available on this pool):
+#   1. csrc/vsc_multi.cpp (the multi-device engine as it is shipped) linked with a host stand-in of the device layer;
+#   2. the mergers (bam_merger_ref_only, bam_merger) linked with invented scores instead of the library's scoring calls.
+# ThreadSanitizer, then AddressSanitizer + UBSan.  Builds in a temporary directory; the log goes to
 # profiles/<TAG>_multi_tsan.txt.   usage: tools/multi_tsan/run.sh
 set -o pipefail
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../.." && pwd); TAG=${TAG:-r04}; LOG=$ROOT/profiles/${TAG}_multi_tsan.txt
@@ -14,6 +16,25 @@ for kind in thread address,undefined; do
         -pthread -ldl -o "$OUT/multi_$$" 2>&1 | grep -E "error" | head -5 | tee -a "$LOG"
     for rep in 1 2 3; do
         TSAN_OPTIONS=halt_on_error=0 ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 timeout 600 "$OUT/multi_$$" 2>&1 | tail -40 | tee -a "$LOG"
+    done
+done
+# ---- the mergers: their own host code (parsing, filters, coordinate restoration, threaded text) over invented scores ----------
+python3 "$HERE/make_merger_inputs.py" "$OUT/sc" 20240 > /dev/null || { echo "could not make the mergers' inputs" | tee -a "$LOG"; exit 1; }
+S=$OUT/sc
+for kind in address,undefined thread; do
+    echo "# -fsanitize=$kind: bam_merger_ref_only / bam_merger over tools/multi_tsan/stub_scores.cpp + csrc/vsc_pack.cpp (FASTA text and packed genomes, MIT / feature matrix / forest)" | tee -a "$LOG"
+    for t in bam_merger_ref_only bam_merger; do
+        $CXX $FLAGS -fsanitize=$kind -fno-sanitize-recover=undefined "$ROOT/varscot_amd/csrc/tools/$t.cpp" "$HERE/stub_scores.cpp" "$ROOT/varscot_amd/csrc/vsc_pack.cpp" \
+            -pthread -o "$OUT/$t" 2>&1 | grep -E "error" | head -5 | tee -a "$LOG"
+    done
+    for packed in "" "VARSCOT_PACKED_GENOME=$S/genome_idx VARSCOT_PACKED_SNP_GENOME=$S/snp_idx"; do
+        for mit in 0 1; do
+            env $packed TSAN_OPTIONS=halt_on_error=0 ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 VARSCOT_TRACE=1 "$OUT/bam_merger_ref_only" "$S/o1.txt" "$S/f1.txt" "$S/ref.sam" \
+                "$S/targets.bed" "$S/genome.fa" "$S/activity.txt" 5 23 $mit 2>&1 | grep -vE "^(Read|Filter|Write|Process|Merge|Compute|Calculate)" | tail -20 | tee -a "$LOG"
+            env $packed TSAN_OPTIONS=halt_on_error=0 ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 VARSCOT_TRACE=1 "$OUT/bam_merger" "$S/o2.txt" "$S/f2.txt" "$S/ref.sam" "$S/snp.sam" \
+                "$S/targets.bed" "$S/genome.fa" "$S/snp.fa" "$S/activity.txt" 5 23 2 $mit 2>&1 | grep -vE "^(Read|Filter|Write|Process|Merge|Compute|Calculate)" | tail -20 | tee -a "$LOG"
+            echo "rows: $(($(wc -l < "$S/o1.txt") - 1)) reference-only, $(($(wc -l < "$S/o2.txt") - 1)) merged (mit $mit${packed:+, packed genomes})" | tee -a "$LOG"
+        done
     done
 done
 grep -cE "ERROR: (Address|Leak)Sanitizer|runtime error:|WARNING: ThreadSanitizer|FAIL " "$LOG" | sed 's/^/sanitizer reports + failures: /' | tee -a "$LOG"
