@@ -173,3 +173,34 @@ def test_windows_from_planes_many_blocks(tmp_path):
     small = va.PackedGenome.from_sequences([genome["chrA"]], ["chrA"])
     with pytest.raises(va.VarscotError):
         va.variant_windows(small, tmp_path / "in.vcf", sample=0)
+
+
+def _unphased_cluster(genome_seq, first_pos, n):
+    """n unphased heterozygous SNPs at consecutive positions from first_pos (1-based) on contig c."""
+    lines = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS0"]
+    for i in range(n):
+        ref = genome_seq[first_pos - 1 + i]
+        lines.append("c\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT\t0/1" % (first_pos + i, ref, "A" if ref != "A" else "C"))
+    return "\n".join(lines) + "\n"
+
+
+def test_unphased_records_of_one_window_are_enumerated_up_to_a_limit(tmp_path):
+    """write_fasta.h:155-229 writes 2^n windows for n unphased records in one range.  Seven of them: 128 allele combinations per
+    range, both routes equal to the restatement; 25: the reference would hold 2^25 sequences in memory before writing one,
+    a streaming port would fill the disk - refused with a message by the tool and by vsc_windows_build."""
+    import varscot_amd as va
+    rng = np.random.default_rng(4242)
+    genome = {"c": random_seq(rng, 400)}
+    vcf = _unphased_cluster(genome["c"], 150, 7)
+    r, got = run_tool(tmp_path, vcf, genome, 0)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert got == vo.format_fasta(vo.vcf_loader(vcf, genome, 0, 23)) and got.count(">") >= 128
+    want = _fasta_route(tmp_path, vcf, genome, 0)
+    ref = va.PackedGenome.from_sequences(list(genome.values()), [n + " some description" for n in genome])
+    win = va.variant_windows(ref, tmp_path / "in.vcf", sample=0, threads=3)
+    assert list(win.names) == want.names and win.hi.tobytes() == want.hi.tobytes() and win.lo.tobytes() == want.lo.tobytes()
+    vcf = _unphased_cluster(genome["c"], 150, 25)
+    r, got = run_tool(tmp_path, vcf, genome, 0)
+    assert r.returncode == 1 and "25 unphased variants within one window" in r.stdout, r.stdout + r.stderr
+    with pytest.raises(Exception, match="25 unphased variants within one window"):
+        va.variant_windows(ref, tmp_path / "in.vcf", sample=0, threads=3)

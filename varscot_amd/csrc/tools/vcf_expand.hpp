@@ -34,6 +34,9 @@ struct Variant {
 
 using Record = std::vector<Variant>;  // the 1-2 variants of one VCF line
 
+// most unphased records one range may hold: 2^n windows are written for n of them (expand_range)
+constexpr size_t kMaxUnphasedInRange = 24;
+
 struct Chromosome {
     std::string name;
     std::vector<Record> records;  // in file order
@@ -388,6 +391,13 @@ inline void expand_range(const std::vector<Record> &recs, const std::vector<uint
         both();
         return;
     }
+    // 2^n windows for n unphased records in one range (write_fasta.h:155-229 enumerates them all - and keeps them in memory): a
+    // VCF with dozens of unphased calls inside one window would fill the disk (or the memory) before anything is searched, and
+    // 64 of them overflow the shift.  Such a range is refused.
+    if (unphased.size() > kMaxUnphasedInRange)
+        throw std::runtime_error("ERROR: " + std::to_string(unphased.size()) + " unphased variants within one window at " + chr + ":" +
+                                 std::to_string(center.pos + 1) + " (2^" + std::to_string(unphased.size()) + " allele combinations; the limit is 2^" +
+                                 std::to_string(kMaxUnphasedInRange) + ").");
     const uint64_t combos = 1ull << unphased.size();
     for (uint64_t mask = 0; mask < combos; ++mask) {
         for (size_t u = 0; u < unphased.size(); ++u) {
