@@ -1,7 +1,8 @@
 #!/bin/bash
 # run.sh - host code that needs a device, under the sanitizers on the CPU (GPU sanitizers are not available on this pool):
 #   1. csrc/vsc_multi.cpp (the multi-device engine as it is shipped) linked with a host stand-in of the device layer;
-#   2. the mergers (bam_merger_ref_only, bam_merger) linked with invented scores instead of the library's scoring calls.
+#   2. the mergers (bam_merger_ref_only, bam_merger) linked with invented scores instead of the library's scoring calls;
+#   3. varscot_pipeline with the real vsc_windows.cpp / vsc_pack.cpp over a brute-force host search and invented scores.
 # ThreadSanitizer, then AddressSanitizer + UBSan.  Builds in a temporary directory; the log goes to
 # profiles/<TAG>_multi_tsan.txt.   usage: tools/multi_tsan/run.sh
 set -o pipefail
@@ -37,4 +38,18 @@ for kind in address,undefined thread; do
         done
     done
 done
+# ---- varscot_pipeline (the driver's stages in one process): its own code + the real vsc_windows.cpp / vsc_pack.cpp over a brute-force
+# host search and invented scores (stub_search.cpp, stub_scores.cpp) -------------------------------------------------------------------
+for kind in address,undefined thread; do
+    echo "# -fsanitize=$kind: varscot_pipeline + csrc/vsc_windows.cpp + csrc/vsc_pack.cpp over tools/multi_tsan/{stub_search,stub_scores}.cpp" | tee -a "$LOG"
+    $CXX $FLAGS -fsanitize=$kind -fno-sanitize-recover=undefined "$ROOT/varscot_amd/csrc/tools/varscot_pipeline.cpp" "$HERE/stub_scores.cpp" "$HERE/stub_search.cpp" \
+        "$ROOT/varscot_amd/csrc/vsc_pack.cpp" "$ROOT/varscot_amd/csrc/vsc_windows.cpp" -pthread -o "$OUT/varscot_pipeline" 2>&1 | grep -E "error" | head -5 | tee -a "$LOG"
+    for args in "-e mit" "-e prob" "-e class -S 1" "-e mit -f $S/in.vcf -s 0 -t 3" "-e prob -f $S/in.vcf -s 0,0 -t 2 -p AG"; do
+        rm -f "$S"/vp*.txt
+        env TSAN_OPTIONS=halt_on_error=0 ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 VARSCOT_RF_MODEL="$ROOT/varscot_amd/models/rfClassifier.vscrf" \
+            "$OUT/varscot_pipeline" -b "$S/targets.bed" -g "$S/genome.fa" -i "$S/genome_idx" -o "$S/vp" -a "$S/activity.txt" -m 5 $args 2>&1 | tail -20 | tee -a "$LOG"
+        echo "varscot_pipeline ${args//$S\//}: $(cat "$S"/vp*.txt 2>/dev/null | grep -vc '^#') rows" | tee -a "$LOG"
+    done
+done
 grep -cE "ERROR: (Address|Leak)Sanitizer|runtime error:|WARNING: ThreadSanitizer|FAIL " "$LOG" | sed 's/^/sanitizer reports + failures: /' | tee -a "$LOG"
+cat "$HERE/NOTES.txt" >> "$LOG"

@@ -6,11 +6,8 @@
 // mismatch count in column 0), the product links libvarscot_hip.so and has no CPU path.
 #include <string>
 
+#include "stub_host.h"
 #include "varscot_hip.h"
-
-struct vsc_ctx {
-    std::string err;
-};
 
 extern "C" {
 int vsc_ctx_create(int, vsc_ctx **out)
