@@ -67,3 +67,20 @@ def test_mergers_rows_without_the_scores_equal_the_restatement(tmp_path, oracle,
     want = mo.merge_results(ref_sam, snp_sam, bed, records, snp_records, tus, 23, False)[0]
     assert without_scores((d / "merged.txt").read_text()) == without_scores(want)
     assert any(row[-1].startswith("VAR_") for row in without_scores(want)[1:])
+
+
+def test_the_shipped_mergers_have_no_cpu_path(tmp_path, oracle):
+    """The stand-in above is test scaffolding: the mergers as they are SHIPPED (varscot_amd/bin) score on the device and say so when
+    there is none - they do not fall back to anything.  (Skipped where a device is visible: tests/test_pipeline.py runs them there.)"""
+    import varscot_amd as va
+    if va.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    d, records, bed, tus, targets = build_scenario(tmp_path)
+    sam = oracle.search_sam([s for _, s in records], [n for n, _ in records], [t[4] for t in targets], [t[0] for t in targets], 4, None, 0)
+    (d / "ref.sam").write_text(sam)
+    r = subprocess.run([os.path.join(BIN, "bam_merger_ref_only"), str(d / "out.txt"), str(d / "feat.txt"), str(d / "ref.sam"), str(d / "targets.bed"),
+                        str(d / "genome.fa"), str(d / "activity.txt"), "4", "23", "0"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no HIP device available (there is no CPU fallback)" in r.stdout
+    # (and nothing of the stand-ins is part of the library or the tools)
+    makefile = open(os.path.join(CSRC, "Makefile")).read()
+    assert "multi_tsan" not in makefile and "stub_" not in makefile
