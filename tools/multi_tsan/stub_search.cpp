@@ -112,3 +112,5 @@ const char *vsc_multi_last_error(const vsc_multi *) { return "stub: one device o
 namespace vsc {
 bool host_timing_on() { return false; }  // (csrc/vsc_windows.cpp asks; defined in vsc_api.cpp in the library)
 }
+
+extern "C" vsc_ctx *vsc_multi_ctx(vsc_multi *, int) { return nullptr; }  // (bidir_mapping -D list: not part of these runs)
