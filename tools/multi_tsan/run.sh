@@ -50,6 +50,21 @@ for kind in address,undefined thread; do
             "$OUT/varscot_pipeline" -b "$S/targets.bed" -g "$S/genome.fa" -i "$S/genome_idx" -o "$S/vp" -a "$S/activity.txt" -m 5 $args 2>&1 | tail -20 | tee -a "$LOG"
         echo "varscot_pipeline ${args//$S\//}: $(cat "$S"/vp*.txt 2>/dev/null | grep -vc '^#') rows" | tee -a "$LOG"
     done
+    # bidir_mapping (reads, SAM order, MD strings, threaded SAM text) over the same stand-in search; classification_pipeline
+    # (feature matrix parsed back, Score column rewritten) over the invented votes
+    for t in bidir_mapping classification_pipeline; do
+        $CXX $FLAGS -fsanitize=$kind -fno-sanitize-recover=undefined "$ROOT/varscot_amd/csrc/tools/$t.cpp" "$HERE/stub_scores.cpp" "$HERE/stub_search.cpp" \
+            "$ROOT/varscot_amd/csrc/vsc_pack.cpp" "$ROOT/varscot_amd/csrc/vsc_windows.cpp" -pthread -o "$OUT/$t" 2>&1 | grep -E "error" | head -5 | tee -a "$LOG"
+    done
+    for style in 0 1; do
+        env TSAN_OPTIONS=halt_on_error=0 ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 "$OUT/bidir_mapping" -G "$S/genome.fa" -I "$S/genome_idx" -R "$S/targets.fa" -M 5 -T 4 \
+            -O "$S/bm.sam" --md-style $style 2>&1 | grep -vE "^(Reads loaded|Index loaded)" | tail -20 | tee -a "$LOG"
+        echo "bidir_mapping --md-style $style: $(wc -l < "$S/bm.sam") SAM records" | tee -a "$LOG"
+    done
+    "$OUT/bam_merger_ref_only" "$S/cp.txt" "$S/cp_feature_matrix.txt" "$S/ref.sam" "$S/targets.bed" "$S/genome.fa" "$S/activity.txt" 5 23 0 > /dev/null 2>&1
+    env TSAN_OPTIONS=halt_on_error=0 ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 VARSCOT_RF_MODEL="$ROOT/varscot_amd/models/rfClassifier.vscrf" \
+        "$OUT/classification_pipeline" "$S/cp.txt" "$S/cp_feature_matrix.txt" FALSE 2>&1 | tail -20 | tee -a "$LOG"
+    echo "classification_pipeline: $(grep -vc '^#' "$S/cp.txt") rows rewritten" | tee -a "$LOG"
 done
 grep -cE "ERROR: (Address|Leak)Sanitizer|runtime error:|WARNING: ThreadSanitizer|FAIL " "$LOG" | sed 's/^/sanitizer reports + failures: /' | tee -a "$LOG"
 cat "$HERE/NOTES.txt" >> "$LOG"
