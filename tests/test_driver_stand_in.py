@@ -83,3 +83,23 @@ def test_one_process_route_equals_the_staged_route_on_the_host_stand_ins(tmp_pat
         assert len(first) > 20
         if case in ("one", "two"):
             assert any(line.endswith("REF") for line in first[1:]) and any("VAR_" in line.split("\t")[-1] for line in first[1:])
+
+
+@pytest.mark.parametrize("seed", [20240, 7, 99])
+def test_sam_text_of_the_stand_in_mapping_equals_the_oracles(tmp_path, stand_in_bin, oracle, seed):
+    """bidir_mapping's own code - reads FASTA, packed genome, records in vsc_sam_order's order, flags (primary / secondary), NM and
+    MD of both styles, the text written on several threads - over the stand-in search: on these scenarios (no N runs, nothing at
+    a contig end, where the brute-force stand-in and the reference's rule would part) the hits are the oracle's, so the SAM text
+    must be the oracle's byte for byte.  (Not so on the SNP genome: its windows are short contigs, hits at their right end fall
+    under bidir_mapping.cpp:51-52, which the stand-in does not know - the real search against the oracle there is
+    tests/test_tools.py's and tests/test_gpu_parity.py's, on the GPU.)"""
+    d, records, bed, tus, targets = build_scenario(tmp_path, seed)
+    for fasta, recs in (("genome.fa", records),):
+        prefix = str(d / fasta.replace(".fa", "_idx"))
+        assert subprocess.run([os.path.join(BIN, "bidir_index"), "-G", str(d / fasta), "-I", prefix], capture_output=True).returncode == 0
+        for style in (0, 1):
+            r = subprocess.run([str(stand_in_bin / "bidir_mapping"), "-G", str(d / fasta), "-I", prefix, "-R", str(d / "targets.fa"), "-M", "5", "-T", "3",
+                                "-O", str(d / "out.sam"), "--md-style", str(style)], capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stdout + r.stderr
+            want = oracle.search_sam([s for _, s in recs], [n for n, _ in recs], [t[4] for t in targets], [t[0] for t in targets], 5, None, style)
+            assert (d / "out.sam").read_text() == want and len(want.splitlines()) > 10
