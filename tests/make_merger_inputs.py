@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Inputs for the mergers' sanitizer run (tools/multi_tsan/run.sh): the scenario of tests/test_pipeline.py written into
 DIR, the SNP genome made by the real vcf_loader, the two SAM files taken from the ORACLE's search (test infrastructure: the
-product's search needs the GPU), and a packed genome of each FASTA.   usage: make_merger_inputs.py DIR SEED"""
+product's search needs the GPU), and a packed genome of each FASTA.  Lives under tests/ because it calls the oracle (only
+tests/, smoke() and bench.py's cpu_baseline may).   usage: tests/make_merger_inputs.py DIR SEED"""
 import os
 import pathlib
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import pyoracle  # noqa: E402

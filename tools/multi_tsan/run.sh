@@ -20,7 +20,7 @@ for kind in thread address,undefined; do
     done
 done
 # ---- the mergers: their own host code (parsing, filters, coordinate restoration, threaded text) over invented scores ----------
-python3 "$HERE/make_merger_inputs.py" "$OUT/sc" 20240 > /dev/null || { echo "could not make the mergers' inputs" | tee -a "$LOG"; exit 1; }
+python3 "$ROOT/tests/make_merger_inputs.py" "$OUT/sc" 20240 > /dev/null || { echo "could not make the mergers' inputs" | tee -a "$LOG"; exit 1; }
 S=$OUT/sc
 for kind in address,undefined thread; do
     echo "# -fsanitize=$kind: bam_merger_ref_only / bam_merger over tools/multi_tsan/stub_scores.cpp + csrc/vsc_pack.cpp (FASTA text and packed genomes, MIT / feature matrix / forest)" | tee -a "$LOG"
@@ -61,7 +61,7 @@ for kind in address,undefined thread; do
             -O "$S/bm.sam" --md-style $style 2>&1 | grep -vE "^(Reads loaded|Index loaded)" | tail -20 | tee -a "$LOG"
         echo "bidir_mapping --md-style $style: $(wc -l < "$S/bm.sam") SAM records" | tee -a "$LOG"
     done
-    "$OUT/bam_merger_ref_only" "$S/cp.txt" "$S/cp_feature_matrix.txt" "$S/ref.sam" "$S/targets.bed" "$S/genome.fa" "$S/activity.txt" 5 23 0 > /dev/null 2>&1
+    "$OUT/bam_merger_ref_only" "$S/cp.txt" "$S/cp_feature_matrix.txt" "$S/ref.sam" "$S/targets.bed" "$S/genome.fa" "$S/activity.txt" 5 23 1 > /dev/null 2>&1
     env TSAN_OPTIONS=halt_on_error=0 ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 VARSCOT_RF_MODEL="$ROOT/varscot_amd/models/rfClassifier.vscrf" \
         "$OUT/classification_pipeline" "$S/cp.txt" "$S/cp_feature_matrix.txt" FALSE 2>&1 | tail -20 | tee -a "$LOG"
     echo "classification_pipeline: $(grep -vc '^#' "$S/cp.txt") rows rewritten" | tee -a "$LOG"
