@@ -9,6 +9,9 @@
                                             soft-masked and IUPAC stretches, several line widths): fasta_writer's two files == a
                                             restatement of extract_fasta_ontargets.h:33-76 written out here, from the FASTA text
                                             and from the packed genome
+    python tests/fuzz_cpu.py mergers [N]    the pipeline tests' scenario under N seeds: bam_merger_ref_only / bam_merger (built over invented
+                                            scores: their scoring runs on the device) on the oracle's SAM text - every column but the
+                                            score == the restatement of variant_processing/{merge_output_bam,filter_output_bam}.h
 """
 import os
 import pathlib
@@ -121,7 +124,50 @@ def ontargets(n):
     return fails
 
 
+def mergers(n):
+    """Scenarios of tests/test_pipeline.py under n seeds (on-targets, planted off-targets, SNPs / indels next to them), the oracle's
+    SAM text for the genome and for the SNP genome of the real vcf_loader, the two mergers built over invented scores
+    (tools/multi_tsan/stub_scores.cpp - their scoring runs on the device): every column but the score == oracle/merge_oracle.py."""
+    from oracle import merge_oracle as mo
+    from oracle import pyoracle
+    from test_pipeline import build_scenario, read_fasta
+    pyoracle.build()
+    csrc, stubs = os.path.join(ROOT, "varscot_amd", "csrc"), os.path.join(ROOT, "tools", "multi_tsan")
+    bin_dir = pathlib.Path(tempfile.mkdtemp(prefix="vsc_fuzz_bin_"))
+    for tool in ("bam_merger_ref_only", "bam_merger"):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-I" + stubs, os.path.join(csrc, "tools", tool + ".cpp"),
+                        os.path.join(stubs, "stub_scores.cpp"), os.path.join(csrc, "vsc_pack.cpp"), "-pthread", "-o", str(bin_dir / tool)], check=True)
+
+    def cut(tsv):
+        return [r.split("\t")[:4] + r.split("\t")[5:] for r in tsv.splitlines()]
+    fails, t0 = 0, time.time()
+    for seed in range(1, n + 1):
+        d = pathlib.Path(tempfile.mkdtemp(prefix="vsc_fuzz_"))
+        d, records, bed, tus, targets = build_scenario(d, seed)
+        subprocess.run([os.path.join(BIN, "vcf_loader"), str(d / "in.vcf"), str(d / "snp.fa"), str(d / "genome.fa"), "0", "23", "2"], check=True, capture_output=True)
+        snp_records = read_fasta(d / "snp.fa")
+        mm = 3 + seed % 3
+        sams = []
+        for recs, name in ((records, "ref.sam"), (snp_records, "snp.sam")):
+            sams.append(pyoracle.search_sam([s for _, s in recs], [x for x, _ in recs], [t[4] for t in targets], [t[0] for t in targets], mm, None, 0))
+            (d / name).write_text(sams[-1])
+        r1 = subprocess.run([str(bin_dir / "bam_merger_ref_only"), str(d / "o1.txt"), str(d / "f1.txt"), str(d / "ref.sam"), str(d / "targets.bed"), str(d / "genome.fa"),
+                             str(d / "activity.txt"), str(mm), "23", "0"], capture_output=True, text=True)
+        r2 = subprocess.run([str(bin_dir / "bam_merger"), str(d / "o2.txt"), str(d / "f2.txt"), str(d / "ref.sam"), str(d / "snp.sam"), str(d / "targets.bed"),
+                             str(d / "genome.fa"), str(d / "snp.fa"), str(d / "activity.txt"), str(mm), "23", "2", "0"], capture_output=True, text=True)
+        ok = (r1.returncode == 0 and r2.returncode == 0 and
+              cut((d / "o1.txt").read_text()) == cut(mo.process_ref_only(sams[0], bed, records, tus, False)[0]) and
+              cut((d / "o2.txt").read_text()) == cut(mo.merge_results(sams[0], sams[1], bed, records, snp_records, tus, 23, False)[0]))
+        if not ok:
+            fails += 1
+            print("FAIL seed", seed, r1.returncode, r2.returncode, flush=True)
+        if seed % 50 == 0:
+            print("%d / %d scenarios, %d failures, %d s" % (seed, n, fails, time.time() - t0), flush=True)
+    print("mergers fuzz: %d scenarios, %d failures" % (n, fails))
+    return fails
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "variants"
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
-    sys.exit(1 if {"variants": variants, "ontargets": ontargets}[what](count) else 0)
+    sys.exit(1 if {"variants": variants, "ontargets": ontargets, "mergers": mergers}[what](count) else 0)
