@@ -12,6 +12,8 @@
     python tests/fuzz_cpu.py mergers [N]    the pipeline tests' scenario under N seeds: bam_merger_ref_only / bam_merger (built over invented
                                             scores: their scoring runs on the device) on the oracle's SAM text - every column but the
                                             score == the restatement of variant_processing/{merge_output_bam,filter_output_bam}.h
+    python tests/fuzz_cpu.py routes [N]     driver/VARSCOT over stand-in builds of the device-bound tools: the one-process route's files ==
+                                            the staged route's, byte for byte, under N scenario seeds (mit / prob / class, one or all samples)
 """
 import os
 import pathlib
@@ -175,7 +177,50 @@ def mergers(n):
     return fails
 
 
+def routes(n):
+    """The driver's one-process route against its staged route (tests/test_driver_stand_in.py) under n scenario seeds, every other one
+    with a wild synthetic VCF: both over the stand-in builds of the device-bound tools, result files byte for byte."""
+    import test_driver_stand_in as ts
+    from test_pipeline import build_scenario
+
+    class Factory:
+        def mktemp(self, name):
+            return pathlib.Path(tempfile.mkdtemp(prefix="vsc_fuzz_" + name))
+    bin_dir = ts.stand_in_bin.__wrapped__(Factory()) if hasattr(ts.stand_in_bin, "__wrapped__") else None
+    driver = os.path.join(ROOT, "varscot_amd", "driver", "VARSCOT")
+    fails, t0 = 0, time.time()
+    for seed in range(1, n + 1):
+        tmp = pathlib.Path(tempfile.mkdtemp(prefix="vsc_fuzz_"))
+        d, records, bed, tus, targets = build_scenario(tmp, seed)
+        if seed % 2:
+            import test_variants as tv
+            rng = np.random.default_rng(seed)
+            (d / "in.vcf").write_text(tv.synth_vcf(seed, dict(records), int(rng.integers(40, 500)), n_samples=2, indel_rate=float(rng.choice([0.0, 0.3, 0.7])),
+                                                   cluster=bool(rng.integers(0, 2))))
+        evaluation = ["mit", "prob", "class"][seed % 3]
+        got = {}
+        for route in ("inproc", "staged"):
+            out = tmp / ("res_%s.txt" % route)
+            cmd = ["bash", driver, "-b", str(d / "targets.bed"), "-o", str(out), "-g", str(d / "genome.fa"), "-i", str(tmp / "idx"), "-m", str(3 + seed % 3),
+                   "-t", "2", "-T", str(tmp / ("tmp_" + route)), "-a", str(d / "activity.txt"), "-e", evaluation, "-f", str(d / "in.vcf"),
+                   "-s", "all" if seed % 2 else "0"]
+            env = dict(os.environ, VARSCOT_BIN=str(bin_dir), VARSCOT_RF_MODEL=os.path.join(ROOT, "varscot_amd", "models", "rfClassifier.vscrf"))
+            if route == "staged":
+                env["VARSCOT_STAGED"] = "1"
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+            files = {p.name.replace(route, ""): p.read_bytes() for p in sorted(tmp.glob("res_%s*.txt" % route))}
+            got[route] = (r.returncode, files)
+        refused = any("unphased variants within one window" in str(v) for v in got.values())
+        if got["inproc"] != got["staged"] or (got["inproc"][0] != 0 and not refused) or (got["inproc"][0] == 0 and not got["inproc"][1]):
+            fails += 1
+            print("FAIL seed", seed, evaluation, got["inproc"][0], got["staged"][0], sorted(got["inproc"][1]), sorted(got["staged"][1]), flush=True)
+        if seed % 25 == 0:
+            print("%d / %d scenarios, %d failures, %d s" % (seed, n, fails, time.time() - t0), flush=True)
+    print("routes fuzz: %d scenarios, %d failures" % (n, fails))
+    return fails
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "variants"
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
-    sys.exit(1 if {"variants": variants, "ontargets": ontargets, "mergers": mergers}[what](count) else 0)
+    sys.exit(1 if {"variants": variants, "ontargets": ontargets, "mergers": mergers, "routes": routes}[what](count) else 0)
