@@ -17,6 +17,7 @@
 """
 import os
 import pathlib
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -66,6 +67,7 @@ def variants(n):
             print("FAIL seed", seed, sizes, sample, indel, n_rec, flush=True)
         if (seed - 99) % 250 == 0:
             print("%d / %d configurations, %d failures, %d refused, %d s" % (seed - 99, n, fails, refused, time.time() - t0), flush=True)
+    shutil.rmtree(tmp, ignore_errors=True)
     print("variants fuzz: %d configurations, %d failures" % (n, fails))
     return fails
 
@@ -122,6 +124,7 @@ def ontargets(n):
                 fails += 1
                 print("FAIL seed", seed, mode, r.returncode, r.stdout[-200:], r.stderr[-200:], flush=True)
                 break
+    shutil.rmtree(d, ignore_errors=True)
     print("ontargets fuzz: %d configurations (FASTA text and packed genome), %d failures" % (n, fails))
     return fails
 
@@ -153,6 +156,7 @@ def mergers(n):
                                                    cluster=bool(rng.integers(0, 2))))
         vr = subprocess.run([os.path.join(BIN, "vcf_loader"), str(d / "in.vcf"), str(d / "snp.fa"), str(d / "genome.fa"), "0", "23", "2"], capture_output=True, text=True)
         if vr.returncode == 1 and "unphased variants within one window" in vr.stdout:
+            shutil.rmtree(d, ignore_errors=True)
             continue
         assert vr.returncode == 0, vr.stdout
         snp_records = read_fasta(d / "snp.fa")
@@ -171,8 +175,10 @@ def mergers(n):
         if not ok:
             fails += 1
             print("FAIL seed", seed, r1.returncode, r2.returncode, flush=True)
+        shutil.rmtree(d, ignore_errors=True)
         if seed % 50 == 0:
             print("%d / %d scenarios, %d failures, %d s" % (seed, n, fails, time.time() - t0), flush=True)
+    shutil.rmtree(bin_dir, ignore_errors=True)
     print("mergers fuzz: %d scenarios, %d failures" % (n, fails))
     return fails
 
@@ -214,8 +220,10 @@ def routes(n):
         if got["inproc"] != got["staged"] or (got["inproc"][0] != 0 and not refused) or (got["inproc"][0] == 0 and not got["inproc"][1]):
             fails += 1
             print("FAIL seed", seed, evaluation, got["inproc"][0], got["staged"][0], sorted(got["inproc"][1]), sorted(got["staged"][1]), flush=True)
+        shutil.rmtree(tmp, ignore_errors=True)
         if seed % 25 == 0:
             print("%d / %d scenarios, %d failures, %d s" % (seed, n, fails, time.time() - t0), flush=True)
+    shutil.rmtree(bin_dir, ignore_errors=True)
     print("routes fuzz: %d scenarios, %d failures" % (n, fails))
     return fails
 
